@@ -1,0 +1,161 @@
+/*
+ * include/mtg.h -- C-ABI of libmtg_hip.so, the MI355X (gfx950) engine behind
+ * mind_the_gaps' GP log-likelihood hot path.
+ *
+ * Every entry point replaces a piece of the reference's Python -> celerite
+ * interface (paths relative to /root/reference); the reference has no FFI of
+ * its own (celerite is a pybind11 dependency), so these are the functions a
+ * ctypes binding inside mind_the_gaps/gpmodelling.py would bind
+ * (INTEGRATION.md shows that stub).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative MTG_E_* code and never throws; the caller owns every
+ * pointer it passes, the library borrows it for the duration of the call;
+ * device buffers created by the library belong to the context.  One in-flight
+ * call per context; any number of contexts (one per process per GPU is the
+ * intended use).  All arithmetic is IEEE float64.
+ */
+#ifndef MTG_H
+#define MTG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTG_API __attribute__((visibility("default")))
+
+/* ---- error codes -------------------------------------------------------- */
+#define MTG_OK 0
+#define MTG_E_ARG (-1)       /* bad argument (message in mtg_last_error)        */
+#define MTG_E_NODEVICE (-2)  /* no usable gfx950 device / HIP runtime failure   */
+#define MTG_E_HIP (-3)       /* a HIP call failed                               */
+#define MTG_E_STATE (-4)     /* light curves or model not set yet               */
+#define MTG_E_UNSUPPORTED (-5) /* kernel structure outside the compiled table  */
+
+/* ---- per-evaluation status (status[b]) ----------------------------------- */
+#define MTG_ST_OK 0        /* lnP finite                                        */
+#define MTG_ST_PRIOR 1     /* log_prior = -inf: lnP = -inf, likelihood skipped
+                              (gpmodelling.py:149-151)                           */
+#define MTG_ST_NOTPD 2     /* non-positive pivot D_n: celerite raises
+                              LinAlgError here; lnP is written as -inf           */
+#define MTG_ST_NONFINITE 3 /* lnL or ln det not finite: celerite returns -inf   */
+
+/* ---- term kinds: celerite coefficient builders, evaluated on the device --- */
+#define MTG_TERM_REAL 0       /* celerite.terms.RealTerm(log_a, log_c)                  */
+#define MTG_TERM_COMPLEX3 1   /* celerite.terms.ComplexTerm(log_a, log_c, log_d), b = 0 */
+#define MTG_TERM_COMPLEX4 2   /* celerite.terms.ComplexTerm(log_a, log_b, log_c, log_d) */
+#define MTG_TERM_SHO 3        /* celerite.terms.SHOTerm(log_S0, log_Q, log_omega0)      */
+#define MTG_TERM_MATERN32 4   /* celerite.terms.Matern32Term(log_sigma, log_rho; eps)   */
+#define MTG_TERM_JITTER 5     /* celerite.terms.JitterTerm(log_sigma)                   */
+#define MTG_TERM_DRW 6        /* mind_the_gaps/models/celerite_models.py:55-68          */
+#define MTG_TERM_LORENTZIAN 7 /* mind_the_gaps/models/celerite_models.py:7-34           */
+#define MTG_TERM_COSINUS 8    /* mind_the_gaps/models/celerite_models.py:36-52          */
+#define MTG_TERM_BPL 9        /* mind_the_gaps/models/celerite_models.py:71-90          */
+#define MTG_N_TERM_KINDS 10
+
+#define MTG_MEAN_CONSTANT 0   /* celerite.modeling.ConstantModel(value)                 */
+#define MTG_MEAN_LINEAR 1     /* mind_the_gaps/models/mean_models.py:24-31 (slope, intercept) */
+
+#define MTG_MAX_TERMS 12
+#define MTG_MAX_PARAMS 40     /* full parameter vector: kernel + mean parameters        */
+#define MTG_MAX_J 10          /* celerite rank J = n_real + 2 n_complex                 */
+
+typedef struct mtg_ctx mtg_ctx;
+
+/* Library / device discovery.  mtg_device_count() < 0 means no HIP runtime. */
+MTG_API int mtg_device_count(void);
+MTG_API const char *mtg_version(void);
+MTG_API int mtg_term_nparams(int kind);
+
+/*
+ * Context = one GPU + its light curves + its model + workspaces.
+ * Replaces the per-process state the reference keeps in `self.gp`
+ * (gpmodelling.py:51-55) and copies into every multiprocessing.Pool worker
+ * (gpmodelling.py:245).  Returns NULL when `device` is not a usable GPU.
+ */
+MTG_API mtg_ctx *mtg_create(int device);
+MTG_API void mtg_destroy(mtg_ctx *ctx);
+/* Message for the last non-zero return on this context (ctx may be NULL for
+ * mtg_create failures). */
+MTG_API const char *mtg_last_error(const mtg_ctx *ctx);
+
+/*
+ * celerite.GP.compute(t, dy + 1e-12)  (gpmodelling.py:54) for L light curves
+ * at once.  t: [N] when t_per_lc == 0 (shared sampling, the PPP case of
+ * gpmodelling.py:538) or [L][N]; y, dy: [L][N], host pointers.  The library
+ * checks that every t row is sorted (celerite raises ValueError otherwise ->
+ * MTG_E_ARG), forms sigma^2 = (dy + 1e-12)^2 and dx_n = t_n - t_{n-1} on the
+ * device and keeps everything resident until the next call / mtg_destroy.
+ */
+MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
+                                const double *y, const double *dy);
+/* Same with DEVICE pointers (light curves born on the GPU); no sortedness
+ * check, the data are copied device-to-device on the context's stream. */
+MTG_API int mtg_set_lightcurves_device(mtg_ctx *ctx, int64_t N, int64_t L, const double *d_t,
+                                       int t_per_lc, const double *d_y, const double *d_dy);
+
+/*
+ * The model: what `celerite.GP(kernel, mean=..., fit_mean=...)`
+ * (gpmodelling.py:51) holds.  The FULL parameter vector is the kernel
+ * parameters of every term in `+` order followed by the mean parameters
+ * (1 for MTG_MEAN_CONSTANT, 2 for MTG_MEAN_LINEAR), PF entries in all.
+ *   kinds[nterms]      MTG_TERM_* tags
+ *   term_extra[nterms] per-term constant (Matern32Term eps), may be NULL
+ *   full_values[PF]    current value of every parameter (used for frozen ones)
+ *   free_index[P]      position in the full vector of each entry of theta,
+ *                      i.e. celerite's unfrozen-parameter order
+ *                      (get_parameter_vector, gpmodelling.py:55)
+ *   bounds[PF][2]      (lo, hi) of every parameter, +-inf for None
+ *                      (get_parameter_bounds(include_frozen=True))
+ */
+MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const double *term_extra,
+                          int mean_kind, int PF, const double *full_values, int P,
+                          const int32_t *free_index, const double *bounds);
+
+/*
+ * GPModelling._log_probability (gpmodelling.py:127-152; add_prior = 1) and
+ * -GPModelling._neg_log_like (gpmodelling.py:155-169; add_prior = 0) for B
+ * parameter vectors in one launch.  theta: [B][P] host; lc_index: [B] light
+ * curve of each row (NULL = all 0); out: [B] lnP; status: [B] MTG_ST_*.
+ * Replaces emcee's `pool.map(self._log_probability, coords)` (gpmodelling.py:247-248)
+ * and scipy's serial finite-difference calls (gpmodelling.py:192).
+ */
+MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index,
+                              int add_prior, double *out, int32_t *status);
+/*
+ * Same with DEVICE pointers, enqueued on `stream` (a hipStream_t passed as
+ * void*; NULL = the context's own stream) without synchronising: inputs stay
+ * resident in HBM, results are valid once the stream reaches this point.
+ */
+MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_theta,
+                                     const int32_t *d_lc_index, int add_prior, double *d_out,
+                                     int32_t *d_status, void *stream);
+
+/*
+ * celerite solver entry `compute(jitter, a_real, c_real, a_comp, b_comp, c_comp,
+ * d_comp, ...)` + log_likelihood for user-defined Python terms whose
+ * coefficients are evaluated on the host (celerite_models.py:9,17 override
+ * points).  All evaluations share one structure (jr real, jc complex terms).
+ * a_real..d_comp: [B][jr] / [B][jc] host, jitter: [B] (NULL = 0),
+ * mean_params: [B][1 or 2] (NULL = 0).
+ */
+MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const double *a_real,
+                               const double *c_real, const double *a_comp, const double *b_comp,
+                               const double *c_comp, const double *d_comp, const double *jitter,
+                               int mean_kind, const double *mean_params, const int32_t *lc_index,
+                               double *out, int32_t *status);
+
+/* Block until everything enqueued on the context's stream has finished. */
+MTG_API int mtg_synchronize(mtg_ctx *ctx);
+/* Device time (ms, HIP events on the launch stream) of the last
+ * mtg_loglike_batch / mtg_loglike_coeffs call: kernels only, no copies. */
+MTG_API double mtg_last_kernel_ms(const mtg_ctx *ctx);
+/* 1 if (jr, jc) has a compiled kernel. */
+MTG_API int mtg_structure_supported(int jr, int jc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTG_H */

@@ -1,0 +1,533 @@
+// mtg_capi.hip -- host side of the C-ABI declared in include/mtg.h.
+// One context = one MI355X + resident light curves + model + workspaces.
+#include "mtg_device.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4;  // grow with slack: batches vary between calls
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct mtg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+
+    // light curves (resident)
+    int64_t N = 0, L = 0;
+    int t_per_lc = 0;
+    DevBuf t, dx, y, var, dy_tmp;
+
+    // model
+    bool has_model = false;
+    MtgModel model;
+
+    // workspaces
+    DevBuf coef, lists, counts;
+    int64_t cstride = 0;
+    // staging for the host-pointer entry points
+    DevBuf theta, lc, out, status;
+};
+
+namespace {
+
+int fail(mtg_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail((ctx), MTG_E_HIP, "%s failed: %s", #call, hipGetErrorString(e__));   \
+    } while (0)
+
+int nparams(int kind)
+{
+    switch (kind) {
+    case MTG_TERM_REAL: return 2;
+    case MTG_TERM_COMPLEX3: return 3;
+    case MTG_TERM_COMPLEX4: return 4;
+    case MTG_TERM_SHO: return 3;
+    case MTG_TERM_MATERN32: return 2;
+    case MTG_TERM_JITTER: return 1;
+    case MTG_TERM_DRW: return 2;
+    case MTG_TERM_LORENTZIAN: return 3;
+    case MTG_TERM_COSINUS: return 2;
+    case MTG_TERM_BPL: return 3;
+    default: return -1;
+    }
+}
+
+int use_device(mtg_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return MTG_OK;
+}
+
+int reserve_workspace(mtg_ctx *ctx, int64_t B, int nslots, int nsig)
+{
+    // stride padded to a multiple of 64 so that every column starts 512-B aligned
+    int64_t stride = (B + 63) / 64 * 64;
+    if (stride < 64) stride = 64;
+    HIP_TRY(ctx, ctx->coef.reserve((size_t)stride * nslots * sizeof(double)));
+    HIP_TRY(ctx, ctx->lists.reserve((size_t)stride * (nsig > 1 ? nsig : 1) * sizeof(int)));
+    HIP_TRY(ctx, ctx->counts.reserve(64 * sizeof(int)));
+    ctx->cstride = stride;
+    return MTG_OK;
+}
+
+// Launch the solver(s) for B prepared evaluations living in ctx->coef.
+int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_t *d_lc,
+                    int add_prior, double *d_out, int32_t *d_status, hipStream_t s)
+{
+    const MtgModel &m = ctx->model;
+    const int nsig = m.nsho + 1;
+    MtgCoefLayout lay{m.nr_max, m.nc_max};
+    // every signature must have a compiled kernel (nr0 + 2k, nc0 - k)
+    for (int k = 0; k < nsig; ++k) {
+        const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
+        if (nr + nc == 0) continue;  // jitter-only model: handled by <0,0>? not supported
+        if (!mtg_find_solver(nr, nc))
+            return fail(ctx, MTG_E_UNSUPPORTED,
+                        "no compiled kernel for %d real + %d complex terms (J=%d)", nr, nc,
+                        nr + 2 * nc);
+    }
+    int rc = reserve_workspace(ctx, B, lay.nslots(), nsig);
+    if (rc) return rc;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+    if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
+
+    MtgPrepArgs pa;
+    pa.model = m;
+    pa.theta = d_theta;
+    pa.B = B;
+    pa.add_prior = add_prior;
+    pa.coef = ctx->coef.as<double>();
+    pa.cstride = ctx->cstride;
+    pa.nsig = nsig;
+    pa.lists = ctx->lists.as<int>();
+    pa.counts = ctx->counts.as<int>();
+    pa.out = d_out;
+    pa.status = d_status;
+    mtg_launch_prepare(pa, s);
+
+    MtgSolveArgs sa;
+    sa.coef = ctx->coef.as<double>();
+    sa.cstride = ctx->cstride;
+    sa.lay = lay;
+    sa.B = B;
+    sa.lc_index = d_lc;
+    sa.status = d_status;
+    sa.out = d_out;
+    sa.t = ctx->t.as<double>();
+    sa.dx = ctx->dx.as<double>();
+    sa.y = ctx->y.as<double>();
+    sa.var = ctx->var.as<double>();
+    sa.N = ctx->N;
+    sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
+    sa.mean_kind = m.mean_kind;
+    for (int k = 0; k < nsig; ++k) {
+        const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
+        mtg_solve_launcher fn = mtg_find_solver(nr, nc);
+        if (!fn) continue;
+        sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
+        sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
+        fn(sa, B, s);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+    ctx->timed = true;
+    return MTG_OK;
+}
+
+int check_ready(mtg_ctx *ctx, bool need_model)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (ctx->N <= 0) return fail(ctx, MTG_E_STATE, "mtg_set_lightcurves has not been called");
+    if (need_model && !ctx->has_model) return fail(ctx, MTG_E_STATE, "mtg_set_model has not been called");
+    return MTG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+MTG_API int mtg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+MTG_API const char *mtg_version(void) { return "mtg-hip 0.1 (gfx950)"; }
+
+MTG_API int mtg_term_nparams(int kind) { return nparams(kind); }
+
+MTG_API int mtg_structure_supported(int jr, int jc) { return mtg_find_solver(jr, jc) ? 1 : 0; }
+
+MTG_API mtg_ctx *mtg_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(nullptr, MTG_E_NODEVICE, "no HIP device available (%s)",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        fail(nullptr, MTG_E_ARG, "device %d out of range [0, %d)", device, n);
+        return nullptr;
+    }
+    mtg_ctx *ctx = new (std::nothrow) mtg_ctx();
+    if (!ctx) return nullptr;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        fail(nullptr, MTG_E_HIP, "could not create stream/events on device %d", device);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+MTG_API void mtg_destroy(mtg_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->t, &ctx->dx, &ctx->y, &ctx->var, &ctx->dy_tmp, &ctx->coef, &ctx->lists,
+                      &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status};
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+MTG_API const char *mtg_last_error(const mtg_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
+                                  const double *y, const double *dy, hipMemcpyKind kind)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (N <= 0 || L <= 0 || !t || !y || !dy)
+        return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, dy");
+    if (L * N > (int64_t)1 << 40) return fail(ctx, MTG_E_ARG, "light-curve set too large");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const int64_t t_rows = t_per_lc ? L : 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx->t.reserve((size_t)t_rows * N * 8));
+    HIP_TRY(ctx, ctx->dx.reserve((size_t)t_rows * N * 8));
+    HIP_TRY(ctx, ctx->y.reserve((size_t)L * N * 8));
+    HIP_TRY(ctx, ctx->var.reserve((size_t)L * N * 8));
+    HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)L * N * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->t.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->y.p, y, (size_t)L * N * 8, kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, dy, (size_t)L * N * 8, kind, ctx->stream));
+    mtg_launch_lc_setup(N, L, t_rows, ctx->t.as<double>(), ctx->dy_tmp.as<double>(),
+                        ctx->dx.as<double>(), ctx->var.as<double>(), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->N = N; ctx->L = L; ctx->t_per_lc = t_per_lc ? 1 : 0;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
+                                const double *y, const double *dy)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (N <= 0 || L <= 0 || !t || !y || !dy)
+        return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, dy");
+    // celerite.GP.compute raises ValueError for unsorted times
+    const int64_t t_rows = t_per_lc ? L : 1;
+    for (int64_t r = 0; r < t_rows; ++r)
+        for (int64_t n = 1; n < N; ++n)
+            if (!(t[r * N + n] >= t[r * N + n - 1]))
+                return fail(ctx, MTG_E_ARG, "the input coordinates must be sorted");
+    return set_lightcurves_common(ctx, N, L, t, t_per_lc, y, dy, hipMemcpyHostToDevice);
+}
+
+MTG_API int mtg_set_lightcurves_device(mtg_ctx *ctx, int64_t N, int64_t L, const double *d_t,
+                                       int t_per_lc, const double *d_y, const double *d_dy)
+{
+    return set_lightcurves_common(ctx, N, L, d_t, t_per_lc, d_y, d_dy, hipMemcpyDeviceToDevice);
+}
+
+MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const double *term_extra,
+                          int mean_kind, int PF, const double *full_values, int P,
+                          const int32_t *free_index, const double *bounds)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (nterms <= 0 || nterms > MTG_MAX_TERMS || !kinds)
+        return fail(ctx, MTG_E_ARG, "mtg_set_model: nterms must be in [1, %d]", MTG_MAX_TERMS);
+    if (mean_kind != MTG_MEAN_CONSTANT && mean_kind != MTG_MEAN_LINEAR)
+        return fail(ctx, MTG_E_ARG, "mtg_set_model: unknown mean kind %d", mean_kind);
+    MtgModel m;
+    memset(&m, 0, sizeof m);
+    m.nterms = nterms;
+    m.mean_kind = mean_kind;
+    int off = 0;
+    for (int i = 0; i < nterms; ++i) {
+        const int np = nparams(kinds[i]);
+        if (np < 0) return fail(ctx, MTG_E_ARG, "mtg_set_model: unknown term kind %d", kinds[i]);
+        m.kinds[i] = kinds[i];
+        m.poff[i] = off;
+        m.extra[i] = term_extra ? term_extra[i] : 0.01;
+        off += np;
+        switch (kinds[i]) {
+        case MTG_TERM_REAL: case MTG_TERM_DRW: m.nr0 += 1; break;
+        case MTG_TERM_JITTER: break;
+        case MTG_TERM_SHO: m.nc0 += 1; m.nsho += 1; break;
+        default: m.nc0 += 1; break;
+        }
+    }
+    m.nk = off;
+    const int nmean = mean_kind == MTG_MEAN_LINEAR ? 2 : 1;
+    if (PF != off + nmean)
+        return fail(ctx, MTG_E_ARG, "mtg_set_model: PF = %d but the terms + mean hold %d parameters",
+                    PF, off + nmean);
+    if (PF > MTG_MAX_PARAMS) return fail(ctx, MTG_E_ARG, "mtg_set_model: more than %d parameters", MTG_MAX_PARAMS);
+    if (P < 0 || P > PF || (P > 0 && !free_index) || !full_values)
+        return fail(ctx, MTG_E_ARG, "mtg_set_model: bad P / free_index / full_values");
+    m.PF = PF;
+    m.P = P;
+    for (int k = 0; k < PF; ++k) {
+        m.src[k] = -1;
+        m.defaults[k] = full_values[k];
+        m.lo[k] = bounds ? bounds[2 * k] : -INFINITY;
+        m.hi[k] = bounds ? bounds[2 * k + 1] : INFINITY;
+    }
+    for (int i = 0; i < P; ++i) {
+        if (free_index[i] < 0 || free_index[i] >= PF || m.src[free_index[i]] != -1)
+            return fail(ctx, MTG_E_ARG, "mtg_set_model: free_index[%d] = %d invalid or repeated", i,
+                        free_index[i]);
+        m.src[free_index[i]] = i;
+    }
+    m.nr_max = m.nr0 + 2 * m.nsho;
+    m.nc_max = m.nc0;
+    if (m.nr0 + m.nc0 == 0)
+        return fail(ctx, MTG_E_UNSUPPORTED, "mtg_set_model: the kernel has no real or complex term");
+    for (int k = 0; k <= m.nsho; ++k) {
+        const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
+        if (!mtg_find_solver(nr, nc))
+            return fail(ctx, MTG_E_UNSUPPORTED,
+                        "mtg_set_model: no compiled kernel for %d real + %d complex terms (J = %d > %d?)",
+                        nr, nc, nr + 2 * nc, MTG_MAX_J);
+    }
+    ctx->model = m;
+    ctx->has_model = true;
+    return MTG_OK;
+}
+
+MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_theta,
+                                     const int32_t *d_lc_index, int add_prior, double *d_out,
+                                     int32_t *d_status, void *stream)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!d_out || !d_status || (!d_theta && ctx->model.P > 0))))
+        return fail(ctx, MTG_E_ARG, "mtg_loglike_batch_device: bad arguments");
+    if (B == 0) return MTG_OK;
+    if (B > INT32_MAX) return fail(ctx, MTG_E_ARG, "batch too large");
+    rc = use_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return run_model_batch(ctx, B, d_theta, d_lc_index, add_prior, d_out, d_status, s);
+}
+
+MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index,
+                              int add_prior, double *out, int32_t *status)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!out || !status || (!theta && ctx->model.P > 0))))
+        return fail(ctx, MTG_E_ARG, "mtg_loglike_batch: bad arguments");
+    if (B == 0) return MTG_OK;
+    if (B > INT32_MAX) return fail(ctx, MTG_E_ARG, "batch too large");
+    if (lc_index)
+        for (int64_t b = 0; b < B; ++b)
+            if (lc_index[b] < 0 || lc_index[b] >= ctx->L)
+                return fail(ctx, MTG_E_ARG, "lc_index[%lld] = %d outside [0, %lld)", (long long)b,
+                            lc_index[b], (long long)ctx->L);
+    rc = use_device(ctx);
+    if (rc) return rc;
+    const int P = ctx->model.P;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, ctx->theta.reserve((size_t)B * (P > 0 ? P : 1) * 8));
+    HIP_TRY(ctx, ctx->out.reserve((size_t)B * 8));
+    HIP_TRY(ctx, ctx->status.reserve((size_t)B * 4));
+    if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->theta.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, s));
+    const int32_t *d_lc = nullptr;
+    if (lc_index) {
+        HIP_TRY(ctx, ctx->lc.reserve((size_t)B * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->lc.p, lc_index, (size_t)B * 4, hipMemcpyHostToDevice, s));
+        d_lc = ctx->lc.as<int32_t>();
+    }
+    rc = run_model_batch(ctx, B, ctx->theta.as<double>(), d_lc, add_prior, ctx->out.as<double>(),
+                         ctx->status.as<int32_t>(), s);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(status, ctx->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTG_OK;
+}
+
+MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const double *a_real,
+                               const double *c_real, const double *a_comp, const double *b_comp,
+                               const double *c_comp, const double *d_comp, const double *jitter,
+                               int mean_kind, const double *mean_params, const int32_t *lc_index,
+                               double *out, int32_t *status)
+{
+    int rc = check_ready(ctx, false);
+    if (rc) return rc;
+    if (B < 0 || jr < 0 || jc < 0 || (B > 0 && (!out || !status)))
+        return fail(ctx, MTG_E_ARG, "mtg_loglike_coeffs: bad arguments");
+    if ((jr > 0 && (!a_real || !c_real)) || (jc > 0 && (!a_comp || !b_comp || !c_comp || !d_comp)))
+        return fail(ctx, MTG_E_ARG, "mtg_loglike_coeffs: NULL coefficient array");
+    if (mean_kind != MTG_MEAN_CONSTANT && mean_kind != MTG_MEAN_LINEAR)
+        return fail(ctx, MTG_E_ARG, "mtg_loglike_coeffs: unknown mean kind %d", mean_kind);
+    if (B == 0) return MTG_OK;
+    if (B > INT32_MAX) return fail(ctx, MTG_E_ARG, "batch too large");
+    mtg_solve_launcher fn = mtg_find_solver(jr, jc);
+    if (!fn)
+        return fail(ctx, MTG_E_UNSUPPORTED, "no compiled kernel for %d real + %d complex terms", jr, jc);
+    if (lc_index)
+        for (int64_t b = 0; b < B; ++b)
+            if (lc_index[b] < 0 || lc_index[b] >= ctx->L)
+                return fail(ctx, MTG_E_ARG, "lc_index[%lld] = %d outside [0, %lld)", (long long)b,
+                            lc_index[b], (long long)ctx->L);
+    rc = use_device(ctx);
+    if (rc) return rc;
+    MtgCoefLayout lay{jr, jc};
+    rc = reserve_workspace(ctx, B, lay.nslots(), 1);
+    if (rc) return rc;
+    const int64_t cs = ctx->cstride;
+    hipStream_t s = ctx->stream;
+    // host-side transpose [B][j] -> SoA columns, then one upload
+    const int nmean = mean_kind == MTG_MEAN_LINEAR ? 2 : 1;
+    double *h = (double *)malloc((size_t)cs * lay.nslots() * 8);
+    if (!h) return fail(ctx, MTG_E_ARG, "out of host memory");
+    memset(h, 0, (size_t)cs * lay.nslots() * 8);
+    for (int64_t b = 0; b < B; ++b) {
+        double asum = jitter ? jitter[b] : 0.0;
+        for (int j = 0; j < jr; ++j) {
+            h[lay.ar(j) * cs + b] = a_real[b * jr + j];
+            h[lay.cr(j) * cs + b] = c_real[b * jr + j];
+            asum += a_real[b * jr + j];
+        }
+        for (int k = 0; k < jc; ++k) {
+            h[lay.ac(k) * cs + b] = a_comp[b * jc + k];
+            h[lay.bc(k) * cs + b] = b_comp[b * jc + k];
+            h[lay.cc(k) * cs + b] = c_comp[b * jc + k];
+            h[lay.dc(k) * cs + b] = d_comp[b * jc + k];
+            asum += a_comp[b * jc + k];
+        }
+        h[lay.asum() * cs + b] = asum;
+        h[lay.mean(0) * cs + b] = mean_params ? mean_params[b * nmean] : 0.0;
+        h[lay.mean(1) * cs + b] = (mean_params && nmean == 2) ? mean_params[b * nmean + 1] : 0.0;
+    }
+    hipError_t e = hipMemcpyAsync(ctx->coef.p, h, (size_t)cs * lay.nslots() * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    free(h);
+    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "coefficient upload failed: %s", hipGetErrorString(e));
+    HIP_TRY(ctx, ctx->out.reserve((size_t)B * 8));
+    HIP_TRY(ctx, ctx->status.reserve((size_t)B * 4));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->status.p, 0, (size_t)B * 4, s));
+    const int32_t *d_lc = nullptr;
+    if (lc_index) {
+        HIP_TRY(ctx, ctx->lc.reserve((size_t)B * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->lc.p, lc_index, (size_t)B * 4, hipMemcpyHostToDevice, s));
+        d_lc = ctx->lc.as<int32_t>();
+    }
+    MtgSolveArgs sa;
+    sa.coef = ctx->coef.as<double>();
+    sa.cstride = cs;
+    sa.lay = lay;
+    sa.list = nullptr;
+    sa.count_ptr = nullptr;
+    sa.B = B;
+    sa.lc_index = d_lc;
+    sa.status = ctx->status.as<int32_t>();
+    sa.out = ctx->out.as<double>();
+    sa.t = ctx->t.as<double>();
+    sa.dx = ctx->dx.as<double>();
+    sa.y = ctx->y.as<double>();
+    sa.var = ctx->var.as<double>();
+    sa.N = ctx->N;
+    sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
+    sa.mean_kind = mean_kind;
+    ctx->timed = true;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+    fn(sa, B, s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(status, ctx->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTG_OK;
+}
+
+MTG_API int mtg_synchronize(mtg_ctx *ctx)
+{
+    if (!ctx) return MTG_E_ARG;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MTG_OK;
+}
+
+MTG_API double mtg_last_kernel_ms(const mtg_ctx *ctx)
+{
+    if (!ctx || !ctx->timed) return -1.0;
+    float ms = -1.0f;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// mtg_device.h -- data structures shared by the host side of the C-ABI and the
+// gfx950 kernels.  Written for MI355X (CDNA4, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mtg.h"
+
+// What celerite.GP(kernel, mean, fit_mean) holds (reference gpmodelling.py:51),
+// flattened so that it travels as a kernel argument (scalar loads only).
+struct MtgModel {
+    int nterms;
+    int mean_kind;
+    int PF;      // full parameter vector length (kernel + mean)
+    int P;       // free parameters = length of one theta row
+    int nk;      // kernel parameters (mean parameters start here)
+    int nsho;    // SHOTerm count: each may expand to 1 complex or 2 real terms
+    int nr0, nc0;        // structure with every SHO under-damped (Q >= 1/2)
+    int nr_max, nc_max;  // widest real / complex expansion (workspace layout)
+    int kinds[MTG_MAX_TERMS];
+    int poff[MTG_MAX_TERMS];
+    int src[MTG_MAX_PARAMS];  // theta column feeding full[k], or -1 = frozen
+    double defaults[MTG_MAX_PARAMS];
+    double lo[MTG_MAX_PARAMS];
+    double hi[MTG_MAX_PARAMS];
+    double extra[MTG_MAX_TERMS];
+};
+
+// Coefficient workspace: structure-of-arrays, one column per evaluation so that
+// lane e reads/writes coef[slot * stride + e] (coalesced).  Slots:
+//   a_real[nr_max] c_real[nr_max] a_comp[nc_max] b_comp[nc_max] c_comp[nc_max]
+//   d_comp[nc_max] asum(= sum a + jitter) mean0 mean1
+struct MtgCoefLayout {
+    int nr_max, nc_max;
+    __host__ __device__ int ar(int j) const { return j; }
+    __host__ __device__ int cr(int j) const { return nr_max + j; }
+    __host__ __device__ int ac(int k) const { return 2 * nr_max + k; }
+    __host__ __device__ int bc(int k) const { return 2 * nr_max + nc_max + k; }
+    __host__ __device__ int cc(int k) const { return 2 * nr_max + 2 * nc_max + k; }
+    __host__ __device__ int dc(int k) const { return 2 * nr_max + 3 * nc_max + k; }
+    __host__ __device__ int asum() const { return 2 * nr_max + 4 * nc_max; }
+    __host__ __device__ int mean(int i) const { return 2 * nr_max + 4 * nc_max + 1 + i; }
+    __host__ __device__ int nslots() const { return 2 * nr_max + 4 * nc_max + 3; }
+};
+
+struct MtgPrepArgs {
+    MtgModel model;
+    const double *theta;  // [B][P]
+    int64_t B;
+    int add_prior;
+    double *coef;
+    int64_t cstride;
+    int nsig;       // number of structure signatures (nsho + 1); 1 = identity mapping
+    int *lists;     // [nsig][cstride] evaluation indices grouped by signature
+    int *counts;    // [nsig]
+    double *out;    // [B]
+    int32_t *status;  // [B]
+};
+
+struct MtgSolveArgs {
+    const double *coef;
+    int64_t cstride;
+    MtgCoefLayout lay;
+    const int *list;       // NULL = identity mapping
+    const int *count_ptr;  // NULL = B
+    int64_t B;
+    const int32_t *lc_index;  // NULL = light curve 0
+    int32_t *status;
+    double *out;
+    const double *t;    // [N] or [L][N]
+    const double *dx;   // same shape, dx[0] = 0
+    const double *y;    // [L][N]
+    const double *var;  // [L][N]  (dy + 1e-12)^2
+    int64_t N;
+    int64_t t_stride;  // 0 (shared sampling) or N
+    int mean_kind;
+};
+
+typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStream_t);
+// Table lookup of the compiled <NR, NC> instantiations (mtg_kernels.hip).
+mtg_solve_launcher mtg_find_solver(int nr, int nc);
+void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
+void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *dy,
+                         double *dx, double *var, hipStream_t);

@@ -1,0 +1,234 @@
+"""ctypes binding of libmtg_hip.so (C-ABI: include/mtg.h).
+
+This is the only door between the Python host code and the MI355X kernels.
+There is no CPU fallback: if the shared library or a GPU is missing, every
+entry point raises (``EngineUnavailable``) -- a likelihood is never computed
+on the host.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtg_hip.so")
+
+# term kinds / mean kinds / status codes: numerically identical to include/mtg.h
+TERM_REAL, TERM_COMPLEX3, TERM_COMPLEX4, TERM_SHO, TERM_MATERN32, TERM_JITTER, \
+    TERM_DRW, TERM_LORENTZIAN, TERM_COSINUS, TERM_BPL = range(10)
+MEAN_CONSTANT, MEAN_LINEAR = 0, 1
+ST_OK, ST_PRIOR, ST_NOTPD, ST_NONFINITE = 0, 1, 2, 3
+E_ARG, E_NODEVICE, E_HIP, E_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
+
+EXPORTS = (
+    "mtg_device_count", "mtg_version", "mtg_term_nparams", "mtg_create", "mtg_destroy",
+    "mtg_last_error", "mtg_set_lightcurves", "mtg_set_lightcurves_device", "mtg_set_model",
+    "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
+    "mtg_last_kernel_ms", "mtg_structure_supported",
+)
+
+
+class EngineUnavailable(RuntimeError):
+    """libmtg_hip.so is not built, or no MI355X is visible."""
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mtg error %d: %s" % (code, message))
+        self.code = code
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_lib = None
+
+
+def load_library():
+    """dlopen libmtg_hip.so and declare the prototypes (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mind_the_gaps_amd/csrc`" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # e.g. libamdhip64 missing
+        raise EngineUnavailable("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+    lib.mtg_device_count.restype = c_int
+    lib.mtg_version.restype = ctypes.c_char_p
+    lib.mtg_term_nparams.restype = c_int
+    lib.mtg_term_nparams.argtypes = [c_int]
+    lib.mtg_create.restype = c_vp
+    lib.mtg_create.argtypes = [c_int]
+    lib.mtg_destroy.restype = None
+    lib.mtg_destroy.argtypes = [c_vp]
+    lib.mtg_last_error.restype = ctypes.c_char_p
+    lib.mtg_last_error.argtypes = [c_vp]
+    lib.mtg_set_lightcurves.restype = c_int
+    lib.mtg_set_lightcurves.argtypes = [c_vp, c_i64, c_i64, _dp, c_int, _dp, _dp]
+    lib.mtg_set_lightcurves_device.restype = c_int
+    lib.mtg_set_lightcurves_device.argtypes = [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_vp]
+    lib.mtg_set_model.restype = c_int
+    lib.mtg_set_model.argtypes = [c_vp, c_int, _ip, _dp, c_int, c_int, _dp, c_int, _ip, _dp]
+    lib.mtg_loglike_batch.restype = c_int
+    lib.mtg_loglike_batch.argtypes = [c_vp, c_i64, _dp, _ip, c_int, _dp, _ip]
+    lib.mtg_loglike_batch_device.restype = c_int
+    lib.mtg_loglike_batch_device.argtypes = [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
+    lib.mtg_loglike_coeffs.restype = c_int
+    lib.mtg_loglike_coeffs.argtypes = [c_vp, c_i64, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                       _dp, c_int, _dp, _ip, _dp, _ip]
+    lib.mtg_synchronize.restype = c_int
+    lib.mtg_synchronize.argtypes = [c_vp]
+    lib.mtg_last_kernel_ms.restype = ctypes.c_double
+    lib.mtg_last_kernel_ms.argtypes = [c_vp]
+    lib.mtg_structure_supported.restype = c_int
+    lib.mtg_structure_supported.argtypes = [c_int, c_int]
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load_library().mtg_device_count())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _iptr(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+class Engine:
+    """One MI355X with resident light curves and a model (an ``mtg_ctx``)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = self._lib.mtg_create(int(device))
+        if not self._ctx:
+            raise EngineUnavailable(
+                "mtg_create(%d) failed: %s" % (device, self._lib.mtg_last_error(None).decode()))
+        self.device = int(device)
+        self.N = 0
+        self.L = 0
+        self.P = None
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.mtg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self._lib.mtg_last_error(self._ctx).decode())
+
+    # -- data ---------------------------------------------------------------
+    def set_lightcurves(self, t, y, dy):
+        """t: [N] (shared sampling) or [L][N]; y, dy: [N] or [L][N]."""
+        y = np.atleast_2d(_f64(y))
+        dy = np.atleast_2d(_f64(dy))
+        t = _f64(t)
+        L, N = y.shape
+        if dy.shape != (L, N):
+            raise ValueError("y and dy must have the same shape")
+        t_per_lc = 0
+        if t.ndim == 2:
+            if t.shape == (L, N) and L > 1:
+                t_per_lc = 1
+            elif t.shape[1] == N and t.shape[0] == 1:
+                t = t[0]
+            else:
+                raise ValueError("t must be [N] or [L][N]")
+        if t.ndim == 1 and t.shape[0] != N:
+            raise ValueError("t and y lengths differ")
+        rc = self._lib.mtg_set_lightcurves(self._ctx, N, L, _ptr(np.ascontiguousarray(t)), t_per_lc,
+                                           _ptr(y), _ptr(dy))
+        if rc == E_ARG and b"sorted" in self._lib.mtg_last_error(self._ctx):
+            raise ValueError("the input coordinates must be sorted")  # celerite GP.compute wording
+        self._check(rc)
+        self.N, self.L = N, L
+
+    def set_lightcurves_device(self, N, L, t_ptr, y_ptr, dy_ptr, t_per_lc=False):
+        self._check(self._lib.mtg_set_lightcurves_device(self._ctx, N, L, t_ptr, int(bool(t_per_lc)),
+                                                         y_ptr, dy_ptr))
+        self.N, self.L = int(N), int(L)
+
+    def set_model(self, kinds, full_values, free_index, bounds, mean_kind=MEAN_CONSTANT, extra=None):
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        full_values = _f64(full_values)
+        free_index = np.ascontiguousarray(free_index, dtype=np.int32)
+        bounds = _f64(bounds).reshape(-1, 2)
+        if bounds.shape[0] != full_values.shape[0]:
+            raise ValueError("bounds must hold one (lo, hi) pair per full parameter")
+        extra_ = _f64(extra) if extra is not None else None
+        self._check(self._lib.mtg_set_model(self._ctx, len(kinds), _iptr(kinds), _ptr(extra_),
+                                            int(mean_kind), len(full_values), _ptr(full_values),
+                                            len(free_index), _iptr(free_index), _ptr(bounds)))
+        self.P = len(free_index)
+
+    # -- evaluation ---------------------------------------------------------
+    def loglike(self, theta, lc_index=None, add_prior=True):
+        """theta: [B][P] -> (lnP[B], status[B])."""
+        theta = np.atleast_2d(_f64(theta))
+        B = theta.shape[0]
+        if self.P is None:
+            raise EngineError(E_STATE, "set_model has not been called")
+        if theta.shape[1] != self.P:
+            raise ValueError("theta has %d columns, the model has %d free parameters"
+                             % (theta.shape[1], self.P))
+        lc = None if lc_index is None else np.ascontiguousarray(lc_index, dtype=np.int32)
+        if lc is not None and lc.shape != (B,):
+            raise ValueError("lc_index must have one entry per theta row")
+        out = np.empty(B, dtype=np.float64)
+        status = np.empty(B, dtype=np.int32)
+        self._check(self._lib.mtg_loglike_batch(self._ctx, B, _ptr(theta), _iptr(lc),
+                                                int(bool(add_prior)), _ptr(out), _iptr(status)))
+        return out, status
+
+    def loglike_device(self, B, theta_ptr, lc_ptr, out_ptr, status_ptr, add_prior=True, stream=None):
+        """Raw device pointers (ints); asynchronous on ``stream`` (int, hipStream_t)."""
+        self._check(self._lib.mtg_loglike_batch_device(self._ctx, int(B), theta_ptr, lc_ptr,
+                                                       int(bool(add_prior)), out_ptr, status_ptr,
+                                                       stream))
+
+    def loglike_coeffs(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=None,
+                       mean_kind=MEAN_CONSTANT, mean_params=None, lc_index=None):
+        """Raw celerite coefficients [B][jr] / [B][jc] evaluated on the host."""
+        a_real, c_real = np.atleast_2d(_f64(a_real)), np.atleast_2d(_f64(c_real))
+        a_comp, b_comp = np.atleast_2d(_f64(a_comp)), np.atleast_2d(_f64(b_comp))
+        c_comp, d_comp = np.atleast_2d(_f64(c_comp)), np.atleast_2d(_f64(d_comp))
+        B = max(a_real.shape[0], a_comp.shape[0])
+        jr = a_real.shape[1] if a_real.size else 0
+        jc = a_comp.shape[1] if a_comp.size else 0
+        jit = _f64(jitter) if jitter is not None else None
+        mp = np.atleast_2d(_f64(mean_params)) if mean_params is not None else None
+        lc = None if lc_index is None else np.ascontiguousarray(lc_index, dtype=np.int32)
+        out = np.empty(B, dtype=np.float64)
+        status = np.empty(B, dtype=np.int32)
+        self._check(self._lib.mtg_loglike_coeffs(
+            self._ctx, B, jr, jc, _ptr(a_real) if jr else None, _ptr(c_real) if jr else None,
+            _ptr(a_comp) if jc else None, _ptr(b_comp) if jc else None,
+            _ptr(c_comp) if jc else None, _ptr(d_comp) if jc else None, _ptr(jit),
+            int(mean_kind), _ptr(mp), _iptr(lc), _ptr(out), _iptr(status)))
+        return out, status
+
+    def synchronize(self):
+        self._check(self._lib.mtg_synchronize(self._ctx))
+
+    @property
+    def last_kernel_ms(self):
+        return float(self._lib.mtg_last_kernel_ms(self._ctx))

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One MI355X context shared by the GPU parity tests (fails loudly without a GPU)."""
+    from mind_the_gaps_amd.engine import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()
