@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- celerite log-likelihood evaluations/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (per GPU, weak scaling): BASELINE.json configs[3], the Protassov
+posterior-predictive sweep -- L = 2000 simulated light curves sharing one
+irregular sampling (N = 10 000), W = 256 walkers each, alternative model
+DRW + SHO + Lorentzian (celerite rank J = 6, P = 8 free parameters).  One step =
+one full-ensemble sweep = L x W = 512 000 log-probability evaluations through
+mtg_loglike_batch_device (prior + coefficients + fused Cholesky/solve), with
+t, y, sigma^2 and theta already resident in HBM.  No collective is needed on
+the data path (independent light curves); ranks only agree on the timing.
+
+The JSON line also carries
+  roofline     : algorithmic bytes (24 N + 8 P + 12 per evaluation, SURVEY.md
+                 section 8(d)) / mean duration of the dominant kernel
+                 (mtg_solve_kernel<1,2>), HIP events on the launch stream;
+  cpu_baseline : oracle/celerite_ref.c (a plain-C port of celerite's algorithm)
+                 on the host cores of this box, bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10000, help="samples per light curve")
+    ap.add_argument("--lightcurves", type=int, default=2000)
+    ap.add_argument("--walkers", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="time box of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 hardware threads but grants a 16-CPU quota)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(t, y, dy, kinds, theta, mean_value, seconds):
+    """oracle/celerite_ref.c on all usable host cores, same inputs, bounded sample."""
+    from oracle import celerite as oracle_c
+    cores = usable_cores()
+    oracle_c.lib()
+    L = y.shape[0]
+    chunk = max(cores * 32, 64)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        idx = (np.arange(chunk) + done) % theta.shape[0]
+        full = np.hstack([theta[idx], np.full((chunk, 1), mean_value)])
+        lc = (idx // (theta.shape[0] // L)).astype(np.int32) % L
+        oracle_c.logprob_batch(t, y, dy, kinds, full, lc_index=lc, nthreads=cores)
+        done += chunk
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": done / el, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "%d evaluations of the same workload (N=%d, J=6) in %.1f s, OpenMP over %d "
+                      "threads, oracle/celerite_ref.c" % (done, len(t), el, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mind_the_gaps_amd import synthetic as synth
+    from mind_the_gaps_amd.engine import Engine
+
+    N, L, W = args.n, args.lightcurves, args.walkers
+    kinds = synth.ALT_MODEL
+    P = len(synth.truth(kinds))
+    B = L * W
+    # seed = 20250704 + config index; every rank owns different light curves
+    t, y, dy = synth.make_lightcurves(N, L, seed=20250704 + 4 + 1000 * rank)
+    theta = synth.draw_thetas(kinds, B, seed=20250704 + 40 + 1000 * rank)
+    full, free, bounds = synth.model_spec(kinds, y)
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+
+    eng = Engine(local_rank)
+    eng.set_lightcurves(t, y, dy)          # uploaded once; resident for the whole run
+    eng.set_model(kinds, full, free, bounds)
+    d_theta = torch.from_numpy(theta).to(dev)
+    d_lc = torch.from_numpy(lc).to(dev)
+    d_out = torch.empty(B, dtype=torch.float64, device=dev)
+    d_status = torch.empty(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        eng.loglike_device(B, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(),
+                           d_status.data_ptr(), add_prior=True, stream=stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prep_ms, solve_ms = eng.profile_read()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity: every evaluation finite or prior-rejected, and a spot check of the values
+    status = d_status.cpu().numpy()
+    out = d_out.cpu().numpy()
+    n_ok = int((status == 0).sum())
+    if not np.all(np.isfinite(out[status == 0])) or n_ok < B // 2:
+        raise SystemExit("bench: non-finite log-likelihoods in the timed batch")
+
+    if rank == 0:
+        bytes_eval = 24 * N + 8 * P + 12
+        solve_s = float(np.mean(solve_ms)) * 1e-3
+        achieved = n_ok * bytes_eval / solve_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("N") == N and rec.get("B") == B:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "celerite log-likelihood evals/sec (N=1e4, J=6)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[3] per GPU: Protassov PPP sweep, %d light curves x %d "
+                            "walkers = %d evals/step, alt model DRW+SHO+Lorentzian (J=6, P=%d), "
+                            "N=%d irregular samples" % (L, W, B, P, N),
+                "N": N, "J": 6, "P": P, "lightcurves_per_gpu": L, "walkers": W,
+                "evals_per_step_per_gpu": B, "sharding": "light curves across ranks, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "mtg_solve_kernel<1,2>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_eval": bytes_eval,
+                "evals_per_launch": n_ok,
+                "kernel_ms": solve_s * 1e3,
+                "prepare_kernel_ms": float(np.mean(prep_ms)),
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, full[-1], args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,15 @@ MTG_API int mtg_synchronize(mtg_ctx *ctx);
 /* Device time (ms, HIP events on the launch stream) of the last
  * mtg_loglike_batch / mtg_loglike_coeffs call: kernels only, no copies. */
 MTG_API double mtg_last_kernel_ms(const mtg_ctx *ctx);
+/*
+ * Per-call kernel timing for the next `capacity` mtg_loglike_batch[_device]
+ * calls: HIP events are recorded on the launch stream before the prepare
+ * kernel, between prepare and the solve kernel(s), and after them.
+ * mtg_profile_read waits for the recorded calls, writes their durations (ms)
+ * and returns how many were recorded (<= capacity), ending the session.
+ */
+MTG_API int mtg_profile_begin(mtg_ctx *ctx, int capacity);
+MTG_API int mtg_profile_read(mtg_ctx *ctx, int capacity, double *prepare_ms, double *solve_ms);
 /* 1 if (jr, jc) has a compiled kernel. */
 MTG_API int mtg_structure_supported(int jr, int jc);
 

@@ -9,6 +9,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -58,6 +59,10 @@ struct mtg_ctx {
     int64_t cstride = 0;
     // staging for the host-pointer entry points
     DevBuf theta, lc, out, status;
+
+    // per-call kernel timing (mtg_profile_*): event triples start / solve / end
+    std::vector<hipEvent_t> prof_ev;
+    int prof_cap = 0, prof_n = 0;
 };
 
 namespace {
@@ -134,7 +139,10 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     int rc = reserve_workspace(ctx, B, lay.nslots(), nsig);
     if (rc) return rc;
 
+    const bool prof = ctx->prof_n < ctx->prof_cap;
+    hipEvent_t *pe = prof ? &ctx->prof_ev[3 * (size_t)ctx->prof_n] : nullptr;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+    if (prof) HIP_TRY(ctx, hipEventRecord(pe[0], s));
     if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
 
     MtgPrepArgs pa;
@@ -150,6 +158,7 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     pa.out = d_out;
     pa.status = d_status;
     mtg_launch_prepare(pa, s);
+    if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
 
     MtgSolveArgs sa;
     sa.coef = ctx->coef.as<double>();
@@ -176,6 +185,10 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+    if (prof) {
+        HIP_TRY(ctx, hipEventRecord(pe[2], s));
+        ctx->prof_n += 1;
+    }
     ctx->timed = true;
     return MTG_OK;
 }
@@ -239,6 +252,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     DevBuf *bufs[] = {&ctx->t, &ctx->dx, &ctx->y, &ctx->var, &ctx->dy_tmp, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status};
     for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -519,6 +533,38 @@ MTG_API int mtg_synchronize(mtg_ctx *ctx)
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MTG_OK;
+}
+
+MTG_API int mtg_profile_begin(mtg_ctx *ctx, int capacity)
+{
+    if (!ctx || capacity < 0) return MTG_E_ARG;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    while ((int)ctx->prof_ev.size() < 3 * capacity) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->prof_ev.push_back(e);
+    }
+    ctx->prof_cap = capacity;
+    ctx->prof_n = 0;
+    return MTG_OK;
+}
+
+MTG_API int mtg_profile_read(mtg_ctx *ctx, int capacity, double *prepare_ms, double *solve_ms)
+{
+    if (!ctx || capacity < 0) return MTG_E_ARG;
+    const int n = ctx->prof_n < capacity ? ctx->prof_n : capacity;
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t *pe = &ctx->prof_ev[3 * (size_t)i];
+        float a = 0.f, b = 0.f;
+        HIP_TRY(ctx, hipEventSynchronize(pe[2]));
+        HIP_TRY(ctx, hipEventElapsedTime(&a, pe[0], pe[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, pe[1], pe[2]));
+        if (prepare_ms) prepare_ms[i] = a;
+        if (solve_ms) solve_ms[i] = b;
+    }
+    ctx->prof_cap = 0;
+    return n;
 }
 
 MTG_API double mtg_last_kernel_ms(const mtg_ctx *ctx)

@@ -24,7 +24,7 @@ EXPORTS = (
     "mtg_device_count", "mtg_version", "mtg_term_nparams", "mtg_create", "mtg_destroy",
     "mtg_last_error", "mtg_set_lightcurves", "mtg_set_lightcurves_device", "mtg_set_model",
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
-    "mtg_last_kernel_ms", "mtg_structure_supported",
+    "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
 )
 
 
@@ -84,6 +84,10 @@ def load_library():
     lib.mtg_synchronize.argtypes = [c_vp]
     lib.mtg_last_kernel_ms.restype = ctypes.c_double
     lib.mtg_last_kernel_ms.argtypes = [c_vp]
+    lib.mtg_profile_begin.restype = c_int
+    lib.mtg_profile_begin.argtypes = [c_vp, c_int]
+    lib.mtg_profile_read.restype = c_int
+    lib.mtg_profile_read.argtypes = [c_vp, c_int, _dp, _dp]
     lib.mtg_structure_supported.restype = c_int
     lib.mtg_structure_supported.argtypes = [c_int, c_int]
     _lib = lib
@@ -225,6 +229,21 @@ class Engine:
             _ptr(c_comp) if jc else None, _ptr(d_comp) if jc else None, _ptr(jit),
             int(mean_kind), _ptr(mp), _iptr(lc), _ptr(out), _iptr(status)))
         return out, status
+
+    def profile_begin(self, capacity):
+        """Record HIP-event timings of the next ``capacity`` batch calls."""
+        self._check(self._lib.mtg_profile_begin(self._ctx, int(capacity)))
+        self._prof_cap = int(capacity)
+
+    def profile_read(self):
+        """-> (prepare_ms[n], solve_ms[n]) of the calls recorded since profile_begin."""
+        cap = getattr(self, "_prof_cap", 0)
+        prep = np.zeros(cap)
+        solve = np.zeros(cap)
+        n = self._lib.mtg_profile_read(self._ctx, cap, _ptr(prep), _ptr(solve))
+        if n < 0:
+            self._check(n)
+        return prep[:n], solve[:n]
 
     def synchronize(self):
         self._check(self._lib.mtg_synchronize(self._ctx))

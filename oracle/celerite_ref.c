@@ -274,7 +274,10 @@ ORACLE_API int oracle_logprob_batch(long N, long L, const double *t, const doubl
 #pragma omp parallel num_threads(nthreads)
 #endif
     {
-        double *work = (double *)malloc(sizeof(double) * (size_t)(4 * 32 + 1) * (size_t)N);
+        int jmax = 0; /* widest expansion: 2 slots per SHO/complex, 3 for Lorentzian */
+        for (int i = 0; i < nterms; ++i) jmax += kinds[i] == K_LORENTZIAN ? 3 : 2;
+        if (jmax > 32) jmax = 32;
+        double *work = (double *)malloc(sizeof(double) * (size_t)(4 * jmax + 1) * (size_t)N);
         double ar[24], cr[24], ac[12], bc[12], cc[12], dc[12];
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)

@@ -4,7 +4,7 @@ observed ~1e-13."""
 import numpy as np
 import pytest
 
-import synth
+from mind_the_gaps_amd import synthetic as synth
 from oracle import celerite as oracle_c
 from oracle import dense
 
