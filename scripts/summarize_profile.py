@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (scripts/profile_bench.sh) -> profiles/<tag>_* summaries.
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE
+and WRITE_SIZE come from separate --pmc passes, are in KiB, and on gfx950
+FETCH_SIZE tallies 128-B requests at 64 B, so the read side is doubled.  The
+doubling is calibrated in the same run on mtg_lc_setup_kernel, whose byte count
+is known (it reads dy[L*N] + t[N] and writes var[L*N] + dx[N]).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+W = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+
+
+def mean_counter(sub, counter):
+    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+fetch = mean_counter("pmc_fetch", "FETCH_SIZE")
+write = mean_counter("pmc_write", "WRITE_SIZE")
+rows = []
+for k in sorted(set(fetch) | set(write)):
+    f, nf = fetch.get(k, (0.0, 0))
+    w, nw = write.get(k, (0.0, 0))
+    rows.append({"kernel": k, "launches": max(nf, nw), "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w,
+                 "hbm_read_bytes_corrected": 2.0 * f * 1024.0, "hbm_write_bytes": w * 1024.0})
+with open(os.path.join(dst, tag + "_pmc_hbm.csv"), "w", newline="") as fh:
+    wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
+    wr.writeheader()
+    wr.writerows(rows)
+
+setup = [r for r in rows if r["kernel"].startswith("mtg_lc_setup_kernel")][0]
+known_read = (L * N + N) * 8.0
+known_write = (L * N + N) * 8.0
+solve = max((r for r in rows if "mtg_solve_kernel" in r["kernel"]),
+            key=lambda r: r["hbm_read_bytes_corrected"])
+rec = {
+    "tag": tag, "N": N, "B": L * W, "kernel": solve["kernel"],
+    "hbm_bytes_per_launch": solve["hbm_read_bytes_corrected"] + solve["hbm_write_bytes"],
+    "hbm_read_bytes_per_launch": solve["hbm_read_bytes_corrected"],
+    "hbm_write_bytes_per_launch": solve["hbm_write_bytes"],
+    "algorithmic_bytes_per_launch": L * W * (24 * N + 8 * 8 + 12),
+    "calibration": {
+        "kernel": "mtg_lc_setup_kernel", "known_read_bytes": known_read,
+        "FETCH_SIZE_x1024": setup["FETCH_SIZE_KiB_raw"] * 1024.0,
+        "read_ratio_raw": setup["FETCH_SIZE_KiB_raw"] * 1024.0 / known_read,
+        "known_write_bytes": known_write, "WRITE_SIZE_x1024": setup["WRITE_SIZE_KiB_raw"] * 1024.0,
+        "write_ratio_raw": setup["WRITE_SIZE_KiB_raw"] * 1024.0 / known_write,
+    },
+    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); "
+            "separate --pmc passes; per-launch means",
+}
+json.dump(rec, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(dst, "bench_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(rec, indent=1))
+print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
