@@ -1,0 +1,56 @@
+"""CPU tests of the drop-in boundary: libmtg_hip.so loads, exports every symbol
+include/mtg.h declares, and fails loudly (never falls back) without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mtg.h")).read()
+    return sorted(set(re.findall(r"MTG_API\s+[\w\s\*]+?\b(mtg_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = engine.load_library()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "include/mtg.h declares %s but libmtg_hip.so does not export it" % n
+    assert sorted(engine.EXPORTS) == names
+
+
+def test_constants_match_header():
+    text = open(os.path.join(ROOT, "include", "mtg.h")).read()
+    defs = dict(re.findall(r"#define\s+(MTG_\w+)\s+\(?(-?\d+)\)?", text))
+    for name, value in (("MTG_TERM_REAL", engine.TERM_REAL), ("MTG_TERM_SHO", engine.TERM_SHO),
+                        ("MTG_TERM_DRW", engine.TERM_DRW), ("MTG_TERM_LORENTZIAN", engine.TERM_LORENTZIAN),
+                        ("MTG_TERM_COSINUS", engine.TERM_COSINUS), ("MTG_TERM_BPL", engine.TERM_BPL),
+                        ("MTG_TERM_MATERN32", engine.TERM_MATERN32), ("MTG_TERM_JITTER", engine.TERM_JITTER),
+                        ("MTG_MEAN_LINEAR", engine.MEAN_LINEAR), ("MTG_ST_NOTPD", engine.ST_NOTPD),
+                        ("MTG_ST_PRIOR", engine.ST_PRIOR), ("MTG_E_UNSUPPORTED", engine.E_UNSUPPORTED)):
+        assert int(defs[name]) == value, name
+
+
+def test_pure_queries_need_no_gpu():
+    lib = engine.load_library()
+    assert lib.mtg_version().startswith(b"mtg-hip")
+    assert [lib.mtg_term_nparams(k) for k in range(10)] == [2, 3, 4, 3, 2, 1, 2, 3, 2, 3]
+    assert lib.mtg_term_nparams(99) == -1
+    # compiled structure table: J = jr + 2 jc <= 10
+    assert lib.mtg_structure_supported(1, 2) == 1
+    assert lib.mtg_structure_supported(0, 5) == 1
+    assert lib.mtg_structure_supported(10, 0) == 1
+    assert lib.mtg_structure_supported(0, 0) == 0
+    assert lib.mtg_structure_supported(1, 5) == 0
+
+
+@pytest.mark.skipif(engine.device_count() > 0, reason="a GPU is present")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(engine.EngineUnavailable):
+        engine.Engine(0)
