@@ -117,7 +117,7 @@ def main():
     lc = np.repeat(np.arange(L, dtype=np.int32), W)
 
     eng = Engine(local_rank)
-    eng.set_lightcurves(t, y, dy)          # uploaded once; resident for the whole run
+    eng.set_lightcurves(t, y, dy + 1e-12)          # uploaded once; resident for the whole run
     eng.set_model(kinds, full, free, bounds)
     d_theta = torch.from_numpy(theta).to(dev)
     d_lc = torch.from_numpy(lc).to(dev)

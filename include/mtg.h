@@ -82,19 +82,21 @@ MTG_API void mtg_destroy(mtg_ctx *ctx);
 MTG_API const char *mtg_last_error(const mtg_ctx *ctx);
 
 /*
- * celerite.GP.compute(t, dy + 1e-12)  (gpmodelling.py:54) for L light curves
- * at once.  t: [N] when t_per_lc == 0 (shared sampling, the PPP case of
- * gpmodelling.py:538) or [L][N]; y, dy: [L][N], host pointers.  The library
- * checks that every t row is sorted (celerite raises ValueError otherwise ->
- * MTG_E_ARG), forms sigma^2 = (dy + 1e-12)^2 and dx_n = t_n - t_{n-1} on the
- * device and keeps everything resident until the next call / mtg_destroy.
+ * celerite.GP.compute(t, yerr) for L light curves at once; the reference calls
+ * it with yerr = dy + 1e-12 (gpmodelling.py:54) and the host layer above this
+ * ABI does the same.  t: [N] when t_per_lc == 0 (shared sampling, the PPP case
+ * of gpmodelling.py:538) or [L][N]; y, yerr: [L][N], host pointers.  The
+ * library checks that every t row is sorted (celerite raises ValueError
+ * otherwise -> MTG_E_ARG), forms sigma^2 = yerr^2 (celerite squares yerr) and
+ * dx_n = t_n - t_{n-1} on the device and keeps everything resident until the
+ * next call / mtg_destroy.
  */
 MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
-                                const double *y, const double *dy);
+                                const double *y, const double *yerr);
 /* Same with DEVICE pointers (light curves born on the GPU); no sortedness
  * check, the data are copied device-to-device on the context's stream. */
 MTG_API int mtg_set_lightcurves_device(mtg_ctx *ctx, int64_t N, int64_t L, const double *d_t,
-                                       int t_per_lc, const double *d_y, const double *d_dy);
+                                       int t_per_lc, const double *d_y, const double *d_yerr);
 
 /*
  * The model: what `celerite.GP(kernel, mean=..., fit_mean=...)`

@@ -265,11 +265,11 @@ MTG_API const char *mtg_last_error(const mtg_ctx *ctx)
 }
 
 static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
-                                  const double *y, const double *dy, hipMemcpyKind kind)
+                                  const double *y, const double *yerr, hipMemcpyKind kind)
 {
     if (!ctx) return MTG_E_ARG;
-    if (N <= 0 || L <= 0 || !t || !y || !dy)
-        return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, dy");
+    if (N <= 0 || L <= 0 || !t || !y || !yerr)
+        return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, yerr");
     if (L * N > (int64_t)1 << 40) return fail(ctx, MTG_E_ARG, "light-curve set too large");
     int rc = use_device(ctx);
     if (rc) return rc;
@@ -282,7 +282,7 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)L * N * 8));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->y.p, y, (size_t)L * N * 8, kind, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, dy, (size_t)L * N * 8, kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr, (size_t)L * N * 8, kind, ctx->stream));
     mtg_launch_lc_setup(N, L, t_rows, ctx->t.as<double>(), ctx->dy_tmp.as<double>(),
                         ctx->dx.as<double>(), ctx->var.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
@@ -292,24 +292,24 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
 }
 
 MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
-                                const double *y, const double *dy)
+                                const double *y, const double *yerr)
 {
     if (!ctx) return MTG_E_ARG;
-    if (N <= 0 || L <= 0 || !t || !y || !dy)
-        return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, dy");
+    if (N <= 0 || L <= 0 || !t || !y || !yerr)
+        return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, yerr");
     // celerite.GP.compute raises ValueError for unsorted times
     const int64_t t_rows = t_per_lc ? L : 1;
     for (int64_t r = 0; r < t_rows; ++r)
         for (int64_t n = 1; n < N; ++n)
             if (!(t[r * N + n] >= t[r * N + n - 1]))
                 return fail(ctx, MTG_E_ARG, "the input coordinates must be sorted");
-    return set_lightcurves_common(ctx, N, L, t, t_per_lc, y, dy, hipMemcpyHostToDevice);
+    return set_lightcurves_common(ctx, N, L, t, t_per_lc, y, yerr, hipMemcpyHostToDevice);
 }
 
 MTG_API int mtg_set_lightcurves_device(mtg_ctx *ctx, int64_t N, int64_t L, const double *d_t,
-                                       int t_per_lc, const double *d_y, const double *d_dy)
+                                       int t_per_lc, const double *d_y, const double *d_yerr)
 {
-    return set_lightcurves_common(ctx, N, L, d_t, t_per_lc, d_y, d_dy, hipMemcpyDeviceToDevice);
+    return set_lightcurves_common(ctx, N, L, d_t, t_per_lc, d_y, d_yerr, hipMemcpyDeviceToDevice);
 }
 
 MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const double *term_extra,

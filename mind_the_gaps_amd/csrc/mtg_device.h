@@ -70,7 +70,7 @@ struct MtgSolveArgs {
     const double *t;    // [N] or [L][N]
     const double *dx;   // same shape, dx[0] = 0
     const double *y;    // [L][N]
-    const double *var;  // [L][N]  (dy + 1e-12)^2
+    const double *var;  // [L][N]  yerr^2
     int64_t N;
     int64_t t_stride;  // 0 (shared sampling) or N
     int mean_kind;
@@ -80,5 +80,5 @@ typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStre
 // Table lookup of the compiled <NR, NC> instantiations (mtg_kernels.hip).
 mtg_solve_launcher mtg_find_solver(int nr, int nc);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
-void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *dy,
+void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *yerr,
                          double *dx, double *var, hipStream_t);

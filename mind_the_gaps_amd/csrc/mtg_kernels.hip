@@ -1,8 +1,8 @@
 // mtg_kernels.hip -- gfx950 (MI355X, CDNA4, wave64) kernels of the celerite
 // log-likelihood hot path.
 //
-//   mtg_lc_setup   : celerite.GP.compute(t, dy + 1e-12) (reference
-//                    gpmodelling.py:54): sigma^2 = (dy + 1e-12)^2, dx_n.
+//   mtg_lc_setup   : celerite.GP.compute(t, yerr) (called with yerr = dy + 1e-12
+//                    at reference gpmodelling.py:54): sigma^2 = yerr^2, dx_n.
 //   mtg_prepare    : set_parameter_vector + log_prior + Term.coefficients
 //                    (gpmodelling.py:147-151, celerite_models.py:7-90,
 //                    celerite built-in terms): theta -> prior verdict and the
@@ -27,13 +27,13 @@
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restrict__ t,
-                    const double *__restrict__ dy, double *__restrict__ dx,
+                    const double *__restrict__ yerr, double *__restrict__ dx,
                     double *__restrict__ var)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = i0; i < L * N; i += stride) {
-        const double s = dy[i] + 1e-12;  // gpmodelling.py:54, squared by celerite
+        const double s = yerr[i];  // celerite squares the yerr handed to compute()
         var[i] = s * s;
     }
     for (int64_t i = i0; i < t_rows * N; i += stride) {
@@ -42,14 +42,14 @@ mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restri
     }
 }
 
-void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *dy,
+void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *yerr,
                          double *dx, double *var, hipStream_t stream)
 {
     int64_t blocks = (L * N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mtg_lc_setup_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, L,
-                       t_rows, t, dy, dx, var);
+                       t_rows, t, yerr, dx, var);
 }
 
 // ---------------------------------------------------------------------------
@@ -74,8 +74,13 @@ __global__ void __launch_bounds__(256) mtg_prepare_kernel(MtgPrepArgs a)
             ok = ok && (v >= m.lo[k]) && (v <= m.hi[k]);
         }
         // BendingPowerlaw.log_prior, celerite_models.py:85-90
-        for (int i = 0; i < m.nterms; ++i)
-            if (m.kinds[i] == MTG_TERM_BPL) ok = ok && !(par(m.poff[i]) < par(m.poff[i] + 1));
+        // celerite ComplexTerm.log_prior (4-parameter form): log_a + log_c >= log_b + log_d
+        for (int i = 0; i < m.nterms; ++i) {
+            const int o = m.poff[i];
+            if (m.kinds[i] == MTG_TERM_BPL) ok = ok && !(par(o) < par(o + 1));
+            if (m.kinds[i] == MTG_TERM_COMPLEX4)
+                ok = ok && !(par(o) + par(o + 2) < par(o + 1) + par(o + 3));
+        }
     }
     if (live) {
         a.status[e] = ok ? MTG_ST_OK : MTG_ST_PRIOR;

@@ -141,14 +141,15 @@ class Engine:
             raise EngineError(rc, self._lib.mtg_last_error(self._ctx).decode())
 
     # -- data ---------------------------------------------------------------
-    def set_lightcurves(self, t, y, dy):
-        """t: [N] (shared sampling) or [L][N]; y, dy: [N] or [L][N]."""
+    def set_lightcurves(self, t, y, yerr):
+        """t: [N] (shared sampling) or [L][N]; y, yerr: [N] or [L][N].  ``yerr`` is what
+        celerite's ``compute`` receives, i.e. ``dy + 1e-12`` in the reference (gpmodelling.py:54)."""
         y = np.atleast_2d(_f64(y))
-        dy = np.atleast_2d(_f64(dy))
+        dy = np.atleast_2d(_f64(yerr))
         t = _f64(t)
         L, N = y.shape
         if dy.shape != (L, N):
-            raise ValueError("y and dy must have the same shape")
+            raise ValueError("y and yerr must have the same shape")
         t_per_lc = 0
         if t.ndim == 2:
             if t.shape == (L, N) and L > 1:

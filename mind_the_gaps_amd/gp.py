@@ -1,0 +1,272 @@
+"""``GP``: the celerite.GP interface of the hot path, evaluated on MI355X.
+
+Host-side mirror of what /root/reference/mind_the_gaps/gpmodelling.py does with
+``celerite.GP`` (third-party; semantics restated in SURVEY.md Appendix A.1/A.2):
+
+    gp = GP(kernel, mean=meanmodel, fit_mean=fit_mean)        gpmodelling.py:51
+    gp.compute(times, dy + 1e-12)                             gpmodelling.py:54
+    gp.get_parameter_vector() / set_parameter_vector(theta)   gpmodelling.py:55,147
+    gp.log_prior(); gp.log_likelihood(y)                      gpmodelling.py:149-152
+    gp.get_parameter_bounds() / get_parameter_names()         gpmodelling.py:193,454
+
+Every likelihood value comes from the HIP kernels through the C-ABI
+(engine.Engine).  There is no host fallback: without libmtg_hip.so or a GPU the
+first evaluation raises ``EngineUnavailable``.
+
+Beyond celerite's one-theta-at-a-time calls, ``LogProbEvaluator`` exposes the
+batched form the ensemble sampler and the finite-difference gradient use:
+``evaluate(theta[B, P], lc_index[B]) -> (lnP[B], status[B])`` over L resident
+light curves.
+"""
+import numpy as np
+
+from . import engine as _engine
+from .modeling import ConstantModel, Model, ModelSet
+from .terms import Term
+
+__all__ = ["GP", "LinAlgError", "LogProbEvaluator", "DeviceModel", "get_engine"]
+
+
+class LinAlgError(Exception):
+    """The covariance matrix is not positive definite (celerite.solver.LinAlgError)."""
+
+
+_engines = {}
+
+
+def get_engine(device=0):
+    """Process-wide engine (one ``mtg_ctx``) per GPU."""
+    eng = _engines.get(device)
+    if eng is None:
+        eng = _engine.Engine(device)
+        eng.bound_to = None
+        _engines[device] = eng
+    return eng
+
+
+def _inf_bounds(bounds):
+    out = np.empty((len(bounds), 2), dtype=np.float64)
+    for i, (lo, hi) in enumerate(bounds):
+        out[i, 0] = -np.inf if lo is None else lo
+        out[i, 1] = np.inf if hi is None else hi
+    return out
+
+
+class DeviceModel:
+    """Flattened (kernel, mean) description handed to ``mtg_set_model``.
+
+    ``device_terms`` is False when some term has no ``mtg_kind`` (a user-defined
+    Python term): coefficients are then evaluated on the host per theta and sent
+    through ``mtg_loglike_coeffs``.
+    """
+
+    def __init__(self, kernel, mean, mean_unfrozen):
+        self.terms = list(kernel.terms)
+        self.kinds = [t.mtg_kind for t in self.terms]
+        self.device_terms = all(k is not None for k in self.kinds)
+        self.extra = [float(t.mtg_extra()) for t in self.terms]
+        if isinstance(mean, ConstantModel):
+            self.mean_kind = _engine.MEAN_CONSTANT
+        elif getattr(mean, "mtg_mean_kind", None) is not None:
+            self.mean_kind = mean.mtg_mean_kind
+        else:
+            self.mean_kind = None  # host-evaluated mean: only a frozen one is supported
+        kfull = kernel.get_parameter_vector(include_frozen=True)
+        kmask = np.atleast_1d(kernel.unfrozen_mask).astype(bool)
+        kbounds = kernel.get_parameter_bounds(include_frozen=True)
+        if self.mean_kind is None:
+            mfull, mmask, mbounds = np.zeros(1), np.zeros(1, dtype=bool), [(None, None)]
+        else:
+            mfull = mean.get_parameter_vector(include_frozen=True)
+            mmask = np.atleast_1d(mean_unfrozen).astype(bool)
+            mbounds = mean.get_parameter_bounds(include_frozen=True)
+        self.nk = len(kfull)
+        self.full = np.concatenate([kfull, mfull]).astype(np.float64)
+        self.mask = np.concatenate([kmask, mmask])
+        self.free_index = np.flatnonzero(self.mask).astype(np.int32)
+        self.bounds = _inf_bounds(list(kbounds) + list(mbounds))
+
+    def signature(self):
+        frozen = self.full[~self.mask]
+        return (tuple(-1 if k is None else k for k in self.kinds), tuple(self.extra), self.mean_kind,
+                self.mask.tobytes(), frozen.tobytes(), self.bounds.tobytes())
+
+
+class LogProbEvaluator:
+    """L light curves resident on one GPU + one model; batched lnP / lnL.
+
+    ``t``: [N] shared sampling (gpmodelling.py:538 gives every simulated light
+    curve the observed ``times``) or [L][N]; ``y``, ``yerr``: [N] or [L][N];
+    ``yerr`` is what the reference passes to ``gp.compute``, i.e. ``dy + 1e-12``
+    (gpmodelling.py:54); the device squares it.
+    """
+
+    def __init__(self, t, y, yerr, device=0):
+        self.t = np.ascontiguousarray(t, dtype=np.float64)
+        self.y = np.atleast_2d(np.ascontiguousarray(y, dtype=np.float64))
+        self.yerr = np.atleast_2d(np.ascontiguousarray(yerr, dtype=np.float64))
+        if self.yerr.shape != self.y.shape:
+            raise ValueError("dimension mismatch")
+        self.device = device
+        self._model_sig = None
+        self._token = object()
+
+    @property
+    def n_lightcurves(self):
+        return self.y.shape[0]
+
+    def _bind(self, model):
+        eng = get_engine(self.device)
+        if eng.bound_to is not self._token:
+            eng.set_lightcurves(self.t, self.y, self.yerr)
+            eng.bound_to = self._token
+            self._model_sig = None
+        if model.device_terms:
+            sig = model.signature()
+            if sig != self._model_sig:
+                eng.set_model(model.kinds, model.full, model.free_index, model.bounds,
+                              mean_kind=model.mean_kind, extra=model.extra)
+                self._model_sig = sig
+        return eng
+
+    def evaluate(self, model, theta, lc_index=None, add_prior=True):
+        """theta [B][P] -> (lnP [B], status [B]); ``model`` is a DeviceModel."""
+        if not model.device_terms:
+            raise ValueError("batched evaluation needs device-expandable terms")
+        if model.mean_kind is None:
+            raise NotImplementedError("only constant and linear mean models run on the device")
+        eng = self._bind(model)
+        return eng.loglike(theta, lc_index, add_prior=add_prior)
+
+    def evaluate_coefficients(self, coeffs, jitter, mean_kind, mean_params, lc_index=None):
+        eng = self._bind(_NoModel)
+        ar, cr, ac, bc, cc, dc = coeffs
+        return eng.loglike_coeffs(ar, cr, ac, bc, cc, dc, jitter=jitter, mean_kind=mean_kind,
+                                  mean_params=mean_params, lc_index=lc_index)
+
+
+class _NoModelType:
+    device_terms = False
+
+
+_NoModel = _NoModelType()
+
+
+class GP(ModelSet):
+    """celerite.GP look-alike; parameters are ``kernel:*`` then ``mean:*``."""
+
+    def __init__(self, kernel, mean=0.0, fit_mean=False, device=0):
+        if not isinstance(kernel, Term):
+            raise TypeError("kernel must be a mind_the_gaps_amd Term")
+        try:
+            mean = ConstantModel(float(mean))
+        except TypeError:
+            if not isinstance(mean, Model):
+                raise
+        if not fit_mean:
+            mean.freeze_all_parameters()
+        super().__init__([("kernel", kernel), ("mean", mean)])
+        self.device = device
+        self._t = None
+        self._yerr = None
+        self._evaluator = None
+        self._y_bound = None
+
+    # -- celerite.GP API ---------------------------------------------------------
+    @property
+    def mean(self):
+        return self.models["mean"]
+
+    @property
+    def kernel(self):
+        return self.models["kernel"]
+
+    @property
+    def computed(self):
+        return self._t is not None
+
+    def compute(self, t, yerr=1.123e-12, check_sorted=True):
+        """Bind the sampling ``t`` and the per-point standard deviations ``yerr``."""
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        if t.ndim != 1:
+            raise ValueError("dimension mismatch")
+        if check_sorted and np.any(np.diff(t) < 0.0):
+            raise ValueError("the input coordinates must be sorted")
+        self._t = t
+        self._yerr = np.empty_like(t)
+        self._yerr[:] = yerr
+        self._evaluator = None
+
+    def _device_model(self):
+        return DeviceModel(self.kernel, self.mean, self.mean.unfrozen_mask)
+
+    def _ensure_evaluator(self, y):
+        if self._t is None:
+            raise RuntimeError("you must call 'compute' first")
+        y = np.asarray(y, dtype=np.float64)
+        if y.shape != self._t.shape:
+            raise ValueError("dimension mismatch")
+        if self._evaluator is None or self._y_bound is None or not np.array_equal(self._y_bound, y):
+            self._evaluator = LogProbEvaluator(self._t, y, self._yerr, device=self.device)
+            self._y_bound = y.copy()
+        return self._evaluator
+
+    def log_likelihood(self, y, quiet=False):
+        """ln L of the current parameter vector (gpmodelling.py:152,169)."""
+        ev = self._ensure_evaluator(y)
+        model = self._device_model()
+        if model.mean_kind is None:
+            raise NotImplementedError("only constant and linear mean models run on the device")
+        if model.device_terms:
+            out, status = ev.evaluate(model, model.full[model.free_index][None, :], add_prior=False)
+        else:
+            coeffs = tuple(c[None, :] for c in self.kernel.coefficients)
+            out, status = ev.evaluate_coefficients(
+                coeffs, np.array([self.kernel.jitter]), model.mean_kind,
+                self.mean.get_parameter_vector(include_frozen=True)[None, :])
+        if status[0] == _engine.ST_NOTPD:
+            if quiet:
+                return -np.inf
+            raise LinAlgError("failed to factorize or solve matrix")
+        return float(out[0])
+
+    def log_probability_batch(self, theta, y, add_prior=True):
+        """lnP of B free-parameter vectors at once -> (lnP[B], status[B]); pure in theta."""
+        ev = self._ensure_evaluator(y)
+        theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+        model = self._device_model()
+        if model.device_terms:
+            return ev.evaluate(model, theta, add_prior=add_prior)
+        return self._host_coefficient_batch(ev, model, theta, add_prior)
+
+    def _host_coefficient_batch(self, ev, model, theta, add_prior):
+        """User-defined Python terms: coefficients on the host, recurrence on the device."""
+        saved = self.get_parameter_vector()
+        B = theta.shape[0]
+        rows, jit, means, keep = [], [], [], np.ones(B, dtype=bool)
+        try:
+            for b in range(B):
+                self.set_parameter_vector(theta[b])
+                if add_prior and not np.isfinite(self.log_prior()):
+                    keep[b] = False
+                    continue
+                rows.append(self.kernel.coefficients)
+                jit.append(self.kernel.jitter)
+                means.append(self.mean.get_parameter_vector(include_frozen=True))
+        finally:
+            self.set_parameter_vector(saved)
+        out = np.full(B, -np.inf)
+        status = np.full(B, _engine.ST_PRIOR, dtype=np.int32)
+        if rows:
+            shapes = {tuple(len(c) for c in r) for r in rows}
+            if len(shapes) != 1:
+                raise ValueError("host-evaluated terms must keep one structure across the batch")
+            coeffs = tuple(np.array([r[i] for r in rows]).reshape(len(rows), -1) for i in range(6))
+            o, s = ev.evaluate_coefficients(coeffs, np.array(jit), model.mean_kind, np.array(means))
+            out[keep], status[keep] = o, s
+        return out, status
+
+    def predict(self, *args, **kwargs):
+        raise NotImplementedError(
+            "GP.predict (conditional mean/variance) is outside the log-likelihood hot path "
+            "(SURVEY.md section 8(f), row f3)")

@@ -1,0 +1,315 @@
+"""``GPModelling``: the reference's workflow facade on the MI355X engine.
+
+Drop-in mirror of /root/reference/mind_the_gaps/gpmodelling.py:23-539 for the
+log-likelihood hot path: same constructor, method names, defaults, attributes
+and error behaviour; every likelihood comes from the HIP kernels (gp.GP ->
+engine.Engine -> libmtg_hip.so).  What changes underneath:
+
+* ``_log_probability`` / ``_neg_log_like`` accept one theta (P,) -> float exactly
+  like the reference, or a batch (B, P) -> array, which is one GPU launch;
+* ``fit`` gives L-BFGS-B the value and the forward-difference gradient from ONE
+  batched launch of P + 1 evaluations (scipy's own serial finite differences,
+  gpmodelling.py:192, cost P + 1 sequential likelihood calls);
+* ``derive_posteriors`` runs the stretch move with the whole half-ensemble per
+  launch; ``cores`` (a multiprocessing.Pool size in the reference,
+  gpmodelling.py:245) is accepted and ignored.
+"""
+import warnings
+from typing import List, Tuple
+
+import numpy as np
+from scipy.optimize import minimize
+
+from . import engine as _engine
+from .gp import GP, LinAlgError
+from .lightcurves import GappyLightcurve
+from .modeling import ConstantModel
+from .models import GaussianModel, LinearModel
+from .sampler import EnsembleSampler
+
+__all__ = ["GPModelling"]
+
+
+class GPModelling:
+    """The interface for Gaussian Process (GP) modelling on MI355X."""
+
+    meanmodels = ["linear", "constant", "gaussian"]
+
+    def __init__(self, lightcurve: GappyLightcurve, kernel, mean_model: str = None, device: int = 0,
+                 quiet: bool = False):
+        """
+        Parameters
+        ----------
+        lightcurve
+            An instance of a lightcurve
+        kernel: mind_the_gaps_amd.terms.Term
+            The model to be fitted to the lightcurve
+        mean_model
+            Mean model. If given it will be fitted, otherwise assumed the mean value.
+            Available implementations are Constant, Linear and Gaussian.
+        device
+            GPU ordinal (new, optional).
+        quiet
+            Return -inf instead of raising ``LinAlgError`` for a non positive-definite
+            covariance (new, optional; the reference raises, gpmodelling.py:152).
+        """
+        self._lightcurve = lightcurve
+        meanmodel, fit_mean = self._build_mean_model(mean_model)
+        self.gp = GP(kernel, mean=meanmodel, fit_mean=fit_mean, device=device)
+        # gpmodelling.py:54 -- celerite squares yerr = dy + 1e-12
+        self.gp.compute(self._lightcurve.times, np.asarray(self._lightcurve.dy, dtype=np.float64) + 1e-12)
+        self.initial_params = self.gp.get_parameter_vector()
+        self._ndim = len(self.initial_params)
+        self._autocorr = []
+        self._loglikelihoods = None
+        self._mcmc_samples = None
+        self._quiet = quiet
+        self._y = np.asarray(self._lightcurve.y, dtype=np.float64)
+
+    def _build_mean_model(self, meanmodel: str = None):
+        """Mean model from the light-curve properties (gpmodelling.py:62-124)."""
+        maxy = np.max(self._lightcurve.y)
+        if meanmodel is None:
+            meanmodel = ConstantModel(self._lightcurve.mean, bounds=[(np.min(self._lightcurve.y), maxy)])
+            return meanmodel, False
+        elif meanmodel.lower() not in GPModelling.meanmodels:
+            raise ValueError("Input mean model %s not implemented! Only \n %s \n are available"
+                             % (meanmodel, "\t".join(GPModelling.meanmodels)))
+        elif meanmodel.lower() == "constant":
+            meanmodel = ConstantModel(self._lightcurve.mean, bounds=[(np.min(self._lightcurve.y), maxy)])
+            return meanmodel, True
+        elif meanmodel.lower() == "linear":
+            meanmodel = LinearModel(0, 1.5, bounds=[(-np.inf, np.inf), (-np.inf, np.inf)])
+        elif meanmodel.lower() == "gaussian":
+            # as in the reference this builds a 4-parameter model from 3 values and
+            # raises ValueError
+            sigma_guess = (self._lightcurve.duration) / 2
+            amplitude_guess = (maxy - np.min(self._lightcurve.y)) * np.sqrt(2 * np.pi) * sigma_guess
+            mean_guess = self._lightcurve.times[len(self._lightcurve.times) // 2]
+            norm = maxy * np.sqrt(2 * np.pi) * self._lightcurve.duration
+            meanmodel = GaussianModel(mean_guess, sigma_guess, amplitude_guess,
+                                      bounds=[(self._lightcurve.times[0], self._lightcurve.times[-1]),
+                                              (0, self._lightcurve.duration), (norm, 50 * norm)])
+        return meanmodel, True
+
+    # -- the hot path --------------------------------------------------------------
+    def _batch(self, params, add_prior):
+        theta = np.asarray(params, dtype=np.float64)
+        single = theta.ndim == 1
+        out, status = self.gp.log_probability_batch(np.atleast_2d(theta), self._y, add_prior=add_prior)
+        if not self._quiet and np.any(status == _engine.ST_NOTPD):
+            raise LinAlgError("failed to factorize or solve matrix")
+        return (float(out[0]) if single else out)
+
+    def _log_probability(self, params):
+        """Logarithm of the posterior: box prior + GP log-likelihood
+        (gpmodelling.py:127-152).  ``params``: (P,) -> float or (B, P) -> array."""
+        return self._batch(params, add_prior=True)
+
+    def _neg_log_like(self, params):
+        """Negative log-likelihood, no prior (gpmodelling.py:155-169)."""
+        r = self._batch(params, add_prior=False)
+        return -r
+
+    def _neg_log_like_and_grad(self, x, lower, upper, step=1e-8):
+        """-lnL and its forward-difference gradient from one batched launch.
+
+        Same scheme scipy applies for L-BFGS-B without a jacobian (absolute step
+        ``eps`` = 1e-8, flipped or shrunk where x + h would leave the bounds)."""
+        x = np.asarray(x, dtype=np.float64)
+        h = np.full_like(x, step)
+        room_up, room_dn = upper - x, x - lower
+        out_of_box = x + h > upper
+        flip = out_of_box & (np.abs(h) <= np.maximum(room_dn, room_up))
+        h[flip] *= -1.0
+        shrink = out_of_box & ~flip
+        h[shrink & (room_up >= room_dn)] = room_up[shrink & (room_up >= room_dn)]
+        h[shrink & (room_up < room_dn)] = -room_dn[shrink & (room_up < room_dn)]
+        pts = np.vstack([x[None, :], x[None, :] + np.diag(h)])
+        vals = self._neg_log_like(pts)
+        f0 = float(vals[0])
+        dx = pts[1:].diagonal() - x
+        with np.errstate(divide="ignore", invalid="ignore"):
+            grad = np.where(dx != 0.0, (vals[1:] - f0) / dx, 0.0)
+        return f0, grad
+
+    def fit(self, initial_params=None):
+        """L-BFGS-B minimisation of the negative log-likelihood within the
+        parameter bounds (gpmodelling.py:172-194).  Returns scipy's OptimizeResult."""
+        if initial_params is None:
+            initial_params = self.initial_params
+        bounds = self.gp.get_parameter_bounds()
+        lower = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+        upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        solution = minimize(self._neg_log_like_and_grad, initial_params, args=(lower, upper), jac=True,
+                            method="L-BFGS-B", bounds=bounds)
+        return solution
+
+    def derive_posteriors(self, initial_chain_params=None, fit: bool = True, converge: bool = True,
+                          max_steps: int = 10000, convergence_steps: int = 500, walkers: int = 12,
+                          cores: int = 6, progress: bool = True):
+        """Derive GP posteriors (gpmodelling.py:197-286): optional fit, walker
+        spreading, stretch-move MCMC with an autocorrelation-time convergence check
+        every ``convergence_steps`` iterations, then burn-in and thinning."""
+        if initial_chain_params is None:
+            if not fit:
+                initial_params = self.initial_params
+            else:
+                solution = self.fit(self.initial_params)
+                initial_params = solution.x
+            initial_chain_params = self.spread_walkers(walkers, initial_params,
+                                                       np.array(self.gp.get_parameter_bounds()))
+        every_samples = convergence_steps
+        old_tau = np.inf
+        self.converged = False
+        sampler = EnsembleSampler(walkers, self._ndim, self._log_probability, vectorize=True)
+        tau = None
+        for sample in sampler.sample(initial_chain_params, iterations=max_steps, progress=progress):
+            if sampler.iteration % every_samples:
+                continue
+            # tol=0: always get an estimate, even an untrustworthy one
+            tau = sampler.get_autocorr_time(tol=0)
+            self.autocorr.append(np.mean(tau))
+            if np.all(tau * 100 < sampler.iteration) and np.all(np.abs(old_tau - tau) / tau < 0.01) and converge:
+                print("Convergence reached after %d samples!" % sampler.iteration)
+                self.converged = True
+                break
+            old_tau = tau
+        if tau is None:
+            # max_steps < convergence_steps: the reference hits a NameError here
+            # (SURVEY.md Appendix C.1); estimate once from the chain we have
+            tau = sampler.get_autocorr_time(tol=0)
+        self._tau = tau
+        mean_tau = np.mean(tau)
+        if not self.converged:
+            warnings.warn(f"The chains did not converge after {sampler.iteration} iterations!")
+            thin = int(mean_tau / 4)
+            discard = int(mean_tau) * 5
+        else:
+            discard = int(mean_tau * 40)
+            if discard > max_steps:
+                discard = int(mean_tau * 10)
+            thin = int(mean_tau / 2)
+        thin = max(thin, 1)  # int(mean_tau / k) can be 0 for short chains (Appendix C.1)
+        discard = min(max(discard, 0), max(sampler.iteration - thin, 0))
+        self._loglikelihoods = sampler.get_log_prob(discard=discard, thin=thin, flat=True)
+        self._mcmc_samples = sampler.get_chain(discard=discard, thin=thin, flat=True)
+        self._sampler = sampler
+
+    def spread_walkers(self, walkers: int, parameters, bounds: List[Tuple[float, float]],
+                       percent: float = 0.1, max_attempts: int = 20):
+        """Spread the walkers with a Gaussian around ``parameters``
+        (gpmodelling.py:289-350): resample a walker while it is out of bounds (at most
+        ``max_attempts`` times), then clamp what is still outside next to the bound."""
+        if percent < 0 or percent > 1:
+            raise ValueError("The 'percent' parameter must be between 0 and 1 (inclusive).")
+        std = np.abs(parameters) * percent
+        initial_samples = np.random.normal(parameters, std, size=(walkers, len(parameters)))
+        bounds = np.array([(-np.inf if lower is None else lower, np.inf if upper is None else upper)
+                           for lower, upper in bounds])
+        factors_lower = np.where(bounds[:, 0] > 0, 1.05, 0.95)
+        factors_upper = np.where(bounds[:, 1] > 0, 0.95, 1.05)
+        for i in range(walkers):
+            for attempt in range(max_attempts):
+                inside = np.logical_and(bounds[:, 0] <= initial_samples[i], initial_samples[i] <= bounds[:, 1])
+                if np.all(inside):
+                    break
+                initial_samples[i] = np.random.normal(parameters, std)
+            if attempt == max_attempts - 1:
+                warnings.warn("Some walkers are out of bounds! Setting them to values close to the bounds")
+                below = initial_samples[i] < bounds[:, 0]
+                above = initial_samples[i] > bounds[:, 1]
+                initial_samples[i][below] = (bounds[:, 0] * factors_lower)[below]
+                initial_samples[i][above] = (bounds[:, 1] * factors_upper)[above]
+        return initial_samples
+
+    def standarized_residuals(self, include_noise: bool = True):
+        """Standardised residuals (gpmodelling.py:353-370) need ``GP.predict`` -- outside
+        the log-likelihood hot path."""
+        pred_mean, pred_var = self.gp.predict(self._lightcurve.y, return_var=True, return_cov=False)
+        if include_noise:
+            pred_var += self.gp.kernel.jitter
+        return (self._lightcurve.y - pred_mean) / np.sqrt(pred_var)
+
+    def get_rstat(self, burnin: int = None):
+        """Gelman-Rubin-like statistic as the reference computes it
+        (gpmodelling.py:373-403): within-chain over total variance."""
+        if getattr(self, "_sampler", None) is None:
+            raise ValueError("Posteriors have not been derived. Please run derive_posteriors prior to "
+                             "populate the attributes.")
+        if burnin is None:
+            burnin = int(np.mean(self.tau)) * 10
+        samples = self._sampler.get_chain(discard=burnin)
+        whithin_chain_variances = np.var(samples, axis=0)
+        samples = self._sampler.get_chain(flat=True, discard=burnin)
+        between_chain_variances = np.var(samples, axis=0)
+        return whithin_chain_variances / between_chain_variances[np.newaxis, :]
+
+    # -- result accessors (gpmodelling.py:405-475) -----------------------------------
+    _NOT_DERIVED = ("Posteriors have not been derived. Please run derive_posteriors prior to "
+                    "populate the attributes.")
+
+    @property
+    def loglikelihoods(self):
+        if self._loglikelihoods is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return self._loglikelihoods
+
+    @property
+    def autocorr(self):
+        return self._autocorr
+
+    @property
+    def sampler(self):
+        if self._loglikelihoods is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return self._sampler
+
+    @property
+    def mcmc_samples(self):
+        if self._mcmc_samples is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return self._mcmc_samples
+
+    @property
+    def max_loglikelihood(self):
+        if self._loglikelihoods is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return np.max(self._loglikelihoods)
+
+    @property
+    def max_parameters(self):
+        if self._mcmc_samples is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return self._mcmc_samples[np.argmax(self._loglikelihoods)]
+
+    @property
+    def median_parameters(self):
+        if self._mcmc_samples is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return np.median(self._mcmc_samples, axis=0)
+
+    @property
+    def parameter_names(self):
+        return self.gp.get_parameter_names()
+
+    @property
+    def k(self) -> int:
+        return self._ndim
+
+    @property
+    def tau(self):
+        if self._mcmc_samples is None:
+            raise AttributeError(self._NOT_DERIVED)
+        return self._tau
+
+    def generate_from_posteriors(self, nsims: int = 10, cpus: int = 8, pdf: str = "Gaussian",
+                                 extension_factor: int = 2, sigma_noise=None):
+        """Posterior-predictive light-curve simulation (gpmodelling.py:478-513) is the
+        step BEFORE the hot path (TK95/E13 simulator)."""
+        if self._mcmc_samples is None:
+            raise RuntimeError("Posteriors have not been derived. Please run derive_posteriors prior to "
+                               "calling this method.")
+        raise NotImplementedError(
+            "light-curve simulation (mind_the_gaps.simulator) is outside the log-likelihood hot path; "
+            "draw parameters from `mcmc_samples` and simulate with the reference simulator")

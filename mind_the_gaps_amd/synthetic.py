@@ -16,7 +16,7 @@ TRUTH = {
     K_LORENTZIAN: [np.log(100.0), np.log(80.0), np.log(2 * np.pi / 10.0)],
     K_REAL: [np.log(30.0), np.log(0.2)],
     K_COMPLEX3: [np.log(20.0), np.log(0.05), np.log(0.7)],
-    K_COMPLEX4: [np.log(20.0), np.log(2.0), np.log(0.05), np.log(0.7)],
+    K_COMPLEX4: [np.log(20.0), np.log(1.0), np.log(0.05), np.log(0.7)],
     K_MATERN32: [np.log(5.0), np.log(8.0)],
     K_JITTER: [np.log(0.7)],
     K_COSINUS: [np.log(15.0), np.log(2 * np.pi / 13.0)],

@@ -145,7 +145,8 @@ ORACLE_API int oracle_build_coeffs(int nterms, const int *kinds, const double *e
 /*
  * Box prior of celerite's Model.log_prior (0 inside [lo, hi] for every
  * parameter, -inf outside) plus BendingPowerlaw.log_prior
- * (celerite_models.py:85-90: -inf when log_S0 < log_Q).  bounds = [PF][2],
+ * (celerite_models.py:85-90: -inf when log_S0 < log_Q) and celerite's
+ * ComplexTerm.log_prior (log_a + log_c < log_b + log_d -> -inf).  bounds = [PF][2],
  * +-inf for an open side.  Returns 0.0 or -INFINITY.
  */
 ORACLE_API double oracle_log_prior(int nterms, const int *kinds, int PF, const double *p,
@@ -156,6 +157,8 @@ ORACLE_API double oracle_log_prior(int nterms, const int *kinds, int PF, const d
     int off = 0;
     for (int i = 0; i < nterms; ++i) {
         if (kinds[i] == K_BPL && p[off] < p[off + 1]) return -INFINITY;
+        /* celerite ComplexTerm.log_prior, 4-parameter form: a c >= b d in log space */
+        if (kinds[i] == K_COMPLEX4 && p[off] + p[off + 2] < p[off + 1] + p[off + 3]) return -INFINITY;
         off += oracle_term_nparams(kinds[i]);
     }
     return 0.0;

@@ -185,5 +185,7 @@ def log_prior(kinds, params_full, bounds):
     for kind in kinds:
         if kind == K_BPL and p[off] < p[off + 1]:
             return -np.inf
+        if kind == K_COMPLEX4 and p[off] + p[off + 2] < p[off + 1] + p[off + 3]:
+            return -np.inf  # celerite ComplexTerm.log_prior
         off += NPARAMS[kind]
     return 0.0

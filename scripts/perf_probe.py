@@ -11,7 +11,7 @@ def main():
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     eng = Engine(0)
     t, y, dy = synth.make_lightcurves(N, L, seed=20250708)
-    eng.set_lightcurves(t, y, dy)
+    eng.set_lightcurves(t, y, dy + 1e-12)
     for name, kinds in (("alt J=6", synth.ALT_MODEL), ("null J=3", synth.NULL_MODEL), ("drw J=1", [synth.K_DRW])):
         full, free, bounds = synth.model_spec(kinds, y)
         eng.set_model(kinds, full, free, bounds)

@@ -1,0 +1,171 @@
+"""GPU tests of the drop-in facade: GPModelling on the HIP engine against the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import synthetic as synth
+from mind_the_gaps_amd import terms
+from mind_the_gaps_amd.gp import GP, LinAlgError
+from mind_the_gaps_amd.gpmodelling import GPModelling
+from mind_the_gaps_amd.lightcurves import GappyLightcurve
+from mind_the_gaps_amd.models import BendingPowerlaw, DampedRandomWalk, Lorentzian
+from mind_the_gaps_amd.sampler import EnsembleSampler
+from oracle import celerite as oracle_c
+
+pytestmark = pytest.mark.gpu
+
+AMP, OTHER = (-10, 50), (-10, 10)
+
+
+def alt_kernel():
+    th = synth.truth(synth.ALT_MODEL)
+    return (DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER])
+            + terms.SHOTerm(th[2], th[3], th[4], bounds=[AMP, OTHER, OTHER])
+            + Lorentzian(th[5], th[6], th[7], bounds=[AMP, OTHER, OTHER]))
+
+
+def oracle_lnp(t, y, dy, kinds, theta, mean, bounds, add_prior=True):
+    theta = np.atleast_2d(theta)
+    full = np.hstack([theta, np.full((len(theta), 1), mean)])
+    b = np.vstack([bounds, [[np.min(y), np.max(y)]]])
+    return oracle_c.logprob_batch(t, y, dy, kinds, full, bounds=b, add_prior=add_prior, nthreads=4)[0]
+
+
+def test_log_probability_single_and_batch():
+    N = 800
+    t, y, dy = synth.make_lightcurves(N, 1, seed=5)
+    y, dy = y[0], dy[0]
+    g = GPModelling(GappyLightcurve(t, y, dy), alt_kernel())
+    theta = synth.draw_thetas(synth.ALT_MODEL, 40, seed=6)
+    theta[3, 1] = 10.5                                     # outside the box -> -inf (gpmodelling.py:150-151)
+    ref = oracle_lnp(t, y, dy, synth.ALT_MODEL, theta, np.mean(y), synth.bounds_for(synth.ALT_MODEL))
+    batch = g._log_probability(theta)
+    assert batch.shape == (40,) and np.isneginf(batch[3]) and np.isneginf(ref[3])
+    ok = np.isfinite(ref)
+    assert np.max(np.abs(batch[ok] - ref[ok]) / np.abs(ref[ok])) < 1e-8
+    one = g._log_probability(theta[0])
+    assert isinstance(one, float) and one == batch[0]
+    assert g._log_probability(theta[3]) == -np.inf
+    nll = g._neg_log_like(theta[3])                        # no prior on this path (gpmodelling.py:168-169)
+    ref_nll = -oracle_lnp(t, y, dy, synth.ALT_MODEL, theta[3], np.mean(y),
+                          synth.bounds_for(synth.ALT_MODEL), add_prior=False)[0]
+    assert abs(nll - ref_nll) / abs(ref_nll) < 1e-8
+    # the facade is pure in theta: the GP's own parameter vector is untouched
+    assert np.array_equal(g.gp.get_parameter_vector(), g.initial_params)
+
+
+def test_gp_log_likelihood_celerite_style():
+    t, y, dy = synth.make_lightcurves(300, 1, seed=8)
+    y, dy = y[0], dy[0]
+    k = DampedRandomWalk(np.log(100.0), np.log(0.3)) + BendingPowerlaw(4.0, 1.0, -1.0)
+    gp = GP(k, mean=float(np.mean(y)))
+    gp.compute(t, dy + 1e-12)
+    v = gp.get_parameter_vector()
+    want = oracle_c.logprob_batch(t, y, dy, [synth.K_DRW, synth.K_BPL], np.append(v, np.mean(y)))[0][0]
+    assert abs(gp.log_likelihood(y) - want) / abs(want) < 1e-8
+    gp.set_parameter_vector(v + 0.1)
+    want2 = oracle_c.logprob_batch(t, y, dy, [synth.K_DRW, synth.K_BPL], np.append(v + 0.1, np.mean(y)))[0][0]
+    assert abs(gp.log_likelihood(y) - want2) / abs(want2) < 1e-8
+
+
+def test_user_defined_term_goes_through_raw_coefficients():
+    """A Python Term without a device tag (celerite_models.py-style override) is
+    expanded on the host and evaluated by mtg_loglike_coeffs."""
+    class MyDRW(terms.Term):
+        parameter_names = ("log_S0", "log_omega0")
+
+        def get_real_coefficients(self, params):
+            return np.exp(params[0]), np.exp(params[1])
+
+    t, y, dy = synth.make_lightcurves(400, 1, seed=9)
+    y, dy = y[0], dy[0]
+    th = synth.truth([synth.K_DRW])
+    g_user = GPModelling(GappyLightcurve(t, y, dy), MyDRW(th[0], th[1], bounds=[AMP, OTHER]))
+    g_dev = GPModelling(GappyLightcurve(t, y, dy), DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]))
+    theta = synth.draw_thetas([synth.K_DRW], 10, seed=1)
+    theta[2, 1] = 11.0
+    a, b = g_user._log_probability(theta), g_dev._log_probability(theta)
+    assert np.isneginf(a[2]) and np.isneginf(b[2])
+    ok = np.isfinite(b)
+    assert np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok])) < 1e-12
+    assert abs(g_user.gp.log_likelihood(y) - g_dev.gp.log_likelihood(y)) < 1e-9 * abs(g_dev.gp.log_likelihood(y))
+
+
+def test_not_positive_definite_raises_like_celerite():
+    t = np.arange(20.0)
+    lc = GappyLightcurve(t, np.zeros(20), np.full(20, 1e-3))
+    with pytest.raises(ValueError):                                # celerite: "non-finite log prior value"
+        terms.ComplexTerm(np.log(1.0), np.log(50.0), np.log(0.01), np.log(1.0))
+    g = GPModelling(lc, terms.ComplexTerm(0.0, -5.0, 0.0, 0.0))
+    bad = np.log([1.0, 50.0, 0.01, 1.0])                          # a c < b d: not a valid kernel
+    assert g._log_probability(bad) == -np.inf                     # ComplexTerm's prior vetoes it
+    with pytest.raises(LinAlgError):
+        g._neg_log_like(bad)                                      # no prior: the solver fails loudly
+    assert GPModelling(lc, terms.ComplexTerm(0.0, -5.0, 0.0, 0.0), quiet=True)._neg_log_like(bad) == np.inf
+
+
+def test_fit_improves_and_matches_oracle_at_optimum():
+    N = 600
+    t, y, dy = synth.make_lightcurves(N, 1, seed=12)
+    y, dy = y[0], dy[0]
+    th = synth.truth(synth.NULL_MODEL)
+    k = DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]) + terms.SHOTerm(th[2], th[3], th[4],
+                                                                            bounds=[AMP, OTHER, OTHER])
+    g = GPModelling(GappyLightcurve(t, y, dy), k)
+    f0 = g._neg_log_like(g.initial_params)
+    sol = g.fit()
+    assert sol.fun <= f0 and np.all(np.isfinite(sol.x))
+    lo, hi = np.array(g.gp.get_parameter_bounds()).T
+    assert np.all(sol.x >= lo) and np.all(sol.x <= hi)
+    ref = -oracle_lnp(t, y, dy, synth.NULL_MODEL, sol.x, np.mean(y), synth.bounds_for(synth.NULL_MODEL),
+                      add_prior=False)[0]
+    assert abs(sol.fun - ref) / abs(ref) < 1e-8
+    # gradient from the batched launch == the same forward differences on the oracle
+    f, grad = g._neg_log_like_and_grad(sol.x, lo.astype(float), hi.astype(float), step=1e-6)
+    pts = np.vstack([sol.x] + [sol.x + 1e-6 * np.eye(5)[i] for i in range(5)])
+    rv = -oracle_lnp(t, y, dy, synth.NULL_MODEL, pts, np.mean(y), synth.bounds_for(synth.NULL_MODEL), False)
+    assert np.allclose(grad, (rv[1:] - rv[0]) / 1e-6, atol=2e-3)
+
+
+def test_derive_posteriors_matches_oracle_driven_chain():
+    """Same sampler, same seed: the chain driven by the HIP likelihood equals the chain
+    driven by the oracle likelihood (accept/reject decisions agree)."""
+    N = 300
+    t, y, dy = synth.make_lightcurves(N, 1, seed=21)
+    y, dy = y[0], dy[0]
+    th = synth.truth([synth.K_DRW])
+    g = GPModelling(GappyLightcurve(t, y, dy), DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]))
+    np.random.seed(123)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g.derive_posteriors(fit=False, max_steps=120, convergence_steps=60, walkers=12, cores=1, progress=False)
+    assert g.sampler.iteration == 120 and len(g.autocorr) == 2 and not g.converged
+    assert g.mcmc_samples.shape[1] == 2 and len(g.loglikelihoods) == len(g.mcmc_samples)
+    assert g.max_loglikelihood == np.max(g.loglikelihoods)
+    assert np.array_equal(g.max_parameters, g.mcmc_samples[np.argmax(g.loglikelihoods)])
+    assert g.median_parameters.shape == (2,) and g.tau.shape == (2,) and g.get_rstat().shape == (12, 2)
+
+    np.random.seed(123)
+    p0 = g.spread_walkers(12, g.initial_params, np.array(g.gp.get_parameter_bounds()))
+    ref = EnsembleSampler(12, 2, lambda p: oracle_lnp(t, y, dy, [synth.K_DRW], p, np.mean(y),
+                                                      synth.bounds_for([synth.K_DRW])))
+    ref.run_mcmc(p0, 120)
+    assert np.allclose(g.sampler.get_chain(), ref.get_chain(), rtol=0, atol=1e-12)
+    assert np.allclose(g.sampler.get_log_prob(), ref.get_log_prob(), rtol=1e-10)
+
+
+def test_config1_drw_n1000_32_walkers():
+    """BASELINE configs[0]: single DRW, N = 1000, 32 walkers, fit() + a short chain."""
+    t, y, dy = synth.make_lightcurves(1000, 1, seed=20250704)
+    y, dy = y[0], dy[0]
+    th = synth.truth([synth.K_DRW])
+    g = GPModelling(GappyLightcurve(t, y, dy), DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]))
+    np.random.seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g.derive_posteriors(fit=True, max_steps=200, convergence_steps=100, walkers=32, progress=False)
+    best = g.max_parameters
+    ref = oracle_lnp(t, y, dy, [synth.K_DRW], best, np.mean(y), synth.bounds_for([synth.K_DRW]))[0]
+    assert abs(g.max_loglikelihood - ref) / abs(ref) < 1e-8
+    assert g.max_loglikelihood >= -g.fit().fun - 0.5      # the chain stays at the mode found by the fit

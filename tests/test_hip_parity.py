@@ -37,7 +37,7 @@ def test_hip_vs_oracle(engine, name, N):
     L, B = 3, 96
     t, y, dy = synth.make_lightcurves(N, L, seed=100 + N)
     full, free, bounds = synth.model_spec(kinds, y)
-    engine.set_lightcurves(t, y, dy)
+    engine.set_lightcurves(t, y, dy + 1e-12)
     engine.set_model(kinds, full, free, bounds)
     theta = synth.draw_thetas(kinds, B, seed=7)
     lc = (np.arange(B) % L).astype(np.int32)
@@ -58,7 +58,7 @@ def test_hip_vs_dense_n10000(engine):
     N, L, B = 10000, 2, 128
     t, y, dy = synth.make_lightcurves(N, L, seed=20250704)
     full, free, bounds = synth.model_spec(kinds, y)
-    engine.set_lightcurves(t, y, dy)
+    engine.set_lightcurves(t, y, dy + 1e-12)
     engine.set_model(kinds, full, free, bounds)
     theta = synth.draw_thetas(kinds, B, seed=3)
     lc = (np.arange(B) % L).astype(np.int32)

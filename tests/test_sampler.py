@@ -1,0 +1,125 @@
+"""CPU tests of the ensemble sampler (emcee 3.1.4 semantics)."""
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd.sampler import AutocorrError, EnsembleSampler, integrated_time
+
+
+def gauss(mu, icov):
+    def f(p):
+        d = np.atleast_2d(p) - mu
+        return -0.5 * np.einsum("bi,ij,bj->b", d, icov, d)
+    return f
+
+
+def test_recovers_gaussian_moments():
+    np.random.seed(42)
+    mu = np.array([1.0, -2.0, 0.5])
+    cov = np.array([[1.0, 0.6, 0.0], [0.6, 2.0, -0.3], [0.0, -0.3, 0.5]])
+    s = EnsembleSampler(24, 3, gauss(mu, np.linalg.inv(cov)))
+    p0 = mu + 0.1 * np.random.randn(24, 3)
+    s.run_mcmc(p0, 3000)
+    flat = s.get_chain(discard=500, flat=True)
+    assert np.allclose(flat.mean(axis=0), mu, atol=0.1)
+    assert np.allclose(np.cov(flat.T), cov, atol=0.2)
+    assert 0.2 < s.acceptance_fraction.mean() < 0.9
+    tau = s.get_autocorr_time(tol=0)
+    assert tau.shape == (3,) and np.all(tau > 1) and np.all(tau < 200)
+
+
+def test_reproducible_from_global_seed_and_private_stream():
+    f = gauss(np.zeros(2), np.eye(2))
+    chains = []
+    for _ in range(2):
+        np.random.seed(7)
+        p0 = np.random.randn(8, 2)
+        s = EnsembleSampler(8, 2, f)          # copies numpy's global state at construction
+        np.random.seed(999)                   # later global reseeding must not matter
+        s.run_mcmc(p0, 50)
+        chains.append(s.get_chain())
+    assert np.array_equal(chains[0], chains[1])
+
+
+def test_vectorized_and_rowwise_agree():
+    f = gauss(np.zeros(2), np.eye(2))
+    out = []
+    for vec in (True, False):
+        np.random.seed(11)
+        p0 = np.random.randn(6, 2)
+        s = EnsembleSampler(6, 2, (f if vec else (lambda row: float(f(row)[0]))), vectorize=vec)
+        s.run_mcmc(p0, 40)
+        out.append((s.get_chain(), s.get_log_prob()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.allclose(out[0][1], out[1][1])
+
+
+def test_half_ensemble_batches():
+    """log_prob_fn sees W evaluations for the initial state, then W/2 per half-step."""
+    sizes = []
+
+    def f(p):
+        sizes.append(len(p))
+        return -0.5 * np.sum(p ** 2, axis=1)
+
+    np.random.seed(1)
+    s = EnsembleSampler(10, 2, f)
+    s.run_mcmc(np.random.randn(10, 2), 3)
+    assert sizes == [10, 5, 5, 5, 5, 5, 5]
+
+
+def test_chain_slicing_semantics():
+    np.random.seed(2)
+    s = EnsembleSampler(6, 2, gauss(np.zeros(2), np.eye(2)))
+    s.run_mcmc(np.random.randn(6, 2), 20)
+    full = s.get_chain()
+    assert full.shape == (20, 6, 2) and s.iteration == 20
+    assert np.array_equal(s.get_chain(discard=5, thin=3), full[5 + 3 - 1::3])
+    assert s.get_chain(discard=5, thin=3, flat=True).shape == (5 * 6, 2)
+    assert np.array_equal(s.get_log_prob(discard=4, flat=True), s.get_log_prob()[4:].reshape(-1))
+    # the flat chain is step-major, walker-minor
+    assert np.array_equal(s.get_chain(flat=True)[:6], full[0])
+
+
+def test_generator_can_be_interrupted_and_continued():
+    np.random.seed(3)
+    s = EnsembleSampler(6, 2, gauss(np.zeros(2), np.eye(2)))
+    for _ in s.sample(np.random.randn(6, 2), iterations=100):
+        if s.iteration == 10:
+            break
+    assert s.get_chain().shape == (10, 6, 2)
+    s.run_mcmc(None, 5)
+    assert s.get_chain().shape == (15, 6, 2)
+
+
+def test_errors():
+    f = gauss(np.zeros(3), np.eye(3))
+    with pytest.raises(RuntimeError):
+        EnsembleSampler(4, 3, f).run_mcmc(np.random.randn(4, 3), 1)        # walkers < 2 ndim
+    with pytest.raises(ValueError):
+        EnsembleSampler(8, 3, f).run_mcmc(np.ones((8, 3)), 1)              # degenerate ensemble
+    with pytest.raises(ValueError):
+        EnsembleSampler(8, 3, lambda p: np.full(len(p), np.nan)).run_mcmc(np.random.randn(8, 3), 1)
+    bad = np.random.randn(8, 3); bad[0, 0] = np.inf
+    with pytest.raises(ValueError):
+        EnsembleSampler(8, 3, f).run_mcmc(bad, 1)
+    # -inf is legal: such proposals are simply never accepted
+    np.random.seed(4)
+    s = EnsembleSampler(8, 3, lambda p: np.where(p[:, 0] > 0, -np.inf, -0.5 * np.sum(p ** 2, axis=1)))
+    p0 = -np.abs(np.random.randn(8, 3))
+    s.run_mcmc(p0, 200)
+    assert np.all(s.get_chain()[..., 0] <= 0)
+
+
+def test_integrated_time_ar1():
+    """AR(1) with coefficient phi has tau = (1 + phi) / (1 - phi)."""
+    rng = np.random.default_rng(0)
+    phi, n, w = 0.9, 40000, 8
+    x = np.zeros((n, w))
+    e = rng.standard_normal((n, w))
+    for i in range(1, n):
+        x[i] = phi * x[i - 1] + e[i]
+    tau = integrated_time(x[:, :, None], tol=0)
+    assert tau.shape == (1,) and abs(tau[0] - 19.0) < 2.5
+    with pytest.raises(AutocorrError):
+        integrated_time(x[:200, :, None], tol=50)
+    assert integrated_time(x[:200, :, None], tol=50, quiet=True).shape == (1,)
+    assert integrated_time(x[:, 0]).shape == (1,)
