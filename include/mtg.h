@@ -163,6 +163,13 @@ MTG_API double mtg_last_kernel_ms(const mtg_ctx *ctx);
  */
 MTG_API int mtg_profile_begin(mtg_ctx *ctx, int capacity);
 MTG_API int mtg_profile_read(mtg_ctx *ctx, int capacity, double *prepare_ms, double *solve_ms);
+/*
+ * Accuracy probe of the device elementary functions the recurrence uses
+ * (tests only): exp_neg[i] = exp(-x[i]), sin/cos(x[i]), rcp_x[i] = 1 / x[i] for
+ * n host values x >= 0.
+ */
+MTG_API int mtg_math_probe(mtg_ctx *ctx, int64_t n, const double *x, double *exp_neg, double *sin_x,
+                           double *cos_x, double *rcp_x);
 /* 1 if (jr, jc) has a compiled kernel. */
 MTG_API int mtg_structure_supported(int jr, int jc);
 

@@ -48,7 +48,7 @@ struct mtg_ctx {
     // light curves (resident)
     int64_t N = 0, L = 0;
     int t_per_lc = 0;
-    DevBuf t, dx, y, var, dy_tmp;
+    DevBuf t, dx, y, var, dy_tmp, dxmax;
 
     // model
     bool has_model = false;
@@ -174,6 +174,7 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     sa.var = ctx->var.as<double>();
     sa.N = ctx->N;
     sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
+    sa.dxmax = ctx->dxmax.as<double>();
     sa.mean_kind = m.mean_kind;
     for (int k = 0; k < nsig; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
@@ -249,7 +250,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->t, &ctx->dx, &ctx->y, &ctx->var, &ctx->dy_tmp, &ctx->coef, &ctx->lists,
+    DevBuf *bufs[] = {&ctx->t, &ctx->dx, &ctx->y, &ctx->var, &ctx->dy_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -270,21 +271,26 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     if (!ctx) return MTG_E_ARG;
     if (N <= 0 || L <= 0 || !t || !y || !yerr)
         return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, yerr");
-    if (L * N > (int64_t)1 << 40) return fail(ctx, MTG_E_ARG, "light-curve set too large");
+    // the solve kernel addresses samples with 32-bit byte offsets
+    if (L * N >= ((int64_t)1 << 29))
+        return fail(ctx, MTG_E_ARG, "light-curve set too large: L * N must be below 2^29 samples");
     int rc = use_device(ctx);
     if (rc) return rc;
     const int64_t t_rows = t_per_lc ? L : 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, ctx->t.reserve((size_t)t_rows * N * 8));
-    HIP_TRY(ctx, ctx->dx.reserve((size_t)t_rows * N * 8));
-    HIP_TRY(ctx, ctx->y.reserve((size_t)L * N * 8));
-    HIP_TRY(ctx, ctx->var.reserve((size_t)L * N * 8));
+    // + 64 B: the solve kernel prefetches one element past the last sample
+    HIP_TRY(ctx, ctx->t.reserve((size_t)t_rows * N * 8 + 64));
+    HIP_TRY(ctx, ctx->dx.reserve((size_t)t_rows * N * 8 + 64));
+    HIP_TRY(ctx, ctx->y.reserve((size_t)L * N * 8 + 64));
+    HIP_TRY(ctx, ctx->var.reserve((size_t)L * N * 8 + 64));
     HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)L * N * 8));
+    HIP_TRY(ctx, ctx->dxmax.reserve(64));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dxmax.p, 0, 8, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->y.p, y, (size_t)L * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr, (size_t)L * N * 8, kind, ctx->stream));
     mtg_launch_lc_setup(N, L, t_rows, ctx->t.as<double>(), ctx->dy_tmp.as<double>(),
-                        ctx->dx.as<double>(), ctx->var.as<double>(), ctx->stream);
+                        ctx->dx.as<double>(), ctx->var.as<double>(), ctx->dxmax.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->L = L; ctx->t_per_lc = t_per_lc ? 1 : 0;
@@ -482,8 +488,10 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
             asum += a_comp[b * jc + k];
         }
         h[lay.asum() * cs + b] = asum;
-        h[lay.mean(0) * cs + b] = mean_params ? mean_params[b * nmean] : 0.0;
-        h[lay.mean(1) * cs + b] = (mean_params && nmean == 2) ? mean_params[b * nmean + 1] : 0.0;
+        // slots are (slope, intercept); a constant mean is slope 0
+        const double m0 = mean_params ? mean_params[b * nmean] : 0.0;
+        h[lay.mean(0) * cs + b] = nmean == 2 ? m0 : 0.0;
+        h[lay.mean(1) * cs + b] = nmean == 2 ? mean_params[b * nmean + 1] : m0;
     }
     hipError_t e = hipMemcpyAsync(ctx->coef.p, h, (size_t)cs * lay.nslots() * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -514,6 +522,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.var = ctx->var.as<double>();
     sa.N = ctx->N;
     sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
+    sa.dxmax = ctx->dxmax.as<double>();
     sa.mean_kind = mean_kind;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
@@ -523,6 +532,31 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(status, ctx->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTG_OK;
+}
+
+MTG_API int mtg_math_probe(mtg_ctx *ctx, int64_t n, const double *x, double *exp_neg, double *sin_x,
+                           double *cos_x, double *rcp_x)
+{
+    if (!ctx || n <= 0 || !x || !exp_neg || !sin_x || !cos_x || !rcp_x) return MTG_E_ARG;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    DevBuf buf;
+    HIP_TRY(ctx, buf.reserve((size_t)n * 8 * 5));
+    double *d = buf.as<double>();
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d, x, (size_t)n * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        mtg_launch_math_probe(n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(exp_neg, d + n, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(sin_x, d + 2 * n, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(cos_x, d + 3 * n, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(rcp_x, d + 4 * n, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    buf.release();
+    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_math_probe: %s", hipGetErrorString(e));
     return MTG_OK;
 }
 

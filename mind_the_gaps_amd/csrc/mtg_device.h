@@ -29,7 +29,7 @@ struct MtgModel {
 // Coefficient workspace: structure-of-arrays, one column per evaluation so that
 // lane e reads/writes coef[slot * stride + e] (coalesced).  Slots:
 //   a_real[nr_max] c_real[nr_max] a_comp[nc_max] b_comp[nc_max] c_comp[nc_max]
-//   d_comp[nc_max] asum(= sum a + jitter) mean0 mean1
+//   d_comp[nc_max] asum(= sum a + jitter) mean_slope mean_intercept
 struct MtgCoefLayout {
     int nr_max, nc_max;
     __host__ __device__ int ar(int j) const { return j; }
@@ -73,6 +73,7 @@ struct MtgSolveArgs {
     const double *var;  // [L][N]  yerr^2
     int64_t N;
     int64_t t_stride;  // 0 (shared sampling) or N
+    const double *dxmax;  // [1] max_n dx_n (device): decides table vs OCML sincos per wave
     int mean_kind;
 };
 
@@ -81,4 +82,6 @@ typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStre
 mtg_solve_launcher mtg_find_solver(int nr, int nc);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *yerr,
-                         double *dx, double *var, hipStream_t);
+                         double *dx, double *var, double *dxmax, hipStream_t);
+void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,
+                           hipStream_t);

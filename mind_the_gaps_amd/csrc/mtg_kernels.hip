@@ -17,6 +17,7 @@
 // Roofline: nominally HBM (24 N bytes of t, y, sigma^2 per evaluation), in
 // practice FP64 VALU issue; there is no dense contraction here, so no MFMA.
 #include "mtg_device.h"
+#include "mtg_math.h"
 
 #include <math.h>
 
@@ -28,7 +29,7 @@
 __global__ void __launch_bounds__(256)
 mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restrict__ t,
                     const double *__restrict__ yerr, double *__restrict__ dx,
-                    double *__restrict__ var)
+                    double *__restrict__ var, unsigned long long *__restrict__ dxmax_bits)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,20 +37,25 @@ mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restri
         const double s = yerr[i];  // celerite squares the yerr handed to compute()
         var[i] = s * s;
     }
+    double mx = 0.0;
     for (int64_t i = i0; i < t_rows * N; i += stride) {
         const int64_t n = i % N;
-        dx[i] = n == 0 ? 0.0 : t[i] - t[i - 1];
+        const double d = n == 0 ? 0.0 : t[i] - t[i - 1];
+        dx[i] = d;
+        mx = fmax(mx, d);
     }
+    // max over the grid: non-negative doubles order like their bit patterns
+    atomicMax(dxmax_bits, (unsigned long long)__double_as_longlong(mx));
 }
 
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *yerr,
-                         double *dx, double *var, hipStream_t stream)
+                         double *dx, double *var, double *dxmax, hipStream_t stream)
 {
     int64_t blocks = (L * N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mtg_lc_setup_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, L,
-                       t_rows, t, yerr, dx, var);
+                       t_rows, t, yerr, dx, var, (unsigned long long *)dxmax);
 }
 
 // ---------------------------------------------------------------------------
@@ -185,8 +191,9 @@ __global__ void __launch_bounds__(256) mtg_prepare_kernel(MtgPrepArgs a)
             }
         }
         c[lay.asum() * cs] = asum;
-        c[lay.mean(0) * cs] = par(m.nk);
-        c[lay.mean(1) * cs] = m.mean_kind == MTG_MEAN_LINEAR ? par(m.nk + 1) : 0.0;
+        // mean(t) = slope * t + intercept; a constant mean is slope 0 (exactly the value)
+        c[lay.mean(0) * cs] = m.mean_kind == MTG_MEAN_LINEAR ? par(m.nk) : 0.0;
+        c[lay.mean(1) * cs] = m.mean_kind == MTG_MEAN_LINEAR ? par(m.nk + 1) : par(m.nk);
     }
 
     if (a.nsig > 1) {
@@ -216,102 +223,85 @@ void mtg_launch_prepare(const MtgPrepArgs &a, hipStream_t stream)
 // ---------------------------------------------------------------------------
 // fused factorisation + forward solve, one lane per evaluation
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double mtg_exp(double x) { return exp(x); }
-__device__ __forceinline__ void mtg_sincos(double x, double *s, double *c) { sincos(x, s, c); }
-
-template <int NR, int NC>
-__global__ void __launch_bounds__(64) mtg_solve_kernel(MtgSolveArgs a)
+// Waves per SIMD the register allocator must leave room for (512 VGPRs / waves):
+// the state is J(J+1)/2 + 4J + ... doubles per lane, so the target drops with J.
+#ifndef MTG_WAVES_BIAS
+#define MTG_WAVES_BIAS 0
+#endif
+__host__ __device__ constexpr int mtg_waves_for(int J)
 {
-    constexpr int J = NR + 2 * NC;   // celerite rank
-    constexpr int NT = NR + NC;      // distinct exp(-c dx) factors
-    const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
-    if (gid >= count) return;
-    const int64_t e = a.list ? (int64_t)a.list[gid] : gid;
-    if (!a.list && a.status[e] != MTG_ST_OK) return;  // prior said -inf
+    return (J <= 2 ? 5 : J <= 3 ? 4 : J <= 5 ? 3 : J <= 8 ? 2 : 1) + MTG_WAVES_BIAS;
+}
 
-    // ---- coefficients of this evaluation -------------------------------
-    const double *cf = a.coef + e;
-    const int64_t cs = a.cstride;
+// Per-lane state of one evaluation, all statically indexed -> VGPRs.
+template <int NR, int NC>
+struct MtgLane {
+    static constexpr int J = NR + 2 * NC;
     double ar[NR > 0 ? NR : 1], cr[NR > 0 ? NR : 1];
     double ac[NC > 0 ? NC : 1], bc[NC > 0 ? NC : 1], cc[NC > 0 ? NC : 1], dc[NC > 0 ? NC : 1];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        ar[j] = cf[a.lay.ar(j) * cs];
-        cr[j] = cf[a.lay.cr(j) * cs];
-    }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        ac[k] = cf[a.lay.ac(k) * cs];
-        bc[k] = cf[a.lay.bc(k) * cs];
-        cc[k] = cf[a.lay.cc(k) * cs];
-        dc[k] = cf[a.lay.dc(k) * cs];
-    }
-    const double asum = cf[a.lay.asum() * cs];
-    const double mean0 = cf[a.lay.mean(0) * cs];
-    const double mean1 = cf[a.lay.mean(1) * cs];
-    const bool linear = a.mean_kind == MTG_MEAN_LINEAR;
-
-    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[e] : 0;
-    const int64_t N = a.N;
-    const double *yp = a.y + lc * N;
-    const double *vp = a.var + lc * N;
-    const double *dxp = a.dx + lc * a.t_stride;
-    const double *tp = a.t + lc * a.t_stride;
-
-    // ---- recurrence state (all statically indexed -> VGPRs) -------------
+    double asum, slope, icpt;
     double S[J * (J + 1) / 2];
     double Wt[J];  // V_n - S U_n  (W_n = Wt / D_n)
     double f[J];
-    double cs_[NC > 0 ? NC : 1], sn_[NC > 0 ? NC : 1];  // cos/sin d_k (t_n - t_0)
-#pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) S[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < J; ++i) { Wt[i] = 0.0; f[i] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) { cs_[k] = 1.0; sn_[k] = 0.0; }
+    double cs[NC > 0 ? NC : 1], sn[NC > 0 ? NC : 1];  // cos/sin d_k (t_n - t_0)
+    double invD, z, dot, dprod;
+    int dexp;
+    bool bad;
+};
 
-    double invD = 0.0, z = 0.0, dot = 0.0;
-    double dprod = 1.0;  // running product of pivots, exponent kept in dexp
-    int dexp = 0;
-    bool bad = false;
+// The sweep over the N samples: ONE basic block per step (no branch besides the
+// back edge), so the scheduler can hoist the five table look-ups and the next
+// sample's loads above the polynomial/recurrence arithmetic.
+//   FAST: every lane's d_k * max(dx) is inside the exact range of the table sincos.
+template <int NR, int NC, bool FAST>
+__device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, uint32_t yoff,
+                                          uint32_t toff, const MtgMathTables *tab)
+{
+    constexpr int J = NR + 2 * NC;
+    constexpr int NT = NR + NC;  // distinct exp(-c dx) factors
+    const char *ybase = (const char *)a.y, *vbase = (const char *)a.var;
+    const char *dbase = (const char *)a.dx, *tbase = (const char *)a.t;
+    auto ld = [](const char *base, uint32_t off) { return *(const double *)(base + off); };
 
-    double dx_n = dxp[0], y_n = yp[0], v_n = vp[0], t_n = linear ? tp[0] : 0.0;
-    for (int64_t n = 0; n < N; ++n) {
+    double dx_n = ld(dbase, toff), t_n = ld(tbase, toff), y_n = ld(ybase, yoff), v_n = ld(vbase, yoff);
+    const uint32_t N = (uint32_t)a.N;
+    for (uint32_t n = 0; n < N; ++n) {
         const double dxc = dx_n, yc = y_n, vc = v_n, tc = t_n;
-        if (n + 1 < N) {  // prefetch the next sample under this step's arithmetic
-            dx_n = dxp[n + 1]; y_n = yp[n + 1]; v_n = vp[n + 1];
-            if (linear) t_n = tp[n + 1];
-        }
-        // -- per-term propagators and generators (celerite U, V, phi) -----
+        // prefetch the next sample under this step's arithmetic (every buffer carries
+        // one element of slack, so the last iteration reads a valid, unused address)
+        yoff += 8; toff += 8;
+        dx_n = ld(dbase, toff); t_n = ld(tbase, toff); y_n = ld(ybase, yoff); v_n = ld(vbase, yoff);
+
+        // -- per-term propagators and generators (celerite phi, U, V) ---------
         double ph[NT > 0 ? NT : 1];
         double U[J], V[J];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            ph[j] = mtg_exp(-cr[j] * dxc);
-            U[j] = ar[j];
+            ph[j] = mtg_exp(-L.cr[j] * dxc, tab);
+            U[j] = L.ar[j];
             V[j] = 1.0;
         }
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-            ph[NR + k] = mtg_exp(-cc[k] * dxc);
+            ph[NR + k] = mtg_exp(-L.cc[k] * dxc, tab);
             double sd, cd;
-            mtg_sincos(dc[k] * dxc, &sd, &cd);
-            // rotate (cos, sin) d_k (t - t_0) by d_k dx: the kernel depends on
-            // time differences only, so the phase origin is free.
-            const double cn = cs_[k] * cd - sn_[k] * sd;
-            const double sn = sn_[k] * cd + cs_[k] * sd;
-            cs_[k] = cn; sn_[k] = sn;
-            U[NR + 2 * k] = ac[k] * cn + bc[k] * sn;
-            U[NR + 2 * k + 1] = ac[k] * sn - bc[k] * cn;
+            if (FAST) mtg_sincos_fast(L.dc[k] * dxc, &sd, &cd, tab);
+            else sincos(L.dc[k] * dxc, &sd, &cd);
+            // rotate (cos, sin) d_k (t - t_0) by d_k dx: the kernel depends on time
+            // differences only, so the phase origin is free
+            const double cn = L.cs[k] * cd - L.sn[k] * sd;
+            const double sn = L.sn[k] * cd + L.cs[k] * sd;
+            L.cs[k] = cn; L.sn[k] = sn;
+            U[NR + 2 * k] = L.ac[k] * cn + L.bc[k] * sn;
+            U[NR + 2 * k + 1] = L.ac[k] * sn - L.bc[k] * cn;
             V[NR + 2 * k] = cn;
             V[NR + 2 * k + 1] = sn;
         }
-        // -- S <- (phi phi^T) o (S + D W W^T) ;  f <- phi o (f + W z) ------
-        const double zs = z * invD;
+        // -- S <- (phi phi^T) o (S + D W W^T) ;  f <- phi o (f + W z) ----------
+        const double zs = L.z * L.invD;
         double wd[J];
 #pragma unroll
-        for (int i = 0; i < J; ++i) wd[i] = Wt[i] * invD;
+        for (int i = 0; i < J; ++i) wd[i] = L.Wt[i] * L.invD;
 #pragma unroll
         for (int i = 0; i < J; ++i) {
             const int ti = i < NR ? i : NR + (i - NR) / 2;
@@ -319,43 +309,122 @@ __global__ void __launch_bounds__(64) mtg_solve_kernel(MtgSolveArgs a)
             for (int j = 0; j <= i; ++j) {
                 const int tj = j < NR ? j : NR + (j - NR) / 2;
                 const double pp = ph[ti] * ph[tj];
-                S[i * (i + 1) / 2 + j] = pp * fma(Wt[i], wd[j], S[i * (i + 1) / 2 + j]);
+                L.S[i * (i + 1) / 2 + j] = pp * fma(L.Wt[i], wd[j], L.S[i * (i + 1) / 2 + j]);
             }
-            f[i] = ph[ti] * fma(Wt[i], zs, f[i]);
+            L.f[i] = ph[ti] * fma(L.Wt[i], zs, L.f[i]);
         }
-        // -- D_n = A_n - U^T S U ; Wt = V - S U ; z_n = r_n - U^T f ---------
-        double D = vc + asum;
-        double zn = yc - (linear ? fma(mean0, tc, mean1) : mean0);
+        // -- D_n = A_n - U^T S U ; Wt = V - S U ; z_n = r_n - U^T f -------------
+        double D = vc + L.asum;
+        double zn = yc - fma(L.slope, tc, L.icpt);
 #pragma unroll
         for (int i = 0; i < J; ++i) {
             double q = 0.0;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int hi = i > j ? i : j, lo = i > j ? j : i;
-                q = fma(S[hi * (hi + 1) / 2 + lo], U[j], q);
+                q = fma(L.S[hi * (hi + 1) / 2 + lo], U[j], q);
             }
-            Wt[i] = V[i] - q;
+            L.Wt[i] = V[i] - q;
             D = fma(-U[i], q, D);
-            zn = fma(-U[i], f[i], zn);
+            zn = fma(-U[i], L.f[i], zn);
         }
-        bad = bad || !(D > 0.0);
-        invD = 1.0 / D;
-        z = zn;
-        dot = fma(zn * zn, invD, dot);
-        dprod *= D;
-        if ((n & 3) == 3) {  // keep the pivot product in range: D in (1e-24, 1e22)
-            int ex;
-            dprod = frexp(dprod, &ex);
-            dexp += ex;
-        }
+        L.bad = L.bad | !(D > 0.0);
+        L.invD = mtg_rcp(D);
+        L.z = zn;
+        L.dot = fma(zn * zn, L.invD, L.dot);
+        // ln det K = ln prod D_n: running product with the exponent peeled off every step
+        const double pr = L.dprod * D;
+        L.dprod = __builtin_amdgcn_frexp_mant(pr);
+        L.dexp += __builtin_amdgcn_frexp_exp(pr);
     }
-    const double logdet = log(dprod) + (double)dexp * 0.69314718055994530942;
-    double ll = -0.5 * (dot + logdet + (double)N * MTG_LN_2PI);
+}
+
+template <int NR, int NC>
+__global__ void __launch_bounds__(64, mtg_waves_for(NR + 2 * NC)) mtg_solve_kernel(MtgSolveArgs a)
+{
+    constexpr int J = NR + 2 * NC;  // celerite rank
+    __shared__ MtgMathTables tab;
+    mtg_fill_tables(&tab, threadIdx.x);
+    __syncthreads();
+    const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if (gid >= count) return;
+    const int64_t e = a.list ? (int64_t)a.list[gid] : gid;
+    if (!a.list && a.status[e] != MTG_ST_OK) return;  // prior said -inf
+
+    // ---- coefficients of this evaluation -----------------------------------
+    MtgLane<NR, NC> L;
+    const double *cf = a.coef + e;
+    const int64_t cs = a.cstride;
+    double dmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        L.ar[j] = cf[a.lay.ar(j) * cs];
+        L.cr[j] = cf[a.lay.cr(j) * cs];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        L.ac[k] = cf[a.lay.ac(k) * cs];
+        L.bc[k] = cf[a.lay.bc(k) * cs];
+        L.cc[k] = cf[a.lay.cc(k) * cs];
+        L.dc[k] = cf[a.lay.dc(k) * cs];
+        dmax = fmax(dmax, fabs(L.dc[k]));
+    }
+    L.asum = cf[a.lay.asum() * cs];
+    L.slope = cf[a.lay.mean(0) * cs];
+    L.icpt = cf[a.lay.mean(1) * cs];
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) L.S[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < J; ++i) { L.Wt[i] = 0.0; L.f[i] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { L.cs[k] = 1.0; L.sn[k] = 0.0; }
+    L.invD = 0.0; L.z = 0.0; L.dot = 0.0; L.dprod = 1.0; L.dexp = 0; L.bad = false;
+
+    const uint32_t lc = a.lc_index ? (uint32_t)a.lc_index[e] : 0u;
+    const uint32_t yoff = lc * (uint32_t)a.N * 8u;                 // L * N * 8 < 4 GiB (checked on the host)
+    const uint32_t toff = lc * (uint32_t)a.t_stride * 8u;
+
+    // table sincos is exact while d_k * dx < MTG_TRIG_FAST_MAX for every lane of the wave
+    const bool fast = !__any(!(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
+    if (fast) mtg_sweep<NR, NC, true>(L, a, yoff, toff, &tab);
+    else mtg_sweep<NR, NC, false>(L, a, yoff, toff, &tab);
+
+    const double logdet = log(L.dprod) + (double)L.dexp * 0.69314718055994530942;
+    double ll = -0.5 * (L.dot + logdet + (double)a.N * MTG_LN_2PI);
     int st = MTG_ST_OK;
-    if (bad) { st = MTG_ST_NOTPD; ll = -INFINITY; }
+    if (L.bad) { st = MTG_ST_NOTPD; ll = -INFINITY; }
     else if (!isfinite(ll)) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
     a.out[e] = ll;
     a.status[e] = st;
+}
+
+// accuracy probe of the device math (tests only): e = exp(-x), (s, c) = sincos(x)
+__global__ void __launch_bounds__(256)
+mtg_math_probe_kernel(int64_t n, const double *x, double *e, double *s, double *c, double *rcp)
+{
+    __shared__ MtgMathTables tab;
+    mtg_fill_tables(&tab, threadIdx.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const double xv = live ? x[i] : 1.0;
+    const double ev = mtg_exp(-xv, &tab);
+    double sv, cv;
+    mtg_sincos(xv, &sv, &cv, &tab);
+    if (live) {
+        e[i] = ev;
+        s[i] = sv;
+        c[i] = cv;
+        rcp[i] = mtg_rcp(xv);
+    }
+}
+
+void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL(mtg_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       n, x, e, s, c, rcp);
 }
 
 template <int NR, int NC>

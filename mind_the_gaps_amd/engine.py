@@ -25,6 +25,7 @@ EXPORTS = (
     "mtg_last_error", "mtg_set_lightcurves", "mtg_set_lightcurves_device", "mtg_set_model",
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
+    "mtg_math_probe",
 )
 
 
@@ -88,6 +89,8 @@ def load_library():
     lib.mtg_profile_begin.argtypes = [c_vp, c_int]
     lib.mtg_profile_read.restype = c_int
     lib.mtg_profile_read.argtypes = [c_vp, c_int, _dp, _dp]
+    lib.mtg_math_probe.restype = c_int
+    lib.mtg_math_probe.argtypes = [c_vp, c_i64, _dp, _dp, _dp, _dp, _dp]
     lib.mtg_structure_supported.restype = c_int
     lib.mtg_structure_supported.argtypes = [c_int, c_int]
     _lib = lib
@@ -245,6 +248,13 @@ class Engine:
         if n < 0:
             self._check(n)
         return prep[:n], solve[:n]
+
+    def math_probe(self, x):
+        """Device exp(-x), sin(x), cos(x), 1/x of the kernel's own math (accuracy tests)."""
+        x = _f64(x).ravel()
+        outs = [np.empty_like(x) for _ in range(4)]
+        self._check(self._lib.mtg_math_probe(self._ctx, len(x), _ptr(x), *[_ptr(o) for o in outs]))
+        return outs
 
     def synchronize(self):
         self._check(self._lib.mtg_synchronize(self._ctx))
