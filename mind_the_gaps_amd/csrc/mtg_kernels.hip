@@ -243,7 +243,11 @@ struct MtgLane {
     double S[J * (J + 1) / 2];
     double Wt[J];  // V_n - S U_n  (W_n = Wt / D_n)
     double f[J];
-    double cs[NC > 0 ? NC : 1], sn[NC > 0 ? NC : 1];  // cos/sin d_k (t_n - t_0)
+    double cs[NC > 0 ? NC : 1], sn[NC > 0 ? NC : 1];  // cos/sin d_k (t_n - t_0)   (OCML path)
+    double pr[NC > 0 ? NC : 1];                        // phase d_k (t_n - t_0) = pm pi/32 + pr
+    int pm[NC > 0 ? NC : 1];                           //   pm = 16 * (m mod N_trig) (table path)
+    double ncr[NR > 0 ? NR : 1], cr64[NR > 0 ? NR : 1];  // -c and -c 8 N_exp/ln2 of the real terms
+    double ncc[NC > 0 ? NC : 1], cc64[NC > 0 ? NC : 1];  // same for the complex terms
     double invD, z, dot, dprod;
     int dexp;
     bool bad;
@@ -277,21 +281,25 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         double U[J], V[J];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            ph[j] = mtg_exp(-L.cr[j] * dxc, tab);
+            ph[j] = mtg_exp_cdx(L.ncr[j], L.cr64[j], dxc, tab);
             U[j] = L.ar[j];
             V[j] = 1.0;
         }
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-            ph[NR + k] = mtg_exp(-L.cc[k] * dxc, tab);
-            double sd, cd;
-            if (FAST) mtg_sincos_fast(L.dc[k] * dxc, &sd, &cd, tab);
-            else sincos(L.dc[k] * dxc, &sd, &cd);
-            // rotate (cos, sin) d_k (t - t_0) by d_k dx: the kernel depends on time
-            // differences only, so the phase origin is free
-            const double cn = L.cs[k] * cd - L.sn[k] * sd;
-            const double sn = L.sn[k] * cd + L.cs[k] * sd;
-            L.cs[k] = cn; L.sn[k] = sn;
+            ph[NR + k] = mtg_exp_cdx(L.ncc[k], L.cc64[k], dxc, tab);
+            // (cos, sin) of d_k (t_n - t_0): the kernel depends on time differences
+            // only, so the phase origin is free
+            double cn, sn;
+            if (FAST) {
+                mtg_phase_step(L.dc[k], dxc, L.pr[k], L.pm[k], &sn, &cn, tab);
+            } else {  // huge d_k dx somewhere in this wave: OCML sincos + rotation
+                double sd, cd;
+                sincos(L.dc[k] * dxc, &sd, &cd);
+                cn = L.cs[k] * cd - L.sn[k] * sd;
+                sn = L.sn[k] * cd + L.cs[k] * sd;
+                L.cs[k] = cn; L.sn[k] = sn;
+            }
             U[NR + 2 * k] = L.ac[k] * cn + L.bc[k] * sn;
             U[NR + 2 * k + 1] = L.ac[k] * sn - L.bc[k] * cn;
             V[NR + 2 * k] = cn;
@@ -339,14 +347,16 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
     }
 }
 
+#define MTG_BLOCK 256
+
 template <int NR, int NC>
-__global__ void __launch_bounds__(64, mtg_waves_for(NR + 2 * NC)) mtg_solve_kernel(MtgSolveArgs a)
+__global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_solve_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;  // celerite rank
     __shared__ MtgMathTables tab;
-    mtg_fill_tables(&tab, threadIdx.x);
+    mtg_fill_tables(&tab, threadIdx.x, MTG_BLOCK, NC > 0);
     __syncthreads();
-    const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * MTG_BLOCK + threadIdx.x;
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
     if (gid >= count) return;
     const int64_t e = a.list ? (int64_t)a.list[gid] : gid;
@@ -378,7 +388,12 @@ __global__ void __launch_bounds__(64, mtg_waves_for(NR + 2 * NC)) mtg_solve_kern
 #pragma unroll
     for (int i = 0; i < J; ++i) { L.Wt[i] = 0.0; L.f[i] = 0.0; }
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { L.cs[k] = 1.0; L.sn[k] = 0.0; }
+    for (int k = 0; k < NC; ++k) {
+        L.cs[k] = 1.0; L.sn[k] = 0.0; L.pr[k] = 0.0; L.pm[k] = 0;
+        L.ncc[k] = -L.cc[k]; L.cc64[k] = L.cc[k] * -MTG_EXP_CSCALE;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { L.ncr[j] = -L.cr[j]; L.cr64[j] = L.cr[j] * -MTG_EXP_CSCALE; }
     L.invD = 0.0; L.z = 0.0; L.dot = 0.0; L.dprod = 1.0; L.dexp = 0; L.bad = false;
 
     const uint32_t lc = a.lc_index ? (uint32_t)a.lc_index[e] : 0u;
@@ -404,14 +419,21 @@ __global__ void __launch_bounds__(256)
 mtg_math_probe_kernel(int64_t n, const double *x, double *e, double *s, double *c, double *rcp)
 {
     __shared__ MtgMathTables tab;
-    mtg_fill_tables(&tab, threadIdx.x);
+    mtg_fill_tables(&tab, threadIdx.x, 256, true);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const double xv = live ? x[i] : 1.0;
-    const double ev = mtg_exp(-xv, &tab);
+    // the sweep's own functions: exp(-c dx) with c = 1, one phase step from phase 0
+    const double ev = mtg_exp_cdx(-1.0, -MTG_EXP_CSCALE, xv, &tab);
     double sv, cv;
-    mtg_sincos(xv, &sv, &cv, &tab);
+    if (__any(!(xv <= MTG_TRIG_FAST_MAX))) {
+        sincos(xv, &sv, &cv);
+    } else {
+        double r = 0.0;
+        int m16 = 0;
+        mtg_phase_step(1.0, xv, r, m16, &sv, &cv, &tab);
+    }
     if (live) {
         e[i] = ev;
         s[i] = sv;
@@ -430,9 +452,9 @@ void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, dou
 template <int NR, int NC>
 static void mtg_launch_solve(const MtgSolveArgs &a, int64_t nlanes, hipStream_t stream)
 {
-    const int64_t blocks = (nlanes + 63) / 64;
+    const int64_t blocks = (nlanes + MTG_BLOCK - 1) / MTG_BLOCK;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL((mtg_solve_kernel<NR, NC>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((mtg_solve_kernel<NR, NC>), dim3((unsigned)blocks), dim3(MTG_BLOCK), 0, stream, a);
 }
 
 // Compiled structures: NR real + NC complex terms, J = NR + 2 NC <= MTG_MAX_J.

@@ -9,11 +9,11 @@
 // through VGPRs.  These versions trade polynomial degree for two small LDS
 // tables (filled once per workgroup):
 //
-//   exp(y)    = 2^k * T[j] * (1 + p(r)),  y = (64 k + j) ln2/64 + r, |r| <= ln2/128,
-//               p of degree 5                         -> 13 FP64 ops + 1 ds_read_b64
-//   sincos(x) : x = m pi/32 + r, |r| <= pi/64, (cos, sin)(m pi/32) from a 64-entry
-//               table, sin r / cos r of degree 7 / 8, angle addition
-//                                                      -> 20 FP64 ops + 1 ds_read_b128
+//   exp(y)    = 2^k * T[j] * (1 + p(r)),  y = (N k + j) ln2/N + r, |r| <= ln2/2N,
+//               N = 2048: p of degree 3                 -> 12 VALU + 1 ds_read_b64
+//   sincos(x) : x = m 2pi/N + r, |r| <= pi/N, (cos, sin)(2 pi m/N) from the table,
+//               N = 2048: sin r / cos r of degree 3 / 4, angle addition
+//                                                      -> 16 VALU + 1 ds_read_b128
 //
 // Both are accurate to ~1 ulp (tests/test_device_math_gpu.py); arguments beyond
 // the exactness range of the Cody-Waite reductions fall back to OCML through a
@@ -21,78 +21,134 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Table sizes (log2 entries).  Bigger tables shorten the polynomials: every VALU
+// instruction, FP64 or not, costs the wave one 4-cycle issue slot, and the sweep is
+// issue bound.  2^11 + 2^11 entries = 16 KiB + 32 KiB of LDS per workgroup.
+#ifndef MTG_EXP_BITS
+#define MTG_EXP_BITS 11
+#endif
+#ifndef MTG_TRIG_BITS
+#define MTG_TRIG_BITS 11
+#endif
+#define MTG_EXP_N (1 << MTG_EXP_BITS)
+#define MTG_TRIG_N (1 << MTG_TRIG_BITS)
+
 struct MtgMathTables {
-    double exp2_frac[64];  // 2^(j/64)
-    double2 cis[64];       // (cos, sin)(2 pi j / 64)
+    double exp2_frac[MTG_EXP_N];  // 2^(j / N)
+    double2 cis[MTG_TRIG_N];      // (cos, sin)(2 pi j / N)
 };
 
-// One entry per lane; call with all 64 lanes of the first wave active, then barrier.
-__device__ __forceinline__ void mtg_fill_tables(MtgMathTables *tab, int lane)
+// Cooperative fill by the whole workgroup; follow with __syncthreads().
+__device__ __forceinline__ void mtg_fill_tables(MtgMathTables *tab, int tid, int nthreads, bool trig)
 {
-    if (lane < 64) {
-        tab->exp2_frac[lane] = exp2((double)lane * (1.0 / 64.0));
-        double s, c;
-        sincospi((double)lane * (1.0 / 32.0), &s, &c);
-        tab->cis[lane] = make_double2(c, s);
-    }
+    for (int j = tid; j < MTG_EXP_N; j += nthreads)
+        tab->exp2_frac[j] = exp2((double)j * (1.0 / MTG_EXP_N));
+    if (trig)
+        for (int j = tid; j < MTG_TRIG_N; j += nthreads) {
+            double s, c;
+            sincospi((double)j * (2.0 / MTG_TRIG_N), &s, &c);
+            tab->cis[j] = make_double2(c, s);
+        }
 }
 
-// exp(y) for y <= 0.  Any y <= 0 is safe: y is clamped at -1e4, where the result
-// has long underflowed to 0 through ldexp.
-__device__ __forceinline__ double mtg_exp(double y, const MtgMathTables *tab)
+// exp(r) - 1 on |r| <= ln2 / 2^(BITS+1), truncation error below 4e-17 absolute.
+__device__ __forceinline__ double mtg_expm1_small(double r)
 {
-    y = __builtin_fmax(y, -1.0e4);
-    const double kd = __builtin_rint(y * 0x1.71547652b82fep+6);           // y * 64 / ln2
-    double r = __builtin_fma(kd, -0x1.62e42fee00000p-7, y);                // ln2/64, 32 high bits
-    r = __builtin_fma(kd, -0x1.a39ef35793c76p-39, r);                      // ln2/64, low part
-    const int ki = (int)kd;
-    const double t = tab->exp2_frac[ki & 63];
-    // exp(r) - 1 = r + r^2 (1/2 + r/6 + r^2/24 + r^3/120 + r^4/720), |r| <= 0.0055
-    double p = 0x1.6c16c16c16c17p-10;
+#if MTG_EXP_BITS >= 11
+    const double p = __builtin_fma(r, 0x1.5555555555555p-3, 0.5);                  // 1/2 + r/6
+#elif MTG_EXP_BITS >= 8
+    double p = 0x1.5555555555555p-5;                                                // 1/24
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, r, 0.5);
+#else
+    double p = 0x1.6c16c16c16c17p-10;                                               // 1/720
     p = __builtin_fma(p, r, 0x1.1111111111111p-7);
     p = __builtin_fma(p, r, 0x1.5555555555555p-5);
     p = __builtin_fma(p, r, 0x1.5555555555555p-3);
     p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p * r, r, r);
-    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 6);
+#endif
+    return __builtin_fma(p * r, r, r);
 }
 
-// Largest argument for which m = rint(x 32/pi) < 2^22 keeps m * P1, m * P2 exact.
-#define MTG_TRIG_FAST_MAX 4.0e5
-
-__device__ __forceinline__ void mtg_sincos_fast(double x, double *sn, double *cs,
-                                                const MtgMathTables *tab)
+// (sin r, cos r) on |r| <= pi / 2^BITS, truncation error below 1e-16 absolute.
+__device__ __forceinline__ void mtg_sincos_small(double r, double *s, double *c)
 {
-    const double md = __builtin_rint(x * 0x1.45f306dc9c883p+3);            // x * 32 / pi
-    double r = __builtin_fma(md, -0x1.921fb54000000p-4, x);                // pi/32 in 30 + 30 + 53 bits
-    r = __builtin_fma(md, -0x1.10b4611800000p-34, r);
-    r = __builtin_fma(md, -0x1.313198a2e0370p-65, r);
-    const double2 cj = tab->cis[(int)md & 63];
     const double z = r * r;
-    // sin r = r + r^3 (-1/6 + z/120 - z^2/5040), cos r = 1 + z (-1/2 + z/24 - z^2/720 + z^3/40320)
+#if MTG_TRIG_BITS >= 11
+    *s = __builtin_fma(r * z, -0x1.5555555555555p-3, r);                            // r - r^3/6
+    *c = __builtin_fma(__builtin_fma(z, 0x1.5555555555555p-5, -0.5), z, 1.0);       // 1 - z/2 + z^2/24
+#elif MTG_TRIG_BITS >= 8
+    const double ps = __builtin_fma(z, 0x1.1111111111111p-7, -0x1.5555555555555p-3);
+    *s = __builtin_fma(r * z, ps, r);
+    double pc = -0x1.6c16c16c16c17p-10;
+    pc = __builtin_fma(pc, z, 0x1.5555555555555p-5);
+    pc = __builtin_fma(pc, z, -0.5);
+    *c = __builtin_fma(pc, z, 1.0);
+#else
     double ps = -0x1.a01a01a01a01ap-13;
     ps = __builtin_fma(ps, z, 0x1.1111111111111p-7);
     ps = __builtin_fma(ps, z, -0x1.5555555555555p-3);
+    *s = __builtin_fma(r * z, ps, r);
     double pc = 0x1.a01a01a01a01ap-16;
     pc = __builtin_fma(pc, z, -0x1.6c16c16c16c17p-10);
     pc = __builtin_fma(pc, z, 0x1.5555555555555p-5);
     pc = __builtin_fma(pc, z, -0.5);
-    const double s = __builtin_fma(r * z, ps, r);
-    const double c = __builtin_fma(pc, z, 1.0);
-    // angle addition with the table entry (cj.x, cj.y) = (cos, sin)(m pi/32)
+    *c = __builtin_fma(pc, z, 1.0);
+#endif
+}
+
+// Largest phase increment d * dx the table sincos reduces exactly: the 24-bit head of
+// 2 pi / (16 N) times md16 = 16 rint(x N / 2 pi) must be an exact product (md16 < 2^29).
+#define MTG_TRIG_FAST_MAX 1.0e5
+
+// ---------------------------------------------------------------------------
+// Every VALU instruction costs the wave the same 4-cycle issue slot, FP64 or not,
+// so the reductions also strip integer glue: rounding is done by adding
+// 1.5 * 2^(52+s), which rounds to a multiple of 2^s, so the integer comes out
+// pre-multiplied by the table's entry size (s = 3 for 8-byte entries, 4 for
+// 16-byte ones): one cvt + one and give the LDS byte offset, no shift.
+// ---------------------------------------------------------------------------
+
+// Phase accumulation for a complex term: the running phase d (t_n - t_0) is kept as
+// (m16, r): phase = (m16 / 16) 2 pi / N + r, |r| <= pi / N, m16 = 16 * (m mod N) being the
+// byte offset of the table entry.  One step adds d * dx, re-reduces and returns
+// (cos, sin) of the NEW phase directly -- no separate rotation of the previous pair.
+// Requires d * dx <= MTG_TRIG_FAST_MAX.
+__device__ __forceinline__ void mtg_phase_step(double d, double dx, double &r, int &m16, double *sn,
+                                               double *cs, const MtgMathTables *tab)
+{
+    const double magic = 0x1.8p+56;                                                 // 1.5 * 2^(52+4)
+    const double x = __builtin_fma(d, dx, r);
+    const double w = __builtin_fma(x, 0x1.45f306dc9c883p+1 * MTG_TRIG_N, magic);    // x 16 N / 2 pi
+    const double md16 = w - magic;                                                  // 16 rint(x N / 2 pi)
+    double rr = __builtin_fma(md16, -(0x1.921fb40000000p-2 / MTG_TRIG_N), x);       // 2 pi / 16 N
+    rr = __builtin_fma(md16, -(0x1.4442d18469899p-26 / MTG_TRIG_N), rr);
+    m16 = (m16 + (int)md16) & ((MTG_TRIG_N - 1) * 16);
+    r = rr;
+    const double2 cj = *(const double2 *)((const char *)tab->cis + m16);
+    double s, c;
+    mtg_sincos_small(rr, &s, &c);
     *sn = __builtin_fma(cj.x, s, cj.y * c);
     *cs = __builtin_fma(-cj.y, s, cj.x * c);
 }
 
-// sin/cos(x) for x >= 0 of any size: table path when EVERY lane of the wave is in
-// range (the branch is wave-uniform), OCML otherwise.
-__device__ __forceinline__ void mtg_sincos(double x, double *sn, double *cs, const MtgMathTables *tab)
+// exp(-c dx): negc = -c and cs8 = -c * 8 N / ln2 are per-lane constants hoisted out of
+// the sweep.  One-constant reduction r = y - q ln2 / N: its error is |y| 2^-53 relative,
+// i.e. at most 4e-17 ABSOLUTE in the result (x e^-x <= 0.37), which is what matters for
+// a propagator that multiplies bounded state.  Far below the underflow point q
+// saturates (cvt) and ldexp returns 0.
+#define MTG_EXP_CSCALE (0x1.71547652b82fep+3 * MTG_EXP_N)                           /* 8 N / ln2 */
+__device__ __forceinline__ double mtg_exp_cdx(double negc, double cs8, double dx,
+                                              const MtgMathTables *tab)
 {
-    if (__builtin_expect(__any(!(x <= MTG_TRIG_FAST_MAX)), 0)) {
-        sincos(x, sn, cs);
-    } else {
-        mtg_sincos_fast(x, sn, cs, tab);
-    }
+    const double magic = 0x1.8p+55;                                                 // 1.5 * 2^(52+3)
+    const double w = __builtin_fma(dx, cs8, magic);
+    const double q8 = w - magic;                                                    // 8 rint(y N / ln2)
+    const double r = __builtin_fma(q8, -(0x1.62e42fefa39efp-4 / MTG_EXP_N), negc * dx);
+    const int i8 = (int)q8;                                                         // saturates: huge c dx -> 0
+    const double t = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+    const double p = mtg_expm1_small(r);
+    return __builtin_ldexp(__builtin_fma(t, p, t), i8 >> (3 + MTG_EXP_BITS));
 }
 
 // 1 / d for a normal positive d (pivots live in (1e-24, 1e22)): hardware seed

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtg_hip.so")
+# MTG_HIP_LIB selects an alternative build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("MTG_HIP_LIB") or os.path.join(_HERE, "libmtg_hip.so")
 
 # term kinds / mean kinds / status codes: numerically identical to include/mtg.h
 TERM_REAL, TERM_COMPLEX3, TERM_COMPLEX4, TERM_SHO, TERM_MATERN32, TERM_JITTER, \

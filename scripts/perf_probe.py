@@ -1,7 +1,7 @@
 """Quick kernel-throughput probe (development aid; bench.py is the contract)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mind_the_gaps_amd import synthetic as synth
 from mind_the_gaps_amd.engine import Engine
 
