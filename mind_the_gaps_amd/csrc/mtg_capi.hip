@@ -48,7 +48,8 @@ struct mtg_ctx {
     // light curves (resident)
     int64_t N = 0, L = 0;
     int t_per_lc = 0;
-    DevBuf t, dx, y, var, dy_tmp, dxmax;
+    DevBuf dxt, yv, dxmax;  // interleaved (dx, t) and (y, sigma^2) pairs
+    DevBuf t_tmp, y_tmp, dy_tmp;  // upload staging
 
     // model
     bool has_model = false;
@@ -168,13 +169,13 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     sa.lc_index = d_lc;
     sa.status = d_status;
     sa.out = d_out;
-    sa.t = ctx->t.as<double>();
-    sa.dx = ctx->dx.as<double>();
-    sa.y = ctx->y.as<double>();
-    sa.var = ctx->var.as<double>();
+    sa.dxt = ctx->dxt.as<double2>();
+    sa.yv = ctx->yv.as<double2>();
     sa.N = ctx->N;
     sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
     sa.dxmax = ctx->dxmax.as<double>();
+    sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
+    sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
     sa.mean_kind = m.mean_kind;
     for (int k = 0; k < nsig; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
@@ -250,7 +251,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->t, &ctx->dx, &ctx->y, &ctx->var, &ctx->dy_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
+    DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -271,26 +272,26 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     if (!ctx) return MTG_E_ARG;
     if (N <= 0 || L <= 0 || !t || !y || !yerr)
         return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, yerr");
-    // the solve kernel addresses samples with 32-bit byte offsets
-    if (L * N >= ((int64_t)1 << 29))
-        return fail(ctx, MTG_E_ARG, "light-curve set too large: L * N must be below 2^29 samples");
+    // the solve kernel addresses samples with 32-bit byte offsets (16 bytes per sample)
+    if (L * N >= ((int64_t)1 << 28))
+        return fail(ctx, MTG_E_ARG, "light-curve set too large: L * N must be below 2^28 samples");
     int rc = use_device(ctx);
     if (rc) return rc;
     const int64_t t_rows = t_per_lc ? L : 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // + 64 B: the solve kernel prefetches one element past the last sample
-    HIP_TRY(ctx, ctx->t.reserve((size_t)t_rows * N * 8 + 64));
-    HIP_TRY(ctx, ctx->dx.reserve((size_t)t_rows * N * 8 + 64));
-    HIP_TRY(ctx, ctx->y.reserve((size_t)L * N * 8 + 64));
-    HIP_TRY(ctx, ctx->var.reserve((size_t)L * N * 8 + 64));
+    HIP_TRY(ctx, ctx->dxt.reserve((size_t)t_rows * N * 16));
+    HIP_TRY(ctx, ctx->yv.reserve((size_t)L * N * 16));
+    HIP_TRY(ctx, ctx->t_tmp.reserve((size_t)t_rows * N * 8));
+    HIP_TRY(ctx, ctx->y_tmp.reserve((size_t)L * N * 8));
     HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)L * N * 8));
     HIP_TRY(ctx, ctx->dxmax.reserve(64));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dxmax.p, 0, 8, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->t.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->y.p, y, (size_t)L * N * 8, kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->t_tmp.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->y_tmp.p, y, (size_t)L * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr, (size_t)L * N * 8, kind, ctx->stream));
-    mtg_launch_lc_setup(N, L, t_rows, ctx->t.as<double>(), ctx->dy_tmp.as<double>(),
-                        ctx->dx.as<double>(), ctx->var.as<double>(), ctx->dxmax.as<double>(), ctx->stream);
+    mtg_launch_lc_setup(N, L, t_rows, ctx->t_tmp.as<double>(), ctx->y_tmp.as<double>(),
+                        ctx->dy_tmp.as<double>(), ctx->dxt.as<double2>(), ctx->yv.as<double2>(),
+                        ctx->dxmax.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->L = L; ctx->t_per_lc = t_per_lc ? 1 : 0;
@@ -516,13 +517,13 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.lc_index = d_lc;
     sa.status = ctx->status.as<int32_t>();
     sa.out = ctx->out.as<double>();
-    sa.t = ctx->t.as<double>();
-    sa.dx = ctx->dx.as<double>();
-    sa.y = ctx->y.as<double>();
-    sa.var = ctx->var.as<double>();
+    sa.dxt = ctx->dxt.as<double2>();
+    sa.yv = ctx->yv.as<double2>();
     sa.N = ctx->N;
     sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
     sa.dxmax = ctx->dxmax.as<double>();
+    sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
+    sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
     sa.mean_kind = mean_kind;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));

@@ -67,12 +67,12 @@ struct MtgSolveArgs {
     const int32_t *lc_index;  // NULL = light curve 0
     int32_t *status;
     double *out;
-    const double *t;    // [N] or [L][N]
-    const double *dx;   // same shape, dx[0] = 0
-    const double *y;    // [L][N]
-    const double *var;  // [L][N]  yerr^2
+    const double2 *dxt;  // [N] or [L][N] pairs (dx_n, t_n), dx_0 = 0
+    const double2 *yv;   // [L][N] pairs (y_n, sigma_n^2 = yerr_n^2)
     int64_t N;
-    int64_t t_stride;  // 0 (shared sampling) or N
+    int64_t t_stride;    // 0 (shared sampling) or N
+    uint32_t yv_bytes;   // L * N * 16 < 4 GiB
+    uint32_t dxt_bytes;
     const double *dxmax;  // [1] max_n dx_n (device): decides table vs OCML sincos per wave
     int mean_kind;
 };
@@ -81,7 +81,7 @@ typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStre
 // Table lookup of the compiled <NR, NC> instantiations (mtg_kernels.hip).
 mtg_solve_launcher mtg_find_solver(int nr, int nc);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
-void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *yerr,
-                         double *dx, double *var, double *dxmax, hipStream_t);
+void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
+                         const double *yerr, double2 *dxt, double2 *yv, double *dxmax, hipStream_t);
 void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,
                            hipStream_t);

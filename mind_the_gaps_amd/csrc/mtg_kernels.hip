@@ -2,7 +2,8 @@
 // log-likelihood hot path.
 //
 //   mtg_lc_setup   : celerite.GP.compute(t, yerr) (called with yerr = dy + 1e-12
-//                    at reference gpmodelling.py:54): sigma^2 = yerr^2, dx_n.
+//                    at reference gpmodelling.py:54): interleaved (y, sigma^2 = yerr^2)
+//                    and (dx_n, t_n) pairs, one 16-byte load each per sample.
 //   mtg_prepare    : set_parameter_vector + log_prior + Term.coefficients
 //                    (gpmodelling.py:147-151, celerite_models.py:7-90,
 //                    celerite built-in terms): theta -> prior verdict and the
@@ -28,34 +29,36 @@
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restrict__ t,
-                    const double *__restrict__ yerr, double *__restrict__ dx,
-                    double *__restrict__ var, unsigned long long *__restrict__ dxmax_bits)
+                    const double *__restrict__ y, const double *__restrict__ yerr,
+                    double2 *__restrict__ dxt, double2 *__restrict__ yv,
+                    unsigned long long *__restrict__ dxmax_bits)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = i0; i < L * N; i += stride) {
         const double s = yerr[i];  // celerite squares the yerr handed to compute()
-        var[i] = s * s;
+        yv[i] = make_double2(y[i], s * s);
     }
     double mx = 0.0;
     for (int64_t i = i0; i < t_rows * N; i += stride) {
         const int64_t n = i % N;
         const double d = n == 0 ? 0.0 : t[i] - t[i - 1];
-        dx[i] = d;
+        dxt[i] = make_double2(d, t[i]);
         mx = fmax(mx, d);
     }
     // max over the grid: non-negative doubles order like their bit patterns
     atomicMax(dxmax_bits, (unsigned long long)__double_as_longlong(mx));
 }
 
-void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *yerr,
-                         double *dx, double *var, double *dxmax, hipStream_t stream)
+void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
+                         const double *yerr, double2 *dxt, double2 *yv, double *dxmax,
+                         hipStream_t stream)
 {
     int64_t blocks = (L * N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mtg_lc_setup_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, L,
-                       t_rows, t, yerr, dx, var, (unsigned long long *)dxmax);
+                       t_rows, t, y, yerr, dxt, yv, (unsigned long long *)dxmax);
 }
 
 // ---------------------------------------------------------------------------
@@ -249,8 +252,8 @@ struct MtgLane {
     double ncr[NR > 0 ? NR : 1], cr64[NR > 0 ? NR : 1];  // -c and -c 8 N_exp/ln2 of the real terms
     double ncc[NC > 0 ? NC : 1], cc64[NC > 0 ? NC : 1];  // same for the complex terms
     double invD, z, dot, dprod;
+    int dmin_hi;  // smallest high dword of a pivot: <= 0 means some D_n <= 0 (K not positive definite)
     int dexp;
-    bool bad;
 };
 
 // The sweep over the N samples: ONE basic block per step (no branch besides the
@@ -259,22 +262,32 @@ struct MtgLane {
 //   FAST: every lane's d_k * max(dx) is inside the exact range of the table sincos.
 template <int NR, int NC, bool FAST>
 __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, uint32_t yoff,
-                                          uint32_t toff, const MtgMathTables *tab)
+                                          uint32_t toff, const MtgMathTablesT<(NC > 0)> *tab)
 {
     constexpr int J = NR + 2 * NC;
     constexpr int NT = NR + NC;  // distinct exp(-c dx) factors
-    const char *ybase = (const char *)a.y, *vbase = (const char *)a.var;
-    const char *dbase = (const char *)a.dx, *tbase = (const char *)a.t;
-    auto ld = [](const char *base, uint32_t off) { return *(const double *)(base + off); };
+    // Samples come through buffer loads: resource in SGPRs, the light curve's byte
+    // offset per lane (voffset) and the running sample offset on the scalar unit
+    // (soffset += 16 per step) -- no VALU instruction is spent on addressing, and the
+    // hardware range check makes the one-past-the-end prefetch of the last step a
+    // harmless zero.  (y, sigma^2) and (dx, t) are interleaved: one 16-byte load each.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t ryv =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.yv, 0, (int)a.yv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdt =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.dxt, 0, (int)a.dxt_bytes, 0x00020000);
+    auto ld = [](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
 
-    double dx_n = ld(dbase, toff), t_n = ld(tbase, toff), y_n = ld(ybase, yoff), v_n = ld(vbase, yoff);
+    double2 dt_n = ld(rdt, toff, 0), yv_n = ld(ryv, yoff, 0);
     const uint32_t N = (uint32_t)a.N;
+    uint32_t soff = 0;
     for (uint32_t n = 0; n < N; ++n) {
-        const double dxc = dx_n, yc = y_n, vc = v_n, tc = t_n;
-        // prefetch the next sample under this step's arithmetic (every buffer carries
-        // one element of slack, so the last iteration reads a valid, unused address)
-        yoff += 8; toff += 8;
-        dx_n = ld(dbase, toff); t_n = ld(tbase, toff); y_n = ld(ybase, yoff); v_n = ld(vbase, yoff);
+        const double dxc = dt_n.x, tc = dt_n.y, yc = yv_n.x, vc = yv_n.y;
+        // prefetch the next sample under this step's arithmetic
+        soff += 16;
+        dt_n = ld(rdt, toff, soff); yv_n = ld(ryv, yoff, soff);
 
         // -- per-term propagators and generators (celerite phi, U, V) ---------
         double ph[NT > 0 ? NT : 1];
@@ -336,7 +349,7 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
             D = fma(-U[i], q, D);
             zn = fma(-U[i], L.f[i], zn);
         }
-        L.bad = L.bad | !(D > 0.0);
+        L.dmin_hi = min(L.dmin_hi, __double2hiint(D));  // sign / zero test on the high dword
         L.invD = mtg_rcp(D);
         L.z = zn;
         L.dot = fma(zn * zn, L.invD, L.dot);
@@ -353,8 +366,8 @@ template <int NR, int NC>
 __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_solve_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;  // celerite rank
-    __shared__ MtgMathTables tab;
-    mtg_fill_tables(&tab, threadIdx.x, MTG_BLOCK, NC > 0);
+    __shared__ MtgMathTablesT<(NC > 0)> tab;
+    mtg_fill_tables(&tab, threadIdx.x, MTG_BLOCK);
     __syncthreads();
     const int64_t gid = (int64_t)blockIdx.x * MTG_BLOCK + threadIdx.x;
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
@@ -394,11 +407,11 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j) { L.ncr[j] = -L.cr[j]; L.cr64[j] = L.cr[j] * -MTG_EXP_CSCALE; }
-    L.invD = 0.0; L.z = 0.0; L.dot = 0.0; L.dprod = 1.0; L.dexp = 0; L.bad = false;
+    L.invD = 0.0; L.z = 0.0; L.dot = 0.0; L.dprod = 1.0; L.dexp = 0; L.dmin_hi = 0x7fffffff;
 
     const uint32_t lc = a.lc_index ? (uint32_t)a.lc_index[e] : 0u;
-    const uint32_t yoff = lc * (uint32_t)a.N * 8u;                 // L * N * 8 < 4 GiB (checked on the host)
-    const uint32_t toff = lc * (uint32_t)a.t_stride * 8u;
+    const uint32_t yoff = lc * (uint32_t)a.N * 16u;                // L * N * 16 < 4 GiB (checked on the host)
+    const uint32_t toff = lc * (uint32_t)a.t_stride * 16u;
 
     // table sincos is exact while d_k * dx < MTG_TRIG_FAST_MAX for every lane of the wave
     const bool fast = !__any(!(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
@@ -408,7 +421,7 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     const double logdet = log(L.dprod) + (double)L.dexp * 0.69314718055994530942;
     double ll = -0.5 * (L.dot + logdet + (double)a.N * MTG_LN_2PI);
     int st = MTG_ST_OK;
-    if (L.bad) { st = MTG_ST_NOTPD; ll = -INFINITY; }
+    if (L.dmin_hi <= 0) { st = MTG_ST_NOTPD; ll = -INFINITY; }
     else if (!isfinite(ll)) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
     a.out[e] = ll;
     a.status[e] = st;
@@ -419,7 +432,7 @@ __global__ void __launch_bounds__(256)
 mtg_math_probe_kernel(int64_t n, const double *x, double *e, double *s, double *c, double *rcp)
 {
     __shared__ MtgMathTables tab;
-    mtg_fill_tables(&tab, threadIdx.x, 256, true);
+    mtg_fill_tables(&tab, threadIdx.x, 256);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;

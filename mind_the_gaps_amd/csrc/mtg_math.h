@@ -33,17 +33,22 @@
 #define MTG_EXP_N (1 << MTG_EXP_BITS)
 #define MTG_TRIG_N (1 << MTG_TRIG_BITS)
 
-struct MtgMathTables {
-    double exp2_frac[MTG_EXP_N];  // 2^(j / N)
-    double2 cis[MTG_TRIG_N];      // (cos, sin)(2 pi j / N)
+// TRIG = false (kernels without complex terms) leaves the trig table out of LDS, so
+// that the occupancy of those light kernels is not capped by it.
+template <bool TRIG>
+struct MtgMathTablesT {
+    double exp2_frac[MTG_EXP_N];          // 2^(j / N)
+    double2 cis[TRIG ? MTG_TRIG_N : 1];   // (cos, sin)(2 pi j / N)
 };
+typedef MtgMathTablesT<true> MtgMathTables;
 
 // Cooperative fill by the whole workgroup; follow with __syncthreads().
-__device__ __forceinline__ void mtg_fill_tables(MtgMathTables *tab, int tid, int nthreads, bool trig)
+template <bool TRIG>
+__device__ __forceinline__ void mtg_fill_tables(MtgMathTablesT<TRIG> *tab, int tid, int nthreads)
 {
     for (int j = tid; j < MTG_EXP_N; j += nthreads)
         tab->exp2_frac[j] = exp2((double)j * (1.0 / MTG_EXP_N));
-    if (trig)
+    if (TRIG)
         for (int j = tid; j < MTG_TRIG_N; j += nthreads) {
             double s, c;
             sincospi((double)j * (2.0 / MTG_TRIG_N), &s, &c);
@@ -114,8 +119,9 @@ __device__ __forceinline__ void mtg_sincos_small(double r, double *s, double *c)
 // byte offset of the table entry.  One step adds d * dx, re-reduces and returns
 // (cos, sin) of the NEW phase directly -- no separate rotation of the previous pair.
 // Requires d * dx <= MTG_TRIG_FAST_MAX.
+template <class Tab>
 __device__ __forceinline__ void mtg_phase_step(double d, double dx, double &r, int &m16, double *sn,
-                                               double *cs, const MtgMathTables *tab)
+                                               double *cs, const Tab *tab)
 {
     const double magic = 0x1.8p+56;                                                 // 1.5 * 2^(52+4)
     const double x = __builtin_fma(d, dx, r);
@@ -138,8 +144,8 @@ __device__ __forceinline__ void mtg_phase_step(double d, double dx, double &r, i
 // a propagator that multiplies bounded state.  Far below the underflow point q
 // saturates (cvt) and ldexp returns 0.
 #define MTG_EXP_CSCALE (0x1.71547652b82fep+3 * MTG_EXP_N)                           /* 8 N / ln2 */
-__device__ __forceinline__ double mtg_exp_cdx(double negc, double cs8, double dx,
-                                              const MtgMathTables *tab)
+template <class Tab>
+__device__ __forceinline__ double mtg_exp_cdx(double negc, double cs8, double dx, const Tab *tab)
 {
     const double magic = 0x1.8p+55;                                                 // 1.5 * 2^(52+3)
     const double w = __builtin_fma(dx, cs8, magic);
