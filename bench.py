@@ -63,7 +63,7 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(t, y, dy, kinds, theta, mean_value, seconds):
+def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds):
     """oracle/celerite_ref.c on all usable host cores, same inputs, bounded sample."""
     from oracle import celerite as oracle_c
     cores = usable_cores()
@@ -73,8 +73,8 @@ def cpu_baseline(t, y, dy, kinds, theta, mean_value, seconds):
     done, t0 = 0, time.perf_counter()
     while True:
         idx = (np.arange(chunk) + done) % theta.shape[0]
-        full = np.hstack([theta[idx], np.full((chunk, 1), mean_value)])
         lc = (idx // (theta.shape[0] // L)).astype(np.int32) % L
+        full = np.hstack([theta[idx], y_mean[lc][:, None]])
         oracle_c.logprob_batch(t, y, dy, kinds, full, lc_index=lc, nthreads=cores)
         done += chunk
         el = time.perf_counter() - t0
@@ -113,11 +113,13 @@ def main():
     # seed = 20250704 + config index; every rank owns different light curves
     t, y, dy = synth.make_lightcurves(N, L, seed=20250704 + 4 + 1000 * rank)
     theta = synth.draw_thetas(kinds, B, seed=20250704 + 40 + 1000 * rank)
-    full, free, bounds = synth.model_spec(kinds, y)
+    # every light curve keeps its own frozen mean, as GPModelling does (gpmodelling.py:83-87)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    y_mean = y.mean(axis=1)
     lc = np.repeat(np.arange(L, dtype=np.int32), W)
 
     eng = Engine(local_rank)
-    eng.set_lightcurves(t, y, dy + 1e-12)          # uploaded once; resident for the whole run
+    eng.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)   # uploaded once; resident for the whole run
     eng.set_model(kinds, full, free, bounds)
     d_theta = torch.from_numpy(theta).to(dev)
     d_lc = torch.from_numpy(lc).to(dev)
@@ -206,7 +208,7 @@ def main():
             },
         }
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, full[-1], args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

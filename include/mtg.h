@@ -90,13 +90,19 @@ MTG_API const char *mtg_last_error(const mtg_ctx *ctx);
  * otherwise -> MTG_E_ARG), forms sigma^2 = yerr^2 (celerite squares yerr) and
  * dx_n = t_n - t_{n-1} on the device and keeps everything resident until the
  * next call / mtg_destroy.
+ * y_offset: [L] or NULL.  The reference freezes the mean of every light curve at
+ * ITS OWN average, ConstantModel(lightcurve.mean) with fit_mean=False
+ * (gpmodelling.py:83-87): pass those L values here (they are subtracted from y
+ * once, at upload) and give the model a frozen mean of 0.  L * N must stay
+ * below 2^28 samples (32-bit byte offsets in the kernel).
  */
 MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
-                                const double *y, const double *yerr);
+                                const double *y, const double *yerr, const double *y_offset);
 /* Same with DEVICE pointers (light curves born on the GPU); no sortedness
  * check, the data are copied device-to-device on the context's stream. */
 MTG_API int mtg_set_lightcurves_device(mtg_ctx *ctx, int64_t N, int64_t L, const double *d_t,
-                                       int t_per_lc, const double *d_y, const double *d_yerr);
+                                       int t_per_lc, const double *d_y, const double *d_yerr,
+                                       const double *d_y_offset);
 
 /*
  * The model: what `celerite.GP(kernel, mean=..., fit_mean=...)`

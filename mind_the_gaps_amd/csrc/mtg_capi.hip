@@ -49,7 +49,7 @@ struct mtg_ctx {
     int64_t N = 0, L = 0;
     int t_per_lc = 0;
     DevBuf dxt, yv, dxmax;  // interleaved (dx, t) and (y, sigma^2) pairs
-    DevBuf t_tmp, y_tmp, dy_tmp;  // upload staging
+    DevBuf t_tmp, y_tmp, dy_tmp, off_tmp;  // upload staging
 
     // model
     bool has_model = false;
@@ -177,6 +177,9 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
     sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
     sa.mean_kind = m.mean_kind;
+    // the mean vanishes identically when it is a frozen constant equal to 0 (the
+    // per-light-curve frozen mean lives in y_offset)
+    sa.has_mean = !(m.mean_kind == MTG_MEAN_CONSTANT && m.src[m.nk] < 0 && m.defaults[m.nk] == 0.0);
     for (int k = 0; k < nsig; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
         mtg_solve_launcher fn = mtg_find_solver(nr, nc);
@@ -251,7 +254,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
+    DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -267,7 +270,8 @@ MTG_API const char *mtg_last_error(const mtg_ctx *ctx)
 }
 
 static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
-                                  const double *y, const double *yerr, hipMemcpyKind kind)
+                                  const double *y, const double *yerr, const double *y_offset,
+                                  hipMemcpyKind kind)
 {
     if (!ctx) return MTG_E_ARG;
     if (N <= 0 || L <= 0 || !t || !y || !yerr)
@@ -289,8 +293,14 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t_tmp.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->y_tmp.p, y, (size_t)L * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr, (size_t)L * N * 8, kind, ctx->stream));
+    const double *d_off = nullptr;
+    if (y_offset) {
+        HIP_TRY(ctx, ctx->off_tmp.reserve((size_t)L * 8));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->off_tmp.p, y_offset, (size_t)L * 8, kind, ctx->stream));
+        d_off = ctx->off_tmp.as<double>();
+    }
     mtg_launch_lc_setup(N, L, t_rows, ctx->t_tmp.as<double>(), ctx->y_tmp.as<double>(),
-                        ctx->dy_tmp.as<double>(), ctx->dxt.as<double2>(), ctx->yv.as<double2>(),
+                        ctx->dy_tmp.as<double>(), d_off, ctx->dxt.as<double2>(), ctx->yv.as<double2>(),
                         ctx->dxmax.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -299,7 +309,7 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
 }
 
 MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
-                                const double *y, const double *yerr)
+                                const double *y, const double *yerr, const double *y_offset)
 {
     if (!ctx) return MTG_E_ARG;
     if (N <= 0 || L <= 0 || !t || !y || !yerr)
@@ -310,13 +320,14 @@ MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double
         for (int64_t n = 1; n < N; ++n)
             if (!(t[r * N + n] >= t[r * N + n - 1]))
                 return fail(ctx, MTG_E_ARG, "the input coordinates must be sorted");
-    return set_lightcurves_common(ctx, N, L, t, t_per_lc, y, yerr, hipMemcpyHostToDevice);
+    return set_lightcurves_common(ctx, N, L, t, t_per_lc, y, yerr, y_offset, hipMemcpyHostToDevice);
 }
 
 MTG_API int mtg_set_lightcurves_device(mtg_ctx *ctx, int64_t N, int64_t L, const double *d_t,
-                                       int t_per_lc, const double *d_y, const double *d_yerr)
+                                       int t_per_lc, const double *d_y, const double *d_yerr,
+                                       const double *d_y_offset)
 {
-    return set_lightcurves_common(ctx, N, L, d_t, t_per_lc, d_y, d_yerr, hipMemcpyDeviceToDevice);
+    return set_lightcurves_common(ctx, N, L, d_t, t_per_lc, d_y, d_yerr, d_y_offset, hipMemcpyDeviceToDevice);
 }
 
 MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const double *term_extra,
@@ -525,6 +536,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
     sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
     sa.mean_kind = mean_kind;
+    sa.has_mean = mean_params != nullptr;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
     fn(sa, B, s);

@@ -75,6 +75,7 @@ struct MtgSolveArgs {
     uint32_t dxt_bytes;
     const double *dxmax;  // [1] max_n dx_n (device): decides table vs OCML sincos per wave
     int mean_kind;
+    int has_mean;  // 0: the mean is identically zero for every evaluation of this launch
 };
 
 typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStream_t);
@@ -82,6 +83,7 @@ typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStre
 mtg_solve_launcher mtg_find_solver(int nr, int nc);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
-                         const double *yerr, double2 *dxt, double2 *yv, double *dxmax, hipStream_t);
+                         const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,
+                         double *dxmax, hipStream_t);
 void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,
                            hipStream_t);

@@ -30,14 +30,17 @@
 __global__ void __launch_bounds__(256)
 mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restrict__ t,
                     const double *__restrict__ y, const double *__restrict__ yerr,
-                    double2 *__restrict__ dxt, double2 *__restrict__ yv,
-                    unsigned long long *__restrict__ dxmax_bits)
+                    const double *__restrict__ y_offset, double2 *__restrict__ dxt,
+                    double2 *__restrict__ yv, unsigned long long *__restrict__ dxmax_bits)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = i0; i < L * N; i += stride) {
         const double s = yerr[i];  // celerite squares the yerr handed to compute()
-        yv[i] = make_double2(y[i], s * s);
+        // y_offset: the frozen ConstantModel(lightcurve.mean) of gpmodelling.py:83-87,
+        // one value per light curve, subtracted once instead of once per evaluation
+        const double mu = y_offset ? y_offset[i / N] : 0.0;
+        yv[i] = make_double2(y[i] - mu, s * s);
     }
     double mx = 0.0;
     for (int64_t i = i0; i < t_rows * N; i += stride) {
@@ -51,14 +54,14 @@ mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restri
 }
 
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
-                         const double *yerr, double2 *dxt, double2 *yv, double *dxmax,
-                         hipStream_t stream)
+                         const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,
+                         double *dxmax, hipStream_t stream)
 {
     int64_t blocks = (L * N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mtg_lc_setup_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, L,
-                       t_rows, t, y, yerr, dxt, yv, (unsigned long long *)dxmax);
+                       t_rows, t, y, yerr, y_offset, dxt, yv, (unsigned long long *)dxmax);
 }
 
 // ---------------------------------------------------------------------------
@@ -260,7 +263,9 @@ struct MtgLane {
 // back edge), so the scheduler can hoist the five table look-ups and the next
 // sample's loads above the polynomial/recurrence arithmetic.
 //   FAST: every lane's d_k * max(dx) is inside the exact range of the table sincos.
-template <int NR, int NC, bool FAST>
+//   MEAN: a mean function has to be subtracted (false: it is identically zero, the
+//         frozen per-light-curve constant having been folded into y at upload).
+template <int NR, int NC, bool FAST, bool MEAN>
 __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, uint32_t yoff,
                                           uint32_t toff, const MtgMathTablesT<(NC > 0)> *tab)
 {
@@ -336,7 +341,7 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         }
         // -- D_n = A_n - U^T S U ; Wt = V - S U ; z_n = r_n - U^T f -------------
         double D = vc + L.asum;
-        double zn = yc - fma(L.slope, tc, L.icpt);
+        double zn = MEAN ? yc - fma(L.slope, tc, L.icpt) : yc;
 #pragma unroll
         for (int i = 0; i < J; ++i) {
             double q = 0.0;
@@ -415,8 +420,12 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
 
     // table sincos is exact while d_k * dx < MTG_TRIG_FAST_MAX for every lane of the wave
     const bool fast = !__any(!(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
-    if (fast) mtg_sweep<NR, NC, true>(L, a, yoff, toff, &tab);
-    else mtg_sweep<NR, NC, false>(L, a, yoff, toff, &tab);
+    if (fast) {
+        if (a.has_mean) mtg_sweep<NR, NC, true, true>(L, a, yoff, toff, &tab);
+        else mtg_sweep<NR, NC, true, false>(L, a, yoff, toff, &tab);
+    } else {
+        mtg_sweep<NR, NC, false, true>(L, a, yoff, toff, &tab);
+    }
 
     const double logdet = log(L.dprod) + (double)L.dexp * 0.69314718055994530942;
     double ll = -0.5 * (L.dot + logdet + (double)a.N * MTG_LN_2PI);

@@ -70,9 +70,9 @@ def load_library():
     lib.mtg_last_error.restype = ctypes.c_char_p
     lib.mtg_last_error.argtypes = [c_vp]
     lib.mtg_set_lightcurves.restype = c_int
-    lib.mtg_set_lightcurves.argtypes = [c_vp, c_i64, c_i64, _dp, c_int, _dp, _dp]
+    lib.mtg_set_lightcurves.argtypes = [c_vp, c_i64, c_i64, _dp, c_int, _dp, _dp, _dp]
     lib.mtg_set_lightcurves_device.restype = c_int
-    lib.mtg_set_lightcurves_device.argtypes = [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_vp]
+    lib.mtg_set_lightcurves_device.argtypes = [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_vp, c_vp]
     lib.mtg_set_model.restype = c_int
     lib.mtg_set_model.argtypes = [c_vp, c_int, _ip, _dp, c_int, c_int, _dp, c_int, _ip, _dp]
     lib.mtg_loglike_batch.restype = c_int
@@ -145,9 +145,10 @@ class Engine:
             raise EngineError(rc, self._lib.mtg_last_error(self._ctx).decode())
 
     # -- data ---------------------------------------------------------------
-    def set_lightcurves(self, t, y, yerr):
+    def set_lightcurves(self, t, y, yerr, y_offset=None):
         """t: [N] (shared sampling) or [L][N]; y, yerr: [N] or [L][N].  ``yerr`` is what
-        celerite's ``compute`` receives, i.e. ``dy + 1e-12`` in the reference (gpmodelling.py:54)."""
+        celerite's ``compute`` receives, i.e. ``dy + 1e-12`` in the reference (gpmodelling.py:54).
+        ``y_offset``: [L] frozen per-light-curve means (gpmodelling.py:83-87), subtracted at upload."""
         y = np.atleast_2d(_f64(y))
         dy = np.atleast_2d(_f64(yerr))
         t = _f64(t)
@@ -164,16 +165,19 @@ class Engine:
                 raise ValueError("t must be [N] or [L][N]")
         if t.ndim == 1 and t.shape[0] != N:
             raise ValueError("t and y lengths differ")
+        off = None
+        if y_offset is not None:
+            off = _f64(np.broadcast_to(np.asarray(y_offset, dtype=np.float64), (L,)))
         rc = self._lib.mtg_set_lightcurves(self._ctx, N, L, _ptr(np.ascontiguousarray(t)), t_per_lc,
-                                           _ptr(y), _ptr(dy))
+                                           _ptr(y), _ptr(dy), _ptr(off))
         if rc == E_ARG and b"sorted" in self._lib.mtg_last_error(self._ctx):
             raise ValueError("the input coordinates must be sorted")  # celerite GP.compute wording
         self._check(rc)
         self.N, self.L = N, L
 
-    def set_lightcurves_device(self, N, L, t_ptr, y_ptr, dy_ptr, t_per_lc=False):
+    def set_lightcurves_device(self, N, L, t_ptr, y_ptr, dy_ptr, t_per_lc=False, y_offset_ptr=None):
         self._check(self._lib.mtg_set_lightcurves_device(self._ctx, N, L, t_ptr, int(bool(t_per_lc)),
-                                                         y_ptr, dy_ptr))
+                                                         y_ptr, dy_ptr, y_offset_ptr))
         self.N, self.L = int(N), int(L)
 
     def set_model(self, kinds, full_values, free_index, bounds, mean_kind=MEAN_CONSTANT, extra=None):

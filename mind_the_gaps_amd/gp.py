@@ -85,11 +85,20 @@ class DeviceModel:
         self.mask = np.concatenate([kmask, mmask])
         self.free_index = np.flatnonzero(self.mask).astype(np.int32)
         self.bounds = _inf_bounds(list(kbounds) + list(mbounds))
+        # A frozen constant mean -- the reference default, ConstantModel(lightcurve.mean)
+        # with fit_mean=False (gpmodelling.py:83-87) -- is subtracted from y once at upload
+        # (mtg_set_lightcurves y_offset); the device model then carries a mean of exactly 0
+        # and its bounds move with it, so the box prior still vetoes an out-of-range value.
+        self.y_offset = None
+        if self.mean_kind == _engine.MEAN_CONSTANT and not self.mask[self.nk]:
+            self.y_offset = float(self.full[self.nk])
+            self.bounds[self.nk] -= self.y_offset
+            self.full[self.nk] = 0.0
 
     def signature(self):
         frozen = self.full[~self.mask]
         return (tuple(-1 if k is None else k for k in self.kinds), tuple(self.extra), self.mean_kind,
-                self.mask.tobytes(), frozen.tobytes(), self.bounds.tobytes())
+                self.mask.tobytes(), frozen.tobytes(), self.bounds.tobytes(), self.y_offset)
 
 
 class LogProbEvaluator:
@@ -101,14 +110,18 @@ class LogProbEvaluator:
     (gpmodelling.py:54); the device squares it.
     """
 
-    def __init__(self, t, y, yerr, device=0):
+    def __init__(self, t, y, yerr, device=0, y_offset=None):
+        """``y_offset``: [L] frozen per-light-curve means; when None a model with a frozen
+        constant mean supplies its value for every light curve."""
         self.t = np.ascontiguousarray(t, dtype=np.float64)
         self.y = np.atleast_2d(np.ascontiguousarray(y, dtype=np.float64))
         self.yerr = np.atleast_2d(np.ascontiguousarray(yerr, dtype=np.float64))
         if self.yerr.shape != self.y.shape:
             raise ValueError("dimension mismatch")
         self.device = device
+        self.y_offset = None if y_offset is None else np.ascontiguousarray(y_offset, dtype=np.float64)
         self._model_sig = None
+        self._bound_offset = None
         self._token = object()
 
     @property
@@ -117,9 +130,12 @@ class LogProbEvaluator:
 
     def _bind(self, model):
         eng = get_engine(self.device)
-        if eng.bound_to is not self._token:
-            eng.set_lightcurves(self.t, self.y, self.yerr)
+        offset = self.y_offset if self.y_offset is not None else getattr(model, "y_offset", None)
+        key = None if offset is None else np.asarray(offset, dtype=np.float64).tobytes()
+        if eng.bound_to is not self._token or key != self._bound_offset:
+            eng.set_lightcurves(self.t, self.y, self.yerr, y_offset=offset)
             eng.bound_to = self._token
+            self._bound_offset = key
             self._model_sig = None
         if model.device_terms:
             sig = model.signature()
@@ -138,18 +154,13 @@ class LogProbEvaluator:
         eng = self._bind(model)
         return eng.loglike(theta, lc_index, add_prior=add_prior)
 
-    def evaluate_coefficients(self, coeffs, jitter, mean_kind, mean_params, lc_index=None):
-        eng = self._bind(_NoModel)
+    def evaluate_coefficients(self, model, coeffs, jitter, mean_params, lc_index=None):
+        """Host-evaluated celerite coefficients [B][j]; mean_params [B][1 or 2] are the
+        device-side mean parameters (0 for a frozen constant mean, see DeviceModel)."""
+        eng = self._bind(model)
         ar, cr, ac, bc, cc, dc = coeffs
-        return eng.loglike_coeffs(ar, cr, ac, bc, cc, dc, jitter=jitter, mean_kind=mean_kind,
+        return eng.loglike_coeffs(ar, cr, ac, bc, cc, dc, jitter=jitter, mean_kind=model.mean_kind,
                                   mean_params=mean_params, lc_index=lc_index)
-
-
-class _NoModelType:
-    device_terms = False
-
-
-_NoModel = _NoModelType()
 
 
 class GP(ModelSet):
@@ -222,8 +233,7 @@ class GP(ModelSet):
         else:
             coeffs = tuple(c[None, :] for c in self.kernel.coefficients)
             out, status = ev.evaluate_coefficients(
-                coeffs, np.array([self.kernel.jitter]), model.mean_kind,
-                self.mean.get_parameter_vector(include_frozen=True)[None, :])
+                model, coeffs, np.array([self.kernel.jitter]), model.full[model.nk:][None, :])
         if status[0] == _engine.ST_NOTPD:
             if quiet:
                 return -np.inf
@@ -252,7 +262,10 @@ class GP(ModelSet):
                     continue
                 rows.append(self.kernel.coefficients)
                 jit.append(self.kernel.jitter)
-                means.append(self.mean.get_parameter_vector(include_frozen=True))
+                mvec = self.mean.get_parameter_vector(include_frozen=True).copy()
+                if model.y_offset is not None:
+                    mvec[0] = 0.0      # folded into y at upload
+                means.append(mvec)
         finally:
             self.set_parameter_vector(saved)
         out = np.full(B, -np.inf)
@@ -262,7 +275,7 @@ class GP(ModelSet):
             if len(shapes) != 1:
                 raise ValueError("host-evaluated terms must keep one structure across the batch")
             coeffs = tuple(np.array([r[i] for r in rows]).reshape(len(rows), -1) for i in range(6))
-            o, s = ev.evaluate_coefficients(coeffs, np.array(jit), model.mean_kind, np.array(means))
+            o, s = ev.evaluate_coefficients(model, coeffs, np.array(jit), np.array(means))
             out[keep], status[keep] = o, s
         return out, status
 

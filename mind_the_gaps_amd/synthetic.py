@@ -64,11 +64,15 @@ def draw_thetas(kinds, B, seed, percent=0.1):
     return th + percent * np.abs(th) * rng.standard_normal((B, len(th)))
 
 
-def model_spec(kinds, y, mean_kind=0, fit_mean=False, mean_values=None):
+def model_spec(kinds, y, mean_kind=0, fit_mean=False, mean_values=None, per_lc_mean=False):
     """(full_values, free_index, bounds) for engine.set_model, mean frozen at mean(y)
-    unless fit_mean (the reference default, gpmodelling.py:83-87)."""
+    unless fit_mean (the reference default, gpmodelling.py:83-87).  With ``per_lc_mean``
+    the frozen mean is 0 here and every light curve's own average goes to
+    ``engine.set_lightcurves(..., y_offset=y.mean(axis=1))`` -- what GPModelling does."""
     th = truth(kinds)
     nk = len(th)
+    if per_lc_mean:
+        mean_values = [0.0]
     if mean_values is None:
         mean_values = [float(np.mean(y))] if mean_kind == 0 else [0.0, float(np.mean(y))]
     full = np.concatenate([th, mean_values])

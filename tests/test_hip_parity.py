@@ -67,3 +67,48 @@ def test_hip_vs_dense_n10000(engine):
     ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, full_b, lc_index=lc, nthreads=8)
     assert np.all(st == 0) and np.all(rst == 0)
     assert rel(out, ref).max() <= RTOL
+
+
+def test_per_lightcurve_frozen_means(engine):
+    """The reference freezes each light curve's mean at its own average
+    (gpmodelling.py:83-87): y_offset carries those values, the model mean is 0."""
+    kinds = MODELS["drw+sho+lor"]
+    N, L, B = 700, 5, 160
+    t, y, dy = synth.make_lightcurves(N, L, seed=77)
+    y += np.arange(L)[:, None] * 13.0                      # clearly different means
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    y_mean = y.mean(axis=1)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds)
+    theta = synth.draw_thetas(kinds, B, seed=5)
+    lc = (np.arange(B) % L).astype(np.int32)
+    out, st = engine.loglike(theta, lc, add_prior=True)
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, y_mean[lc][:, None]]),
+                                      bounds=bounds, lc_index=lc, add_prior=True, nthreads=4)
+    assert np.array_equal(st, rst)
+    ok = st == 0
+    assert rel(out[ok], ref[ok]).max() <= RTOL
+
+
+def test_per_lightcurve_times(engine):
+    """t may differ per light curve ([L][N]); the kernel then reads (dx, t) per lane."""
+    kinds = MODELS["drw+sho"]
+    N, L, B = 300, 4, 64
+    rng = np.random.default_rng(3)
+    t = np.vstack([synth.make_times(N, rng, offset=100.0 * i) for i in range(L)])
+    dy = rng.uniform(0.5, 2.0, (L, N))
+    y = 100.0 + 10.0 * rng.standard_normal((L, N)) + 0.02 * (t - t[:, :1])
+    kinds_full = synth.truth(kinds)
+    full = np.concatenate([kinds_full, [0.02, 100.0]])           # fitted linear mean
+    bounds = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)] * 2])
+    free = np.arange(len(full), dtype=np.int32)
+    engine.set_lightcurves(t, y, dy + 1e-12)
+    engine.set_model(kinds, full, free, bounds, mean_kind=1)
+    theta = np.hstack([synth.draw_thetas(kinds, B, seed=9), np.tile([0.02, 100.0], (B, 1))])
+    lc = (np.arange(B) % L).astype(np.int32)
+    out, st = engine.loglike(theta, lc, add_prior=False)
+    ref = np.empty(B)
+    for l in range(L):
+        sel = lc == l
+        ref[sel] = oracle_c.logprob_batch(t[l], y[l], dy[l], kinds, theta[sel], mean_kind=1)[0]
+    assert np.all(st == 0) and rel(out, ref).max() <= RTOL
