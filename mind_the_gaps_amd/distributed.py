@@ -1,0 +1,124 @@
+"""Sharding the (theta x light-curve) batch across the GPUs of one node.
+
+The reference's only cross-worker traffic is ``multiprocessing.Pool.map`` returning one
+float per task (/root/reference/mind_the_gaps/gpmodelling.py:245-248) and the
+user-level loop over simulated light curves
+(docs/notebooks/tutorial_ppp.ipynb:326-343).  Both axes are embarrassingly
+parallel, so the MI355X layout is: one process per GPU (``torch.distributed``,
+backend ``nccl`` = RCCL over xGMI; ``gloo`` in the CPU tests), every rank owns a
+contiguous block of the work, no collective on the data path, and ONE all-gather
+of the log-probabilities (8 bytes per evaluation) when every rank needs the full
+vector -- e.g. to run the identical accept/reject step of a walker-sharded
+ensemble.  Nothing here computes a likelihood: ``evaluate`` is the engine call.
+"""
+import numpy as np
+
+__all__ = ["block_bounds", "shard_rows", "shard_lightcurves", "all_gather_rows",
+           "sharded_log_prob", "LightcurveShard"]
+
+
+def block_bounds(n_items, world_size):
+    """Contiguous, balanced blocks: rank r owns [b[r], b[r+1])."""
+    base, extra = divmod(int(n_items), int(world_size))
+    sizes = np.full(world_size, base, dtype=np.int64)
+    sizes[:extra] += 1
+    return np.concatenate([[0], np.cumsum(sizes)])
+
+
+def shard_rows(n_rows, rank, world_size):
+    """Row range of a theta batch owned by ``rank`` (configs with one replicated
+    light curve: the half-ensemble is split evenly across GPUs)."""
+    b = block_bounds(n_rows, world_size)
+    return int(b[rank]), int(b[rank + 1])
+
+
+def shard_lightcurves(n_lightcurves, rank, world_size):
+    """Light-curve range resident on ``rank`` (the Protassov sweep: independent
+    light curves, no communication until the final gather)."""
+    return shard_rows(n_lightcurves, rank, world_size)
+
+
+def all_gather_rows(local, counts, group=None, device=None):
+    """All-gather variable-length 1-d float64 (or int32) shards into the full vector.
+
+    ``counts[r]`` is the length of rank r's shard.  Shards are padded to the longest so
+    that a single fixed-size collective moves them (RCCL all_gather needs equal sizes)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    counts = [int(c) for c in counts]
+    assert len(counts) == world and len(local) == counts[dist.get_rank(group)]
+    width = max(counts) if counts else 0
+    dtype = torch.float64 if np.asarray(local).dtype.kind == "f" else torch.int32
+    buf = torch.zeros(width, dtype=dtype, device=device)
+    if len(local):
+        buf[:len(local)] = torch.as_tensor(np.ascontiguousarray(local), dtype=dtype, device=device)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    parts = [g[:c].cpu().numpy() for g, c in zip(gathered, counts)]
+    return np.concatenate(parts) if parts else np.empty(0)
+
+
+def sharded_log_prob(evaluate, theta, lc_index=None, group=None, device=None):
+    """Row-sharded evaluation with one all-gather.
+
+    Every rank calls this with the SAME ``theta[B, P]`` (and ``lc_index[B]``); rank r
+    evaluates rows ``shard_rows(B, r, world)`` through ``evaluate(theta_rows, lc_rows) ->
+    (lnP, status)`` and all ranks return the full ``(lnP[B], status[B])``."""
+    import torch.distributed as dist
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    B = theta.shape[0]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return evaluate(theta, lc_index)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = block_bounds(B, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    lc_rows = None if lc_index is None else np.asarray(lc_index)[lo:hi]
+    if hi > lo:
+        lnp, status = evaluate(theta[lo:hi], lc_rows)
+    else:
+        lnp, status = np.empty(0), np.empty(0, dtype=np.int32)
+    counts = np.diff(bounds)
+    return (all_gather_rows(np.asarray(lnp, dtype=np.float64), counts, group, device),
+            all_gather_rows(np.asarray(status, dtype=np.int32), counts, group, device).astype(np.int32))
+
+
+class LightcurveShard:
+    """This rank's block of a light-curve set (Protassov sweep, BASELINE configs[3]).
+
+    ``lo, hi`` are the global indices resident here; ``to_local`` maps a global
+    ``lc_index`` array of rows that belong to this rank to indices into the local
+    ``Y[lo:hi]`` uploaded to this rank's engine; ``gather`` all-gathers a per-light-curve
+    result (e.g. max lnL per light curve, gpmodelling.py:431-436) onto every rank."""
+
+    def __init__(self, n_lightcurves, rank=None, world_size=None, group=None):
+        import torch.distributed as dist
+        if rank is None or world_size is None:
+            if dist.is_available() and dist.is_initialized():
+                rank, world_size = dist.get_rank(group), dist.get_world_size(group)
+            else:
+                rank, world_size = 0, 1
+        self.n, self.rank, self.world, self.group = int(n_lightcurves), int(rank), int(world_size), group
+        self.bounds = block_bounds(self.n, self.world)
+        self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def owns(self, lc_index):
+        lc_index = np.asarray(lc_index)
+        return (lc_index >= self.lo) & (lc_index < self.hi)
+
+    def to_local(self, lc_index):
+        lc_index = np.asarray(lc_index)
+        if np.any(~self.owns(lc_index)):
+            raise ValueError("light curve outside this rank's shard [%d, %d)" % (self.lo, self.hi))
+        return (lc_index - self.lo).astype(np.int32)
+
+    def gather(self, per_lightcurve_values, device=None):
+        values = np.asarray(per_lightcurve_values, dtype=np.float64)
+        if values.shape != (len(self),):
+            raise ValueError("expected one value per local light curve")
+        if self.world == 1:
+            return values
+        return all_gather_rows(values, np.diff(self.bounds), self.group, device)

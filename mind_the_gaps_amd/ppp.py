@@ -1,0 +1,322 @@
+"""Lock-step posteriors for MANY light curves: the Protassov loop as a batch axis.
+
+The reference refits every simulated light curve one after the other
+(/root/reference/docs/notebooks/tutorial_ppp.ipynb:326-343):
+
+    for lc in lcs:
+        gpm = GPModelling(lc, kernel)
+        gpm.derive_posteriors(fit=True, max_steps=500, walkers=2 * cpus, cores=cpus)
+        likelihoods.append(gpm.max_loglikelihood)
+
+Every light curve is an independent problem of identical shape, so here all L
+ensembles advance together: one stretch-move half-step of every ensemble is ONE
+launch of L * W/2 evaluations (`LogProbEvaluator.evaluate` over the L resident
+light curves).  The move, the acceptance rule, the autocorrelation estimate and
+the burn-in / thinning arithmetic are those of `sampler.EnsembleSampler` and
+`GPModelling.derive_posteriors` (gpmodelling.py:197-286), applied per light curve;
+random numbers come from one vectorised generator instead of L private streams.
+"""
+import warnings
+
+import numpy as np
+
+from . import engine as _engine
+from .gp import DeviceModel, LinAlgError, LogProbEvaluator
+from .modeling import ConstantModel
+from .sampler import integrated_time
+
+__all__ = ["EnsembleBatchSampler", "BatchPosteriors", "derive_posteriors_batch", "batched_minimize"]
+
+
+class EnsembleBatchSampler:
+    """L independent affine-invariant ensembles (stretch move, a = 2) in lock-step.
+
+    ``log_prob_fn(coords[B, ndim], lc_index[B]) -> lnP[B]``.  ``store_chain=False`` keeps
+    only the running best sample of every light curve (what the LRT needs) instead of
+    the [steps, L, W, ndim] chain.
+    """
+
+    def __init__(self, nlc, nwalkers, ndim, log_prob_fn, seed=None, a=2.0, store_chain=True):
+        if nwalkers < 2 * ndim:
+            raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than "
+                               "twice the number of dimensions.")
+        if nwalkers % 2:
+            raise ValueError("the lock-step sampler needs an even number of walkers")
+        self.L, self.W, self.ndim = int(nlc), int(nwalkers), int(ndim)
+        self.log_prob_fn = log_prob_fn
+        self.a = float(a)
+        self.rng = np.random.default_rng(seed)
+        self.store_chain = store_chain
+        self.iteration = 0
+        self._chain = []
+        self._lnp = []
+        self.coords = None
+        self.lnp = None
+        self.best_lnp = np.full(self.L, -np.inf)
+        self.best_coords = np.full((self.L, self.ndim), np.nan)
+        self.n_accepted = np.zeros((self.L, self.W))
+
+    def _evaluate(self, coords):
+        """coords [L, K, ndim] -> lnP [L, K] in one call."""
+        L, K, _ = coords.shape
+        flat = coords.reshape(L * K, self.ndim)
+        if not np.all(np.isfinite(flat)):
+            raise ValueError("At least one parameter value was infinite or NaN")
+        lc = np.repeat(np.arange(L, dtype=np.int32), K)
+        lnp = np.asarray(self.log_prob_fn(flat, lc), dtype=np.float64)
+        if np.any(np.isnan(lnp)):
+            raise ValueError("Probability function returned NaN")
+        return lnp.reshape(L, K)
+
+    def _track_best(self):
+        j = np.argmax(self.lnp, axis=1)
+        cand = self.lnp[np.arange(self.L), j]
+        better = cand > self.best_lnp
+        self.best_lnp[better] = cand[better]
+        self.best_coords[better] = self.coords[np.arange(self.L), j][better]
+
+    def run(self, initial_state, steps, progress=False):
+        """Advance every ensemble ``steps`` iterations from ``initial_state`` [L, W, ndim]
+        (or continue when it is None)."""
+        L, W, ndim, half = self.L, self.W, self.ndim, self.W // 2
+        if initial_state is not None:
+            p0 = np.array(initial_state, dtype=np.float64)
+            if p0.shape != (L, W, ndim):
+                raise ValueError("incompatible input dimensions {0}".format(p0.shape))
+            self.coords = p0
+            self.lnp = self._evaluate(p0)
+            self._track_best()
+        rows = np.arange(L)[:, None]
+        for _ in range(int(steps)):
+            # red/blue split, independently shuffled for every light curve
+            order = np.argsort(self.rng.random((L, W)), axis=1)
+            red, blue = order[:, :half], order[:, half:]
+            for first, other in ((red, blue), (blue, red)):
+                s = self.coords[rows, first]                                   # [L, half, ndim]
+                zz = ((self.a - 1.0) * self.rng.random((L, half)) + 1.0) ** 2 / self.a
+                partner = other[rows, self.rng.integers(half, size=(L, half))]
+                c = self.coords[rows, partner]
+                q = c - (c - s) * zz[:, :, None]
+                new_lnp = self._evaluate(q)                                    # <- ONE launch
+                lnpdiff = (ndim - 1.0) * np.log(zz) + new_lnp - self.lnp[rows, first]
+                accept = lnpdiff > np.log(self.rng.random((L, half)))
+                li, wi = np.nonzero(accept)
+                tgt = first[li, wi]
+                self.coords[li, tgt] = q[li, wi]
+                self.lnp[li, tgt] = new_lnp[li, wi]
+                self.n_accepted[li, tgt] += 1
+            self.iteration += 1
+            self._track_best()
+            if self.store_chain:
+                self._chain.append(self.coords.copy())
+                self._lnp.append(self.lnp.copy())
+        return self.coords, self.lnp
+
+    # -- per-light-curve views -------------------------------------------------------
+    def get_chain(self, lc=None):
+        chain = np.asarray(self._chain)                     # [steps, L, W, ndim]
+        return chain if lc is None else chain[:, lc]
+
+    def get_log_prob(self, lc=None):
+        lnp = np.asarray(self._lnp)
+        return lnp if lc is None else lnp[:, lc]
+
+    def get_autocorr_time(self, tol=0):
+        """tau[L, ndim]: integrated autocorrelation time per light curve and parameter."""
+        chain = self.get_chain()
+        return np.array([integrated_time(chain[:, l], tol=tol, quiet=True) for l in range(self.L)])
+
+    @property
+    def acceptance_fraction(self):
+        return self.n_accepted / float(max(self.iteration, 1))
+
+
+def batched_minimize(fun, x0, lower, upper, max_iter=60, history=8, fd_step=1e-6, gtol=1e-5, ftol=1e-10):
+    """Projected L-BFGS for L independent box-constrained problems in lock-step.
+
+    ``fun(X[M, P], lc[M]) -> f[M]``; ``x0`` [L, P]; ``lower``/``upper`` [P].  Each
+    iteration costs one launch for the forward-difference gradients (L * (P + 1)
+    evaluations) plus one per backtracking round (L evaluations).  It plays the role of
+    ``scipy.optimize.minimize(method="L-BFGS-B")`` in GPModelling.fit (gpmodelling.py:192)
+    for the lock-step driver: a good starting point for the walkers, not a bit-identical
+    optimiser path.  Returns (x[L, P], f[L], iterations).
+    """
+    x = np.clip(np.array(x0, dtype=np.float64), lower, upper)
+    L, P = x.shape
+    lcs = np.arange(L, dtype=np.int32)
+
+    def value_and_grad(x):
+        h = np.where(x + fd_step > upper, -fd_step, fd_step)            # step inward at the upper bound
+        pts = np.repeat(x[:, None, :], P + 1, axis=1)                   # [L, P+1, P]
+        pts[:, 1:, :] += np.eye(P)[None] * h[:, None, :]
+        vals = fun(pts.reshape(-1, P), np.repeat(lcs, P + 1)).reshape(L, P + 1)
+        return vals[:, 0], (vals[:, 1:] - vals[:, :1]) / h
+
+    f, g = value_and_grad(x)
+    S, Y = [], []
+    active = np.ones(L, dtype=bool)
+    it = 0
+    for it in range(1, max_iter + 1):
+        # projected gradient: components pushing out of the box are dropped
+        blocked = ((x <= lower) & (g > 0)) | ((x >= upper) & (g < 0))
+        pg = np.where(blocked, 0.0, g)
+        active &= np.max(np.abs(pg), axis=1) > gtol
+        if not active.any():
+            break
+        # two-loop recursion, vectorised over the L problems
+        q = pg.copy()
+        alphas = []
+        for s, yv in zip(reversed(S), reversed(Y)):
+            rho = 1.0 / np.maximum(np.einsum("lp,lp->l", yv, s), 1e-300)
+            a = rho * np.einsum("lp,lp->l", s, q)
+            q -= a[:, None] * yv
+            alphas.append((a, rho))
+        if S:
+            sy = np.einsum("lp,lp->l", S[-1], Y[-1])
+            yy = np.maximum(np.einsum("lp,lp->l", Y[-1], Y[-1]), 1e-300)
+            q *= np.where(sy > 0, sy / yy, 1.0)[:, None]
+        for (a, rho), s, yv in zip(reversed(alphas), S, Y):
+            b = rho * np.einsum("lp,lp->l", yv, q)
+            q += (a - b)[:, None] * s
+        d = -np.where(blocked, 0.0, q)
+        bad_dir = np.einsum("lp,lp->l", d, pg) >= 0                      # not a descent direction
+        d[bad_dir] = -pg[bad_dir]
+        # backtracking (Armijo) on the projected path
+        step = np.ones(L)
+        x_new, f_new = x.copy(), f.copy()
+        todo = active.copy()
+        for _ in range(20):
+            if not todo.any():
+                break
+            trial = np.clip(x[todo] + step[todo, None] * d[todo], lower, upper)
+            ft = fun(trial, lcs[todo])
+            ok = np.isfinite(ft) & (ft <= f[todo] + 1e-4 * np.einsum("lp,lp->l", pg[todo], trial - x[todo]))
+            idx = np.flatnonzero(todo)
+            x_new[idx[ok]] = trial[ok]
+            f_new[idx[ok]] = ft[ok]
+            todo[idx[ok]] = False
+            step[todo] *= 0.5
+        active &= ~todo                                                   # line search failed: stop there
+        f_old = f
+        g_old = g
+        moved = np.any(x_new != x, axis=1)
+        f_try, g_try = value_and_grad(x_new)
+        s_vec, y_vec = x_new - x, g_try - g_old
+        good = np.einsum("lp,lp->l", s_vec, y_vec) > 1e-12
+        S.append(np.where(good[:, None], s_vec, 0.0))
+        Y.append(np.where(good[:, None], y_vec, 0.0))
+        if len(S) > history:
+            S.pop(0), Y.pop(0)
+        x, f, g = x_new, f_try, g_try
+        active &= moved & (np.abs(f_old - f) > ftol * np.maximum(np.abs(f), 1.0))
+    return x, f, it
+
+
+class BatchPosteriors:
+    """Per-light-curve results of :func:`derive_posteriors_batch` (the accessors of
+    GPModelling, gpmodelling.py:405-475, with a leading light-curve axis)."""
+
+    def __init__(self, sampler, tau, discard, thin, fit_params, fit_loglike, parameter_names):
+        self.sampler = sampler
+        self.tau = tau                              # [L, ndim]
+        self.discard, self.thin = discard, thin     # [L]
+        self.fit_parameters = fit_params            # [L, ndim] or None
+        self.fit_loglikelihood = fit_loglike        # [L] or None
+        self.parameter_names = parameter_names
+        L = sampler.L
+        if sampler.store_chain:
+            lnp = sampler.get_log_prob()            # [steps, L, W]
+            chain = sampler.get_chain()
+            self.max_loglikelihood = np.empty(L)
+            self.max_parameters = np.empty((L, sampler.ndim))
+            self.median_parameters = np.empty((L, sampler.ndim))
+            for l in range(L):
+                sl = slice(discard[l] + thin[l] - 1, None, thin[l])
+                lp = lnp[sl, l].reshape(-1)
+                ch = chain[sl, l].reshape(-1, sampler.ndim)
+                k = int(np.argmax(lp))
+                self.max_loglikelihood[l] = lp[k]
+                self.max_parameters[l] = ch[k]
+                self.median_parameters[l] = np.median(ch, axis=0)
+        else:
+            self.max_loglikelihood = sampler.best_lnp.copy()
+            self.max_parameters = sampler.best_coords.copy()
+            self.median_parameters = None
+
+
+def _spread(rng, centers, lower, upper, walkers, percent=0.1, max_attempts=20):
+    """spread_walkers (gpmodelling.py:289-350) for every light curve at once."""
+    L, P = centers.shape
+    std = np.abs(centers) * percent
+    p0 = rng.normal(centers[:, None, :], std[:, None, :], size=(L, walkers, P))
+    for _ in range(max_attempts):
+        out = np.any((p0 < lower) | (p0 > upper), axis=2)
+        if not out.any():
+            break
+        li, wi = np.nonzero(out)
+        p0[li, wi] = rng.normal(centers[li], std[li])
+    below, above = p0 < lower, p0 > upper
+    if below.any() or above.any():
+        warnings.warn("Some walkers are out of bounds! Setting them to values close to the bounds")
+        lo_f = np.where(lower > 0, 1.05, 0.95) * lower
+        hi_f = np.where(upper > 0, 0.95, 1.05) * upper
+        p0 = np.where(below, np.broadcast_to(lo_f, p0.shape), p0)
+        p0 = np.where(above, np.broadcast_to(hi_f, p0.shape), p0)
+    return p0
+
+
+def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit=True, seed=None,
+                            device=0, store_chain=True, initial_params=None, quiet=False,
+                            evaluate=None):
+    """GPModelling(lc, kernel).derive_posteriors(...) for L light curves at once.
+
+    times [N] (shared sampling, gpmodelling.py:538); Y, DY [L, N]; ``kernel`` a
+    mind_the_gaps_amd Term (its current parameter vector is the common starting point,
+    as in the tutorial loop).  The mean of every light curve is frozen at its own average
+    (the reference default, gpmodelling.py:83-87).  ``evaluate`` overrides the engine call
+    ``(theta[B, P], lc[B], add_prior) -> (lnP, status)`` (used by the multi-GPU driver).
+    """
+    Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+    DY = np.atleast_2d(np.asarray(DY, dtype=np.float64))
+    L = Y.shape[0]
+    model = DeviceModel(kernel, ConstantModel(0.0), np.zeros(1, dtype=bool))
+    if not model.device_terms:
+        raise ValueError("the lock-step driver needs device-expandable terms")
+    model.y_offset = None                         # offsets are per light curve, owned by the evaluator
+    if evaluate is None:
+        ev = LogProbEvaluator(times, Y, DY + 1e-12, device=device, y_offset=Y.mean(axis=1))
+
+        def evaluate(theta, lc, add_prior):
+            return ev.evaluate(model, theta, lc, add_prior=add_prior)
+
+    def checked(theta, lc, add_prior):
+        out, status = evaluate(theta, lc, add_prior)
+        if not quiet and np.any(status == _engine.ST_NOTPD):
+            raise LinAlgError("failed to factorize or solve matrix")
+        return out
+
+    P = len(model.free_index)
+    lower, upper = model.bounds[model.free_index, 0], model.bounds[model.free_index, 1]
+    start = model.full[model.free_index] if initial_params is None else np.asarray(initial_params, float)
+    centers = np.broadcast_to(start, (L, P)).copy()
+    fit_x = fit_f = None
+    if fit:
+        fit_x, fit_f, _ = batched_minimize(lambda x, lc: -checked(x, lc, False), centers, lower, upper)
+        centers, fit_f = fit_x, -fit_f
+    rng = np.random.default_rng(seed)
+    p0 = _spread(rng, centers, lower, upper, walkers)
+    sampler = EnsembleBatchSampler(L, walkers, P, lambda x, lc: checked(x, lc, True), seed=rng,
+                                   store_chain=store_chain)
+    sampler.run(p0, max_steps)
+    if store_chain:
+        tau = sampler.get_autocorr_time(tol=0)
+        mean_tau = np.mean(tau, axis=1)
+        # not-converged branch of gpmodelling.py:272-276 (a fixed-length PPP run never "converges")
+        thin = np.maximum((mean_tau / 4).astype(int), 1)
+        discard = np.minimum(mean_tau.astype(int) * 5, np.maximum(max_steps - thin, 0))
+    else:
+        tau = None
+        thin = np.ones(L, dtype=int)
+        discard = np.zeros(L, dtype=int)
+    names = tuple("kernel:" + n for n in kernel.get_parameter_names())
+    return BatchPosteriors(sampler, tau, discard, thin, fit_x, fit_f, names)

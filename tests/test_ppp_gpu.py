@@ -1,0 +1,119 @@
+"""GPU tests of the lock-step driver (many light curves in one launch) and of the
+larger BASELINE configurations."""
+import warnings
+
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import synthetic as synth
+from mind_the_gaps_amd import terms
+from mind_the_gaps_amd.gpmodelling import GPModelling
+from mind_the_gaps_amd.lightcurves import GappyLightcurve
+from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
+from mind_the_gaps_amd.ppp import derive_posteriors_batch
+from oracle import celerite as oracle_c
+
+pytestmark = pytest.mark.gpu
+AMP, OTHER = (-10, 50), (-10, 10)
+
+
+def null_kernel():
+    th = synth.truth(synth.NULL_MODEL)
+    return DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]) + terms.SHOTerm(th[2], th[3], th[4],
+                                                                               bounds=[AMP, OTHER, OTHER])
+
+
+def alt_kernel():
+    th = synth.truth(synth.ALT_MODEL)
+    return null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[AMP, OTHER, OTHER])
+
+
+def test_batch_posteriors_match_oracle_and_single_lightcurve_runs():
+    N, L, W = 400, 6, 12
+    t, y, dy = synth.make_lightcurves(N, L, seed=31)
+    y += 5.0 * np.arange(L)[:, None]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = derive_posteriors_batch(t, y, dy, null_kernel(), walkers=W, max_steps=80, fit=True, seed=4)
+    assert res.max_loglikelihood.shape == (L,) and res.max_parameters.shape == (L, 5)
+    assert res.tau.shape == (L, 5) and res.parameter_names[0] == "kernel:terms[0]:log_S0"
+    # every reported maximum is the oracle's lnP of that sample on that light curve
+    full = np.hstack([res.max_parameters, y.mean(axis=1)[:, None]])
+    bounds = np.vstack([synth.bounds_for(synth.NULL_MODEL), [(-np.inf, np.inf)]])
+    ref = oracle_c.logprob_batch(t, y, dy, synth.NULL_MODEL, full, bounds=bounds,
+                                 lc_index=np.arange(L, dtype=np.int32), add_prior=True)[0]
+    assert np.max(np.abs(res.max_loglikelihood - ref) / np.abs(ref)) < 1e-8
+    # the lock-step fit lands where scipy's L-BFGS-B does light curve by light curve (the
+    # surfaces are flat and both optimisers use noisy forward differences: a few units
+    # of lnL either way), and the chains stay at that mode
+    for l in (0, L - 1):
+        g = GPModelling(GappyLightcurve(t, y[l], dy[l]), null_kernel())
+        sol = g.fit()
+        assert abs(res.fit_loglikelihood[l] + sol.fun) < 5.0
+        assert res.max_loglikelihood[l] >= res.fit_loglikelihood[l] - 1.0
+        ref_fit = oracle_c.logprob_batch(t, y[l], dy[l], synth.NULL_MODEL,
+                                         np.append(res.fit_parameters[l], y[l].mean()))[0][0]
+        assert abs(res.fit_loglikelihood[l] - ref_fit) / abs(ref_fit) < 1e-8
+
+
+def test_lrt_statistic_null_vs_alternative():
+    """BASELINE configs[2]: null vs alternative on the same data; T = -2 (lnL_null - lnL_alt) >= 0
+    up to sampling noise (nested models)."""
+    N, L, W = 500, 4, 16
+    t, y, dy = synth.make_lightcurves(N, L, seed=41)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        null = derive_posteriors_batch(t, y, dy, null_kernel(), walkers=W, max_steps=60, seed=1, store_chain=False)
+        alt = derive_posteriors_batch(t, y, dy, alt_kernel(), walkers=W, max_steps=60, seed=2, store_chain=False)
+    T = -2.0 * (null.max_loglikelihood - alt.max_loglikelihood)
+    assert T.shape == (L,) and np.all(np.isfinite(T)) and np.all(T > -3.0)
+
+
+def test_config5_stress_parity(engine):
+    """BASELINE configs[4]: N = 200 000 irregular samples, 5 SHO terms (J = 10)."""
+    kinds = [synth.K_SHO] * 5
+    N, B = 200000, 24
+    t, y, dy = synth.make_lightcurves(N, 1, seed=20250709)
+    th = synth.truth(kinds)
+    for i in range(5):
+        th[3 * i:3 * i + 3] = [np.log(20.0 + 10 * i), np.log([3.0, 8.0, 10.0, 1.0, 0.8][i]), np.log(2 * np.pi / (5.0 + 6 * i))]
+    rng = np.random.default_rng(5)
+    theta = th + 0.05 * np.abs(th) * rng.standard_normal((B, len(th)))
+    full = np.concatenate([th, [0.0]])
+    bounds = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)]])
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, np.arange(15, dtype=np.int32), bounds)
+    out, st = engine.loglike(theta, add_prior=True)
+    ref, rst = oracle_c.logprob_batch(t, y[0], dy[0], kinds, np.hstack([theta, np.full((B, 1), y.mean())]),
+                                      bounds=bounds, add_prior=True, nthreads=8)
+    assert np.array_equal(st, rst) and np.all(st == 0)
+    assert np.max(np.abs(out - ref) / np.abs(ref)) < 1e-8
+
+
+def test_encode_properties_at_baseline_size(engine):
+    """Size-independent properties at N = 1e4, J = 6 (no oracle): permutation of the batch
+    permutes the output; duplicating light curves duplicates results; scaling y, dy and the
+    amplitudes by s shifts lnL by -N ln s."""
+    kinds = synth.ALT_MODEL
+    N, L, W = 10000, 8, 64
+    t, y, dy = synth.make_lightcurves(N, L, seed=99)
+    y[L // 2:] = y[:L // 2]; dy[L // 2:] = dy[:L // 2]                   # duplicated light curves
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    theta = np.tile(synth.draw_thetas(kinds, W, seed=2), (L, 1))
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, free, bounds)
+    out, st = engine.loglike(theta, lc)
+    assert np.all(st == 0)
+    o = out.reshape(L, W)
+    assert np.array_equal(o[:L // 2], o[L // 2:])
+    perm = np.random.default_rng(0).permutation(L * W)
+    out_p, _ = engine.loglike(theta[perm], lc[perm])
+    assert np.array_equal(out_p, out[perm])
+    s = 3.0                                                               # K -> s^2 K, r -> s r
+    engine.set_lightcurves(t, s * y, s * (dy + 1e-12), y_offset=s * y.mean(axis=1))
+    theta_s = theta.copy()
+    theta_s[:, [0, 2, 5]] += 2.0 * np.log(s)                              # log_S0 of DRW, SHO, Lorentzian
+    out_s, st_s = engine.loglike(theta_s, lc)
+    assert np.all(st_s == 0)
+    assert np.max(np.abs(out_s - (out - N * np.log(s))) / np.abs(out)) < 1e-10
