@@ -371,11 +371,12 @@ template <int NR, int NC>
 __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_solve_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;  // celerite rank
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if ((int64_t)blockIdx.x * MTG_BLOCK >= count) return;  // whole workgroup idle (e.g. empty signature list)
     __shared__ MtgMathTablesT<(NC > 0)> tab;
     mtg_fill_tables(&tab, threadIdx.x, MTG_BLOCK);
     __syncthreads();
     const int64_t gid = (int64_t)blockIdx.x * MTG_BLOCK + threadIdx.x;
-    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
     if (gid >= count) return;
     const int64_t e = a.list ? (int64_t)a.list[gid] : gid;
     if (!a.list && a.status[e] != MTG_ST_OK) return;  // prior said -inf

@@ -5,7 +5,8 @@ HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SI
 and WRITE_SIZE come from separate --pmc passes, are in KiB, and on gfx950
 FETCH_SIZE tallies 128-B requests at 64 B, so the read side is doubled.  The
 doubling is calibrated in the same run on mtg_lc_setup_kernel, whose byte count
-is known (it reads dy[L*N] + t[N] and writes var[L*N] + dx[N]).
+is known (it reads y[L*N] + yerr[L*N] + t[N] + y_offset[L] and writes the
+interleaved (y, var)[L*N] and (dx, t)[N] pairs).
 """
 import csv
 import glob
@@ -50,8 +51,8 @@ with open(os.path.join(dst, tag + "_pmc_hbm.csv"), "w", newline="") as fh:
     wr.writerows(rows)
 
 setup = [r for r in rows if r["kernel"].startswith("mtg_lc_setup_kernel")][0]
-known_read = (L * N + N) * 8.0
-known_write = (L * N + N) * 8.0
+known_read = (2 * L * N + N + L) * 8.0     # y, yerr, t, y_offset
+known_write = (L * N + N) * 16.0            # interleaved (y, var) and (dx, t) pairs
 solve = max((r for r in rows if "mtg_solve_kernel" in r["kernel"]),
             key=lambda r: r["hbm_read_bytes_corrected"])
 rec = {
