@@ -236,7 +236,7 @@ void mtg_launch_prepare(const MtgPrepArgs &a, hipStream_t stream)
 #endif
 __host__ __device__ constexpr int mtg_waves_for(int J)
 {
-    return (J <= 2 ? 5 : J <= 3 ? 4 : J <= 5 ? 3 : J <= 8 ? 2 : 1) + MTG_WAVES_BIAS;
+    return (J <= 2 ? 5 : J <= 3 ? 3 : J <= 8 ? 2 : 1) + MTG_WAVES_BIAS;
 }
 
 // Per-lane state of one evaluation, all statically indexed -> VGPRs.
@@ -285,15 +285,9 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
 
-    double2 dt_n = ld(rdt, toff, 0), yv_n = ld(ryv, yoff, 0);
-    const uint32_t N = (uint32_t)a.N;
-    uint32_t soff = 0;
-    for (uint32_t n = 0; n < N; ++n) {
-        const double dxc = dt_n.x, tc = dt_n.y, yc = yv_n.x, vc = yv_n.y;
-        // prefetch the next sample under this step's arithmetic
-        soff += 16;
-        dt_n = ld(rdt, toff, soff); yv_n = ld(ryv, yoff, soff);
-
+    // One step of the recurrence for the sample (dxc, tc, yc, vc): a single basic block.
+    auto step = [&](const double2 dtc, const double2 yvc) __attribute__((always_inline)) {
+        const double dxc = dtc.x, tc = dtc.y, yc = yvc.x, vc = yvc.y;
         // -- per-term propagators and generators (celerite phi, U, V) ---------
         double ph[NT > 0 ? NT : 1];
         double U[J], V[J];
@@ -358,10 +352,31 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         L.invD = mtg_rcp(D);
         L.z = zn;
         L.dot = fma(zn * zn, L.invD, L.dot);
-        // ln det K = ln prod D_n: running product with the exponent peeled off every step
-        const double pr = L.dprod * D;
+        L.dprod *= D;  // ln det K = ln prod D_n, exponent peeled off by the caller
+    };
+    // ln det: the pivot product is renormalised every two steps (D in (1e-70, 1e70))
+    auto renorm = [&]() __attribute__((always_inline)) {
+        const double pr = L.dprod;
         L.dprod = __builtin_amdgcn_frexp_mant(pr);
         L.dexp += __builtin_amdgcn_frexp_exp(pr);
+    };
+
+    // Two steps per trip with ping-pong sample registers: the sample of step n + 1 is
+    // loaded under the arithmetic of step n and nothing is copied between registers.
+    const uint32_t N = (uint32_t)a.N;
+    double2 dtA = ld(rdt, toff, 0), yvA = ld(ryv, yoff, 0);
+    uint32_t soff = 0;
+    for (uint32_t n = 0; n + 1 < N; n += 2) {
+        const double2 dtB = ld(rdt, toff, soff + 16), yvB = ld(ryv, yoff, soff + 16);
+        step(dtA, yvA);
+        soff += 32;
+        dtA = ld(rdt, toff, soff); yvA = ld(ryv, yoff, soff);
+        step(dtB, yvB);
+        renorm();
+    }
+    if (N & 1u) {
+        step(dtA, yvA);
+        renorm();
     }
 }
 
