@@ -170,6 +170,28 @@ MTG_API double mtg_last_kernel_ms(const mtg_ctx *ctx);
 MTG_API int mtg_profile_begin(mtg_ctx *ctx, int capacity);
 MTG_API int mtg_profile_read(mtg_ctx *ctx, int capacity, double *prepare_ms, double *solve_ms);
 /*
+ * Device-resident lock-step ensembles: emcee's stretch move (a = 2, random red/blue
+ * split) as `derive_posteriors` drives it (gpmodelling.py:245-248), for E independent
+ * ensembles of W walkers with state, random numbers (Philox4x32-10 keyed by `seed`)
+ * and accept/reject on the GPU; one iteration = 2 x W/2 evaluations per ensemble, no
+ * host synchronisation inside mtg_ensemble_run.
+ *   coords          [E][W][P] initial walkers (host), e.g. from spread_walkers
+ *   lc_of_ensemble  [E] light curve of every ensemble; NULL = ensemble e -> light
+ *                   curve e (E == L), or all -> 0 when one light curve is resident
+ *   chain/lnp_chain [steps][E][W][P] / [steps][E][W] host buffers or NULL (emcee's
+ *                   get_chain / get_log_prob layout per ensemble)
+ * mtg_ensemble_get copies out the current state, the best sample seen per ensemble
+ * (max_loglikelihood / max_parameters, gpmodelling.py:431-443), acceptance counts,
+ * the iteration count and the number of proposals whose covariance was not positive
+ * definite (celerite would have raised LinAlgError; they are rejected here).
+ */
+MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, const double *coords,
+                              const int32_t *lc_of_ensemble);
+MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp_chain);
+MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *best_lnp, double *best_coords,
+                             int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
+
+/*
  * Accuracy probe of the device elementary functions the recurrence uses
  * (tests only): exp_neg[i] = exp(-x[i]), sin/cos(x[i]), rcp_x[i] = 1 / x[i] for
  * n host values x >= 0.

@@ -61,6 +61,14 @@ struct mtg_ctx {
     // staging for the host-pointer entry points
     DevBuf theta, lc, out, status;
 
+    // device-resident ensembles (mtg_ensemble_*)
+    int64_t ens_E = 0;
+    int ens_W = 0, ens_P = 0;
+    uint64_t ens_seed = 0;
+    uint32_t ens_iteration = 0;
+    DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
+        ens_naccept, ens_best_lnp, ens_best_coords, ens_notpd, ens_chain, ens_lnp_chain;
+
     // per-call kernel timing (mtg_profile_*): event triples start / solve / end
     std::vector<hipEvent_t> prof_ev;
     int prof_cap = 0, prof_n = 0;
@@ -255,7 +263,11 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
-                      &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status};
+                      &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
+                      &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
+                      &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_naccept,
+                      &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,
+                      &ctx->ens_lnp_chain};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -545,6 +557,130 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(status, ctx->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, const double *coords,
+                              const int32_t *lc_of_ensemble)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    const int P = ctx->model.P;
+    if (E <= 0 || W < 2 || (W & 1) || !coords || P <= 0)
+        return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: need E > 0, an even W >= 2, P > 0 and coords");
+    if (W < 2 * P)
+        return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: fewer walkers (%d) than twice the dimension (%d)", W, 2 * P);
+    if (E * (int64_t)W > INT32_MAX) return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: too many walkers");
+    if (!lc_of_ensemble && E != ctx->L && ctx->L != 1)
+        return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: %lld ensembles but %lld light curves and no map",
+                    (long long)E, (long long)ctx->L);
+    rc = use_device(ctx);
+    if (rc) return rc;
+    const int64_t EW = E * W, EH = E * (W / 2);
+    std::vector<int32_t> lc_full((size_t)EW), lc_half((size_t)EH);
+    for (int64_t e = 0; e < E; ++e) {
+        const int32_t l = lc_of_ensemble ? lc_of_ensemble[e] : (ctx->L == 1 ? 0 : (int32_t)e);
+        if (l < 0 || l >= ctx->L) return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: light curve %d out of range", l);
+        for (int w = 0; w < W; ++w) lc_full[(size_t)(e * W + w)] = l;
+        for (int k = 0; k < W / 2; ++k) lc_half[(size_t)(e * (W / 2) + k)] = l;
+    }
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, ctx->ens_coords.reserve((size_t)EW * P * 8));
+    HIP_TRY(ctx, ctx->ens_lnp.reserve((size_t)EW * 8));
+    HIP_TRY(ctx, ctx->ens_perm.reserve((size_t)EW * 4));
+    HIP_TRY(ctx, ctx->ens_q.reserve((size_t)EH * P * 8));
+    HIP_TRY(ctx, ctx->ens_factor.reserve((size_t)EH * 8));
+    HIP_TRY(ctx, ctx->ens_new.reserve((size_t)EW * 8));
+    HIP_TRY(ctx, ctx->ens_st.reserve((size_t)EW * 4));
+    HIP_TRY(ctx, ctx->ens_lc_full.reserve((size_t)EW * 4));
+    HIP_TRY(ctx, ctx->ens_lc_half.reserve((size_t)EH * 4));
+    HIP_TRY(ctx, ctx->ens_naccept.reserve((size_t)EW * 4));
+    HIP_TRY(ctx, ctx->ens_best_lnp.reserve((size_t)E * 8));
+    HIP_TRY(ctx, ctx->ens_best_coords.reserve((size_t)E * P * 8));
+    HIP_TRY(ctx, ctx->ens_notpd.reserve(64));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_coords.p, coords, (size_t)EW * P * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lc_full.p, lc_full.data(), (size_t)EW * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lc_half.p, lc_half.data(), (size_t)EH * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ens_naccept.p, 0, (size_t)EW * 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ens_notpd.p, 0, 4, s));
+    // log-probability of the initial state (emcee evaluates p0 once)
+    rc = run_model_batch(ctx, EW, ctx->ens_coords.as<double>(), ctx->ens_lc_full.as<int32_t>(), 1,
+                         ctx->ens_lnp.as<double>(), ctx->ens_st.as<int32_t>(), s);
+    if (rc) return rc;
+    mtg_launch_initial_best((int)E, W, P, ctx->ens_coords.as<double>(), ctx->ens_lnp.as<double>(),
+                            ctx->ens_best_lnp.as<double>(), ctx->ens_best_coords.as<double>(), s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));  // lc_full / lc_half live on this stack frame
+    ctx->ens_E = E; ctx->ens_W = W; ctx->ens_P = P; ctx->ens_seed = seed; ctx->ens_iteration = 0;
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp_chain)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (ctx->ens_E <= 0) return fail(ctx, MTG_E_STATE, "mtg_ensemble_init has not been called");
+    if (steps < 0) return fail(ctx, MTG_E_ARG, "mtg_ensemble_run: negative step count");
+    if (ctx->ens_P != ctx->model.P) return fail(ctx, MTG_E_STATE, "the model changed since mtg_ensemble_init");
+    rc = use_device(ctx);
+    if (rc) return rc;
+    const int E = (int)ctx->ens_E, W = ctx->ens_W, P = ctx->ens_P, H = W / 2;
+    const int64_t EW = (int64_t)E * W, EH = (int64_t)E * H;
+    hipStream_t s = ctx->stream;
+    if (chain) HIP_TRY(ctx, ctx->ens_chain.reserve((size_t)steps * EW * P * 8));
+    if (lnp_chain) HIP_TRY(ctx, ctx->ens_lnp_chain.reserve((size_t)steps * EW * 8));
+    for (int it = 0; it < steps; ++it) {
+        const uint32_t iter = ctx->ens_iteration;
+        mtg_launch_split(E, W, iter, ctx->ens_seed, ctx->ens_perm.as<int32_t>(), s);
+        for (int half = 0; half < 2; ++half) {
+            mtg_launch_propose(E, W, P, half, iter, ctx->ens_seed, 2.0, ctx->ens_perm.as<int32_t>(),
+                               ctx->ens_coords.as<double>(), ctx->ens_q.as<double>(),
+                               ctx->ens_factor.as<double>(), s);
+            rc = run_model_batch(ctx, EH, ctx->ens_q.as<double>(), ctx->ens_lc_half.as<int32_t>(), 1,
+                                 ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>(), s);
+            if (rc) return rc;
+            mtg_launch_accept(E, W, P, half, iter, ctx->ens_seed, ctx->ens_perm.as<int32_t>(),
+                              ctx->ens_q.as<double>(), ctx->ens_factor.as<double>(), ctx->ens_new.as<double>(),
+                              ctx->ens_st.as<int32_t>(), ctx->ens_coords.as<double>(), ctx->ens_lnp.as<double>(),
+                              ctx->ens_naccept.as<int32_t>(), ctx->ens_best_lnp.as<double>(),
+                              ctx->ens_best_coords.as<double>(), ctx->ens_notpd.as<int32_t>(), s);
+        }
+        if (chain)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_chain.as<double>() + (size_t)it * EW * P, ctx->ens_coords.p,
+                                        (size_t)EW * P * 8, hipMemcpyDeviceToDevice, s));
+        if (lnp_chain)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lnp_chain.as<double>() + (size_t)it * EW, ctx->ens_lnp.p,
+                                        (size_t)EW * 8, hipMemcpyDeviceToDevice, s));
+        ctx->ens_iteration += 1;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (chain)
+        HIP_TRY(ctx, hipMemcpyAsync(chain, ctx->ens_chain.p, (size_t)steps * EW * P * 8, hipMemcpyDeviceToHost, s));
+    if (lnp_chain)
+        HIP_TRY(ctx, hipMemcpyAsync(lnp_chain, ctx->ens_lnp_chain.p, (size_t)steps * EW * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *best_lnp, double *best_coords,
+                             int32_t *naccept, int64_t *iteration, int32_t *n_notpd)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (ctx->ens_E <= 0) return fail(ctx, MTG_E_STATE, "mtg_ensemble_init has not been called");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const int64_t E = ctx->ens_E, EW = E * ctx->ens_W;
+    const int P = ctx->ens_P;
+    hipStream_t s = ctx->stream;
+    if (coords) HIP_TRY(ctx, hipMemcpyAsync(coords, ctx->ens_coords.p, (size_t)EW * P * 8, hipMemcpyDeviceToHost, s));
+    if (lnp) HIP_TRY(ctx, hipMemcpyAsync(lnp, ctx->ens_lnp.p, (size_t)EW * 8, hipMemcpyDeviceToHost, s));
+    if (best_lnp) HIP_TRY(ctx, hipMemcpyAsync(best_lnp, ctx->ens_best_lnp.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
+    if (best_coords)
+        HIP_TRY(ctx, hipMemcpyAsync(best_coords, ctx->ens_best_coords.p, (size_t)E * P * 8, hipMemcpyDeviceToHost, s));
+    if (naccept) HIP_TRY(ctx, hipMemcpyAsync(naccept, ctx->ens_naccept.p, (size_t)EW * 4, hipMemcpyDeviceToHost, s));
+    if (n_notpd) HIP_TRY(ctx, hipMemcpyAsync(n_notpd, ctx->ens_notpd.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (iteration) *iteration = ctx->ens_iteration;
     return MTG_OK;
 }
 

@@ -276,7 +276,6 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
     // (soffset += 16 per step) -- no VALU instruction is spent on addressing, and the
     // hardware range check makes the one-past-the-end prefetch of the last step a
     // harmless zero.  (y, sigma^2) and (dx, t) are interleaved: one 16-byte load each.
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t ryv =
         __builtin_amdgcn_make_buffer_rsrc((void *)a.yv, 0, (int)a.yv_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdt =

@@ -26,7 +26,7 @@ EXPORTS = (
     "mtg_last_error", "mtg_set_lightcurves", "mtg_set_lightcurves_device", "mtg_set_model",
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
-    "mtg_math_probe",
+    "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
 )
 
 
@@ -90,6 +90,12 @@ def load_library():
     lib.mtg_profile_begin.argtypes = [c_vp, c_int]
     lib.mtg_profile_read.restype = c_int
     lib.mtg_profile_read.argtypes = [c_vp, c_int, _dp, _dp]
+    lib.mtg_ensemble_init.restype = c_int
+    lib.mtg_ensemble_init.argtypes = [c_vp, c_i64, c_int, ctypes.c_uint64, _dp, _ip]
+    lib.mtg_ensemble_run.restype = c_int
+    lib.mtg_ensemble_run.argtypes = [c_vp, c_int, _dp, _dp]
+    lib.mtg_ensemble_get.restype = c_int
+    lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_math_probe.restype = c_int
     lib.mtg_math_probe.argtypes = [c_vp, c_i64, _dp, _dp, _dp, _dp, _dp]
     lib.mtg_structure_supported.restype = c_int
@@ -253,6 +259,42 @@ class Engine:
         if n < 0:
             self._check(n)
         return prep[:n], solve[:n]
+
+    # -- device-resident ensembles ------------------------------------------------------
+    def ensemble_init(self, coords, seed=0, lc_of_ensemble=None):
+        """coords [E][W][P]: start E lock-step ensembles of W walkers on the device."""
+        coords = _f64(coords)
+        if coords.ndim != 3 or coords.shape[2] != self.P:
+            raise ValueError("coords must be [E][W][P] with P = %r free parameters" % (self.P,))
+        lc = None if lc_of_ensemble is None else np.ascontiguousarray(lc_of_ensemble, dtype=np.int32)
+        if lc is not None and lc.shape != (coords.shape[0],):
+            raise ValueError("lc_of_ensemble must have one entry per ensemble")
+        self._check(self._lib.mtg_ensemble_init(self._ctx, coords.shape[0], coords.shape[1],
+                                                int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(coords), _iptr(lc)))
+        self._ens_shape = coords.shape
+
+    def ensemble_run(self, steps, store_chain=False):
+        """Advance every ensemble ``steps`` iterations; optionally return
+        (chain [steps][E][W][P], log_prob [steps][E][W])."""
+        E, W, P = self._ens_shape
+        chain = np.empty((steps, E, W, P)) if store_chain else None
+        lnp = np.empty((steps, E, W)) if store_chain else None
+        self._check(self._lib.mtg_ensemble_run(self._ctx, int(steps), _ptr(chain), _ptr(lnp)))
+        return chain, lnp
+
+    def ensemble_state(self):
+        """dict(coords, log_prob, best_log_prob, best_coords, naccept, iteration, n_not_pd)."""
+        E, W, P = self._ens_shape
+        out = dict(coords=np.empty((E, W, P)), log_prob=np.empty((E, W)), best_log_prob=np.empty(E),
+                   best_coords=np.empty((E, P)), naccept=np.empty((E, W), dtype=np.int32))
+        it = ctypes.c_int64(0)
+        bad = np.zeros(1, dtype=np.int32)
+        self._check(self._lib.mtg_ensemble_get(self._ctx, _ptr(out["coords"]), _ptr(out["log_prob"]),
+                                               _ptr(out["best_log_prob"]), _ptr(out["best_coords"]),
+                                               _iptr(out["naccept"]), ctypes.byref(it), _iptr(bad)))
+        out["iteration"] = int(it.value)
+        out["n_not_pd"] = int(bad[0])
+        return out
 
     def math_probe(self, x):
         """Device exp(-x), sin(x), cos(x), 1/x of the kernel's own math (accuracy tests)."""
