@@ -1,0 +1,90 @@
+"""Device-resident ensemble sampler with emcee's read surface.
+
+Same stretch move as ``sampler.EnsembleSampler`` (the emcee 3.1.4 semantics the
+reference relies on, /root/reference/mind_the_gaps/gpmodelling.py:247-285), but the
+walkers, the random numbers (Philox4x32-10) and the accept/reject step live on the
+GPU (``mtg_ensemble_*`` in include/mtg.h): ``run_mcmc`` enqueues all its iterations
+without a host round trip, which is what keeps a many-light-curve sweep at kernel speed.
+The chain comes back in emcee's layout, so ``get_autocorr_time``, ``get_chain`` and
+``get_log_prob`` behave as the reference expects.
+"""
+import numpy as np
+
+from .sampler import integrated_time
+
+__all__ = ["DeviceEnsembleSampler"]
+
+
+class DeviceEnsembleSampler:
+    """E lock-step ensembles of ``nwalkers`` walkers on one engine (E = 1 mirrors emcee).
+
+    ``bind`` is a zero-argument callable returning the engine with the right light curves
+    and model resident (``LogProbEvaluator._bind``); ``lc_of_ensemble`` maps ensembles to
+    light curves (default: ensemble e -> light curve e, or all -> 0 for one light curve).
+    """
+
+    def __init__(self, bind, nwalkers, ndim, n_ensembles=1, lc_of_ensemble=None, seed=None,
+                 store_chain=True):
+        if nwalkers < 2 * ndim:
+            raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than "
+                               "twice the number of dimensions.")
+        if nwalkers % 2:
+            raise ValueError("the device sampler needs an even number of walkers")
+        self._bind = bind
+        self.nwalkers, self.ndim, self.E = int(nwalkers), int(ndim), int(n_ensembles)
+        self.lc_of_ensemble = lc_of_ensemble
+        # like emcee, reproducible from numpy's global state when no seed is given
+        self.seed = int(np.random.randint(0, 2 ** 62)) if seed is None else int(seed)
+        self.store_chain = store_chain
+        self.iteration = 0
+        self._chain = np.empty((0, self.E, self.nwalkers, self.ndim))
+        self._log_prob = np.empty((0, self.E, self.nwalkers))
+        self._started = False
+
+    def run_mcmc(self, initial_state, nsteps):
+        eng = self._bind()
+        if initial_state is not None:
+            p0 = np.asarray(initial_state, dtype=np.float64)
+            if p0.ndim == 2:
+                p0 = p0[None]
+            if p0.shape != (self.E, self.nwalkers, self.ndim):
+                raise ValueError("incompatible input dimensions {0}".format(p0.shape))
+            if not np.all(np.isfinite(p0)):
+                raise ValueError("At least one parameter value was infinite or NaN")
+            eng.ensemble_init(p0, seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
+            self._started = True
+            self.iteration = 0
+            self._chain = np.empty((0, self.E, self.nwalkers, self.ndim))
+            self._log_prob = np.empty((0, self.E, self.nwalkers))
+        elif not self._started:
+            raise ValueError("cannot continue a run that was never started")
+        chain, lnp = eng.ensemble_run(int(nsteps), store_chain=self.store_chain)
+        if self.store_chain:
+            self._chain = np.concatenate([self._chain, chain], axis=0)
+            self._log_prob = np.concatenate([self._log_prob, lnp], axis=0)
+        self.iteration += int(nsteps)
+        self._state = eng.ensemble_state()
+        return self._state
+
+    # -- emcee-style views (ensemble 0 unless ``ensemble`` is given) --------------------
+    def _get(self, arr, flat, thin, discard, ensemble):
+        v = arr[discard + thin - 1::thin, ensemble]
+        return v.reshape((-1,) + v.shape[2:]) if flat else v
+
+    def get_chain(self, flat=False, thin=1, discard=0, ensemble=0):
+        return self._get(self._chain, flat, thin, discard, ensemble)
+
+    def get_log_prob(self, flat=False, thin=1, discard=0, ensemble=0):
+        return self._get(self._log_prob, flat, thin, discard, ensemble)
+
+    def get_autocorr_time(self, discard=0, thin=1, ensemble=0, **kwargs):
+        return thin * integrated_time(self.get_chain(discard=discard, thin=thin, ensemble=ensemble), **kwargs)
+
+    @property
+    def acceptance_fraction(self):
+        return self._state["naccept"] / float(max(self.iteration, 1))
+
+    @property
+    def state(self):
+        """dict(coords, log_prob, best_log_prob, best_coords, naccept, iteration, n_not_pd)."""
+        return self._state

@@ -25,6 +25,7 @@ from .gp import GP, LinAlgError
 from .lightcurves import GappyLightcurve
 from .modeling import ConstantModel
 from .models import GaussianModel, LinearModel
+from .device_sampler import DeviceEnsembleSampler
 from .sampler import EnsembleSampler
 
 __all__ = ["GPModelling"]
@@ -126,11 +127,17 @@ class GPModelling:
         h[shrink & (room_up >= room_dn)] = room_up[shrink & (room_up >= room_dn)]
         h[shrink & (room_up < room_dn)] = -room_dn[shrink & (room_up < room_dn)]
         pts = np.vstack([x[None, :], x[None, :] + np.diag(h)])
-        vals = self._neg_log_like(pts)
+        # Inside the optimiser a numerically singular corner of the box (e.g. log_S0 at its
+        # upper bound) is a very bad point, not a fatal one: celerite's LinAlgError would
+        # abort the reference's fit there; here the line search simply backs off.
+        out, status = self.gp.log_probability_batch(pts, self._y, add_prior=False)
+        vals = np.where(status == _engine.ST_OK, -out, np.inf)
         f0 = float(vals[0])
+        if not np.isfinite(f0):
+            return 1e300, np.zeros_like(x)
         dx = pts[1:].diagonal() - x
         with np.errstate(divide="ignore", invalid="ignore"):
-            grad = np.where(dx != 0.0, (vals[1:] - f0) / dx, 0.0)
+            grad = np.where((dx != 0.0) & np.isfinite(vals[1:]), (vals[1:] - f0) / dx, 0.0)
         return f0, grad
 
     def fit(self, initial_params=None):
@@ -147,10 +154,14 @@ class GPModelling:
 
     def derive_posteriors(self, initial_chain_params=None, fit: bool = True, converge: bool = True,
                           max_steps: int = 10000, convergence_steps: int = 500, walkers: int = 12,
-                          cores: int = 6, progress: bool = True):
+                          cores: int = 6, progress: bool = True, device_sampler: bool = False):
         """Derive GP posteriors (gpmodelling.py:197-286): optional fit, walker
         spreading, stretch-move MCMC with an autocorrelation-time convergence check
-        every ``convergence_steps`` iterations, then burn-in and thinning."""
+        every ``convergence_steps`` iterations, then burn-in and thinning.
+
+        ``device_sampler`` (new, optional): keep walkers, random numbers and the
+        accept/reject step on the GPU (``mtg_ensemble_*``); the host only sees the chain
+        every ``convergence_steps`` iterations.  Needs an even number of walkers."""
         if initial_chain_params is None:
             if not fit:
                 initial_params = self.initial_params
@@ -162,9 +173,25 @@ class GPModelling:
         every_samples = convergence_steps
         old_tau = np.inf
         self.converged = False
-        sampler = EnsembleSampler(walkers, self._ndim, self._log_probability, vectorize=True)
         tau = None
-        for sample in sampler.sample(initial_chain_params, iterations=max_steps, progress=progress):
+        if device_sampler:
+            sampler = self._device_sampler(walkers)
+            first, done = initial_chain_params, 0
+
+            def iterations():
+                nonlocal first, done
+                while done < max_steps:
+                    chunk = min(every_samples - done % every_samples, max_steps - done)
+                    sampler.run_mcmc(first, chunk)
+                    if not self._quiet and sampler.state["n_not_pd"]:
+                        raise LinAlgError("failed to factorize or solve matrix")
+                    first, done = None, done + chunk
+                    yield done
+            steps_iter = iterations()
+        else:
+            sampler = EnsembleSampler(walkers, self._ndim, self._log_probability, vectorize=True)
+            steps_iter = sampler.sample(initial_chain_params, iterations=max_steps, progress=progress)
+        for sample in steps_iter:
             if sampler.iteration % every_samples:
                 continue
             # tol=0: always get an estimate, even an untrustworthy one
@@ -195,6 +222,14 @@ class GPModelling:
         self._loglikelihoods = sampler.get_log_prob(discard=discard, thin=thin, flat=True)
         self._mcmc_samples = sampler.get_chain(discard=discard, thin=thin, flat=True)
         self._sampler = sampler
+
+    def _device_sampler(self, walkers):
+        """One device-resident ensemble on this light curve (see device_sampler.py)."""
+        ev = self.gp._ensure_evaluator(self._y)
+        model = self.gp._device_model()
+        if not model.device_terms or model.mean_kind is None:
+            raise ValueError("the device sampler needs device-expandable terms and a constant or linear mean")
+        return DeviceEnsembleSampler(lambda: ev._bind(model), walkers, self._ndim, n_ensembles=1)
 
     def spread_walkers(self, walkers: int, parameters, bounds: List[Tuple[float, float]],
                        percent: float = 0.1, max_attempts: int = 20):

@@ -265,16 +265,44 @@ def _spread(rng, centers, lower, upper, walkers, percent=0.1, max_attempts=20):
     return p0
 
 
+class _DeviceBatch:
+    """Adapter giving DeviceEnsembleSampler the read surface BatchPosteriors uses."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.L, self.W, self.ndim = dev.E, dev.nwalkers, dev.ndim
+        self.store_chain = dev.store_chain
+        self.iteration = dev.iteration
+        self.best_lnp = dev.state["best_log_prob"]
+        self.best_coords = dev.state["best_coords"]
+        self.n_accepted = dev.state["naccept"]
+
+    def get_chain(self, lc=None):
+        return self.dev._chain if lc is None else self.dev._chain[:, lc]
+
+    def get_log_prob(self, lc=None):
+        return self.dev._log_prob if lc is None else self.dev._log_prob[:, lc]
+
+    def get_autocorr_time(self, tol=0):
+        return np.array([integrated_time(self.dev._chain[:, l], tol=tol, quiet=True) for l in range(self.L)])
+
+    @property
+    def acceptance_fraction(self):
+        return self.n_accepted / float(max(self.iteration, 1))
+
+
 def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit=True, seed=None,
                             device=0, store_chain=True, initial_params=None, quiet=False,
-                            evaluate=None):
+                            evaluate=None, device_sampler=True):
     """GPModelling(lc, kernel).derive_posteriors(...) for L light curves at once.
 
     times [N] (shared sampling, gpmodelling.py:538); Y, DY [L, N]; ``kernel`` a
     mind_the_gaps_amd Term (its current parameter vector is the common starting point,
     as in the tutorial loop).  The mean of every light curve is frozen at its own average
     (the reference default, gpmodelling.py:83-87).  ``evaluate`` overrides the engine call
-    ``(theta[B, P], lc[B], add_prior) -> (lnP, status)`` (used by the multi-GPU driver).
+    ``(theta[B, P], lc[B], add_prior) -> (lnP, status)`` (used by the multi-GPU driver);
+    ``device_sampler`` keeps the L ensembles on the GPU between iterations
+    (``mtg_ensemble_*``) instead of proposing and accepting on the host.
     """
     Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
     DY = np.atleast_2d(np.asarray(DY, dtype=np.float64))
@@ -283,6 +311,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     if not model.device_terms:
         raise ValueError("the lock-step driver needs device-expandable terms")
     model.y_offset = None                         # offsets are per light curve, owned by the evaluator
+    ev = None
     if evaluate is None:
         ev = LogProbEvaluator(times, Y, DY + 1e-12, device=device, y_offset=Y.mean(axis=1))
 
@@ -305,9 +334,18 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
         centers, fit_f = fit_x, -fit_f
     rng = np.random.default_rng(seed)
     p0 = _spread(rng, centers, lower, upper, walkers)
-    sampler = EnsembleBatchSampler(L, walkers, P, lambda x, lc: checked(x, lc, True), seed=rng,
-                                   store_chain=store_chain)
-    sampler.run(p0, max_steps)
+    if device_sampler and ev is not None:
+        from .device_sampler import DeviceEnsembleSampler
+        dev = DeviceEnsembleSampler(lambda: ev._bind(model), walkers, P, n_ensembles=L,
+                                    seed=int(rng.integers(0, 2 ** 62)), store_chain=store_chain)
+        dev.run_mcmc(p0, max_steps)
+        if not quiet and dev.state["n_not_pd"]:
+            raise LinAlgError("failed to factorize or solve matrix")
+        sampler = _DeviceBatch(dev)
+    else:
+        sampler = EnsembleBatchSampler(L, walkers, P, lambda x, lc: checked(x, lc, True), seed=rng,
+                                       store_chain=store_chain)
+        sampler.run(p0, max_steps)
     if store_chain:
         tau = sampler.get_autocorr_time(tol=0)
         mean_tau = np.mean(tau, axis=1)

@@ -169,3 +169,40 @@ def test_config1_drw_n1000_32_walkers():
     ref = oracle_lnp(t, y, dy, [synth.K_DRW], best, np.mean(y), synth.bounds_for([synth.K_DRW]))[0]
     assert abs(g.max_loglikelihood - ref) / abs(ref) < 1e-8
     assert g.max_loglikelihood >= -g.fit().fun - 0.5      # the chain stays at the mode found by the fit
+
+
+def test_derive_posteriors_with_device_sampler():
+    """Same workflow with walkers, random numbers and accept/reject resident on the GPU."""
+    N = 300
+    t, y, dy = synth.make_lightcurves(N, 1, seed=21)
+    y, dy = y[0], dy[0]
+    th = synth.truth([synth.K_DRW])
+    g = GPModelling(GappyLightcurve(t, y, dy), DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]))
+    np.random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g.derive_posteriors(fit=True, max_steps=250, convergence_steps=100, walkers=12, progress=False,
+                            device_sampler=True)
+    assert g.sampler.iteration == 250 and len(g.autocorr) == 2
+    chain, lnp = g.sampler.get_chain(), g.sampler.get_log_prob()
+    assert chain.shape == (250, 12, 2) and lnp.shape == (250, 12)
+    # every stored log-probability is the oracle's value of the stored sample
+    ref = oracle_lnp(t, y, dy, [synth.K_DRW], chain[-1], np.mean(y), synth.bounds_for([synth.K_DRW]))
+    assert np.max(np.abs(lnp[-1] - ref) / np.abs(ref)) < 1e-9
+    assert g.max_loglikelihood == np.max(g.loglikelihoods) and g.get_rstat().shape == (12, 2)
+    assert 0.2 < g.sampler.acceptance_fraction.mean() < 0.95
+    # reproducible from numpy's global seed, like the host sampler
+    g2 = GPModelling(GappyLightcurve(t, y, dy), DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]))
+    np.random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g2.derive_posteriors(fit=True, max_steps=250, convergence_steps=100, walkers=12, progress=False,
+                             device_sampler=True)
+    assert np.array_equal(g2.sampler.get_chain(), chain)
+    # host and device samplers agree on the posterior (not on the trajectory)
+    np.random.seed(6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g2.derive_posteriors(fit=True, max_steps=250, convergence_steps=100, walkers=12, progress=False)
+    a, b = chain[100:].reshape(-1, 2), g2.sampler.get_chain()[100:].reshape(-1, 2)
+    assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 3 * (a.std(axis=0) + b.std(axis=0)) / np.sqrt(40))
