@@ -112,3 +112,32 @@ def test_per_lightcurve_times(engine):
         sel = lc == l
         ref[sel] = oracle_c.logprob_batch(t[l], y[l], dy[l], kinds, theta[sel], mean_kind=1)[0]
     assert np.all(st == 0) and rel(out, ref).max() <= RTOL
+
+
+@pytest.mark.parametrize("kinds", [[synth.K_DRW, synth.K_SHO, synth.K_LORENTZIAN], [synth.K_SHO] * 4])
+def test_mixed_sho_signatures_in_one_batch(engine, kinds):
+    """SHOTerm is one complex term for Q >= 1/2 and two real terms below: a batch whose
+    walkers straddle Q = 1/2 is split by signature on the device and every row still
+    matches the oracle."""
+    N, L, B = 600, 2, 200
+    t, y, dy = synth.make_lightcurves(N, L, seed=55)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    y_mean = y.mean(axis=1)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds)
+    rng = np.random.default_rng(8)
+    theta = synth.draw_thetas(kinds, B, seed=6)
+    off = 0
+    n_over = np.zeros(B, dtype=int)
+    for k in kinds:
+        if k == synth.K_SHO:
+            theta[:, off + 1] = np.log(0.5) + rng.uniform(-1.0, 1.0, B)      # Q in (0.18, 1.36)
+            n_over += theta[:, off + 1] < np.log(0.5)
+        off += synth.NPARAMS[k]
+    assert len(np.unique(n_over)) >= 2                                     # several signatures present
+    lc = (np.arange(B) % L).astype(np.int32)
+    out, st = engine.loglike(theta, lc, add_prior=True)
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, y_mean[lc][:, None]]),
+                                      bounds=bounds, lc_index=lc, add_prior=True, nthreads=8)
+    assert np.array_equal(st, rst) and np.all(st == 0)
+    assert rel(out, ref).max() <= RTOL
