@@ -192,6 +192,19 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
 
 /*
+ * celerite.GP.predict(y, return_var=True) at the training times, as
+ * GPModelling.standarized_residuals calls it (gpmodelling.py:366): conditional mean
+ * mu[b][n] (WITHOUT the per-light-curve y_offset, which the caller adds back) and
+ * variance var[b][n] (without jitter; the caller adds kernel.jitter when
+ * include_noise) for B parameter vectors, in O(N J^2) per vector through the
+ * factorisation instead of celerite's dense N x N cross-covariance.  Rows outside
+ * the prior or with a non positive-definite covariance get their status and no
+ * output.
+ */
+MTG_API int mtg_predict(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index, double *mu,
+                        double *var, int32_t *status);
+
+/*
  * Accuracy probe of the device elementary functions the recurrence uses
  * (tests only): exp_neg[i] = exp(-x[i]), sin/cos(x[i]), rcp_x[i] = 1 / x[i] for
  * n host values x >= 0.

@@ -166,6 +166,7 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     pa.counts = ctx->counts.as<int>();
     pa.out = d_out;
     pa.status = d_status;
+    pa.sig = nullptr;
     mtg_launch_prepare(pa, s);
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
 
@@ -681,6 +682,66 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     if (n_notpd) HIP_TRY(ctx, hipMemcpyAsync(n_notpd, ctx->ens_notpd.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (iteration) *iteration = ctx->ens_iteration;
+    return MTG_OK;
+}
+
+MTG_API int mtg_predict(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index, double *mu,
+                        double *var, int32_t *status)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (B <= 0 || !mu || !var || !status || (!theta && ctx->model.P > 0))
+        return fail(ctx, MTG_E_ARG, "mtg_predict: bad arguments");
+    if (lc_index)
+        for (int64_t b = 0; b < B; ++b)
+            if (lc_index[b] < 0 || lc_index[b] >= ctx->L)
+                return fail(ctx, MTG_E_ARG, "lc_index[%lld] = %d outside [0, %lld)", (long long)b, lc_index[b],
+                            (long long)ctx->L);
+    rc = use_device(ctx);
+    if (rc) return rc;
+    const MtgModel &m = ctx->model;
+    const int P = m.P, J = m.nr_max + 2 * m.nc_max, N = (int)ctx->N;
+    MtgCoefLayout lay{m.nr_max, m.nc_max};
+    rc = reserve_workspace(ctx, B, lay.nslots(), 1);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    DevBuf work, d_mu, d_var, d_sig;
+    HIP_TRY(ctx, ctx->theta.reserve((size_t)B * (P > 0 ? P : 1) * 8));
+    HIP_TRY(ctx, ctx->out.reserve((size_t)B * 8));
+    HIP_TRY(ctx, ctx->status.reserve((size_t)B * 4));
+    hipError_t e = work.reserve((size_t)B * N * (3 * J + 2) * 8);
+    if (e == hipSuccess) e = d_mu.reserve((size_t)B * N * 8);
+    if (e == hipSuccess) e = d_var.reserve((size_t)B * N * 8);
+    if (e == hipSuccess) e = d_sig.reserve((size_t)B * 4);
+    const int32_t *d_lc = nullptr;
+    if (e == hipSuccess && P > 0) e = hipMemcpyAsync(ctx->theta.p, theta, (size_t)B * P * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && lc_index) {
+        e = ctx->lc.reserve((size_t)B * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->lc.p, lc_index, (size_t)B * 4, hipMemcpyHostToDevice, s);
+        d_lc = ctx->lc.as<int32_t>();
+    }
+    if (e == hipSuccess) {
+        MtgPrepArgs pa;
+        pa.model = m; pa.theta = ctx->theta.as<double>(); pa.B = B; pa.add_prior = 1;
+        pa.coef = ctx->coef.as<double>(); pa.cstride = ctx->cstride; pa.nsig = 1;
+        pa.lists = ctx->lists.as<int>(); pa.counts = ctx->counts.as<int>();
+        pa.out = ctx->out.as<double>(); pa.status = ctx->status.as<int32_t>(); pa.sig = d_sig.as<int32_t>();
+        mtg_launch_prepare(pa, s);
+        MtgPredictArgs qa;
+        qa.coef = ctx->coef.as<double>(); qa.cstride = ctx->cstride; qa.lay = lay;
+        qa.nr0 = m.nr0; qa.nc0 = m.nc0; qa.sig = d_sig.as<int32_t>(); qa.B = B; qa.lc_index = d_lc;
+        qa.status_in = ctx->status.as<int32_t>(); qa.dxt = ctx->dxt.as<double2>(); qa.yv = ctx->yv.as<double2>();
+        qa.N = ctx->N; qa.t_stride = ctx->t_per_lc ? ctx->N : 0; qa.work = work.as<double>();
+        qa.mu = d_mu.as<double>(); qa.var = d_var.as<double>(); qa.status = ctx->status.as<int32_t>();
+        mtg_launch_predict(&qa, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(mu, d_mu.p, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(var, d_var.p, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(status, ctx->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    work.release(); d_mu.release(); d_var.release(); d_sig.release();
+    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_predict: %s", hipGetErrorString(e));
     return MTG_OK;
 }
 

@@ -55,6 +55,7 @@ struct MtgPrepArgs {
     int *counts;    // [nsig]
     double *out;    // [B]
     int32_t *status;  // [B]
+    int32_t *sig;   // [B] number of over-damped SHO terms per evaluation, or NULL
 };
 
 struct MtgSolveArgs {
@@ -78,6 +79,22 @@ struct MtgSolveArgs {
     int has_mean;  // 0: the mean is identically zero for every evaluation of this launch
 };
 
+struct MtgPredictArgs {
+    const double *coef;     // SoA coefficient workspace (mtg_prepare_kernel)
+    int64_t cstride;
+    MtgCoefLayout lay;
+    int nr0, nc0;           // structure with no over-damped SHO term
+    const int32_t *sig;     // [B] over-damped SHO terms of each evaluation
+    int64_t B;
+    const int32_t *lc_index;
+    const int32_t *status_in;   // prior verdict from prepare
+    const double2 *dxt, *yv;
+    int64_t N, t_stride;
+    double *work;           // [B][N][3 J + 2]: U, W, phi (per slot), D, z
+    double *mu, *var;       // [B][N]
+    int32_t *status;        // [B]
+};
+
 typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStream_t);
 // Table lookup of the compiled <NR, NC> instantiations (mtg_kernels.hip).
 mtg_solve_launcher mtg_find_solver(int nr, int nc);
@@ -95,5 +112,6 @@ void mtg_launch_accept(int E, int W, int P, int half, uint32_t iteration, uint64
                        int32_t *n_notpd, hipStream_t);
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
                              double *best_coords, hipStream_t);
+void mtg_launch_predict(const void *predict_args, hipStream_t);
 void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,
                            hipStream_t);

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256) mtg_prepare_kernel(MtgPrepArgs a)
         c[lay.mean(1) * cs] = m.mean_kind == MTG_MEAN_LINEAR ? par(m.nk + 1) : par(m.nk);
     }
 
+    if (a.sig && live) a.sig[e] = nover;
     if (a.nsig > 1) {
         // wave-aggregated append of the evaluation index to its signature list
         const int lane = threadIdx.x & 63;

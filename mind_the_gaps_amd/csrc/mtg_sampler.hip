@@ -190,3 +190,135 @@ void mtg_launch_initial_best(int E, int W, int P, const double *coords, const do
     hipLaunchKernelGGL(mtg_initial_best_kernel, dim3((E + 255) / 256), dim3(256), 0, s, E, W, P, coords, lnp,
                        best_lnp, best_coords);
 }
+
+// ---------------------------------------------------------------------------
+// Conditional mean / variance at the training times
+// ---------------------------------------------------------------------------
+// celerite.GP.predict(y, return_var=True) as GPModelling.standarized_residuals uses it
+// (gpmodelling.py:353-370).  celerite forms the dense N x N cross-covariance for the
+// variance; here both come from the semiseparable factorisation in O(N J^2):
+//   alpha = K^-1 r              forward + backward solve
+//   mu_n  = mean_n + r_n - d_n alpha_n,                d_n = sigma_n^2 + jitter
+//   var_n = d_n - d_n^2 (K^-1)_nn
+//   (K^-1)_nn = 1/D_n + W_n^T Phi_{n+1} G_{n+1} Phi_{n+1} W_n,
+//   G_m = U_m U_m^T / D_m + (I - U_m W_m^T) Phi_{m+1} G_{m+1} Phi_{m+1} (I - W_m U_m^T)
+// This is a diagnostic evaluated for one or a few parameter vectors, so it is a plain
+// generic-J kernel (one thread per evaluation, per-step generators kept in a global
+// workspace), not a tuned template family.
+#define MTG_PJ MTG_MAX_J
+
+
+__global__ void __launch_bounds__(64) mtg_predict_kernel(MtgPredictArgs a)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.B) return;
+    if (a.status_in[e] != MTG_ST_OK) { a.status[e] = a.status_in[e]; return; }
+    const int NR = a.nr0 + 2 * a.sig[e], NC = a.nc0 - a.sig[e], J = NR + 2 * NC;
+    const double *cf = a.coef + e;
+    const int64_t cs = a.cstride;
+    double ar[MTG_PJ], cr[MTG_PJ], ac[MTG_PJ / 2], bc[MTG_PJ / 2], cc[MTG_PJ / 2], dc[MTG_PJ / 2];
+    for (int j = 0; j < NR; ++j) { ar[j] = cf[a.lay.ar(j) * cs]; cr[j] = cf[a.lay.cr(j) * cs]; }
+    for (int k = 0; k < NC; ++k) {
+        ac[k] = cf[a.lay.ac(k) * cs]; bc[k] = cf[a.lay.bc(k) * cs];
+        cc[k] = cf[a.lay.cc(k) * cs]; dc[k] = cf[a.lay.dc(k) * cs];
+    }
+    const double asum = cf[a.lay.asum() * cs], slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
+    double ksum = 0.0;  // k(0) = sum of amplitudes
+    for (int j = 0; j < NR; ++j) ksum += ar[j];
+    for (int k = 0; k < NC; ++k) ksum += ac[k];
+    const double jitter = asum - ksum;
+    const int64_t lc = a.lc_index ? a.lc_index[e] : 0;
+    const int64_t N = a.N;
+    const double2 *yv = a.yv + lc * N, *dxt = a.dxt + lc * a.t_stride;
+    const int stride = 3 * J + 2;
+    double *wk = a.work + e * N * stride;
+
+    // ---- forward sweep: factorisation + z = L^-1 r, generators stored -------------
+    double S[MTG_PJ][MTG_PJ], f[MTG_PJ], Wp[MTG_PJ], U[MTG_PJ], V[MTG_PJ], ph[MTG_PJ];
+    double cs_[MTG_PJ / 2], sn_[MTG_PJ / 2];
+    for (int i = 0; i < J; ++i) { f[i] = 0.0; Wp[i] = 0.0; for (int j = 0; j < J; ++j) S[i][j] = 0.0; }
+    for (int k = 0; k < NC; ++k) { cs_[k] = 1.0; sn_[k] = 0.0; }
+    double Dp = 1.0, zp = 0.0;
+    bool bad = false;
+    for (int64_t n = 0; n < N; ++n) {
+        const double dx = dxt[n].x, t = dxt[n].y;
+        for (int j = 0; j < NR; ++j) { ph[j] = exp(-cr[j] * dx); U[j] = ar[j]; V[j] = 1.0; }
+        for (int k = 0; k < NC; ++k) {
+            const double p = exp(-cc[k] * dx);
+            double sd, cd;
+            sincos(dc[k] * dx, &sd, &cd);
+            const double cn = cs_[k] * cd - sn_[k] * sd, sn = sn_[k] * cd + cs_[k] * sd;
+            cs_[k] = cn; sn_[k] = sn;
+            ph[NR + 2 * k] = ph[NR + 2 * k + 1] = p;
+            U[NR + 2 * k] = ac[k] * cn + bc[k] * sn; U[NR + 2 * k + 1] = ac[k] * sn - bc[k] * cn;
+            V[NR + 2 * k] = cn; V[NR + 2 * k + 1] = sn;
+        }
+        for (int i = 0; i < J; ++i) {
+            for (int j = 0; j < J; ++j) S[i][j] = ph[i] * ph[j] * (S[i][j] + Dp * Wp[i] * Wp[j]);
+            f[i] = ph[i] * (f[i] + Wp[i] * zp);
+        }
+        double D = yv[n].y + asum, z = yv[n].x - (slope * t + icpt);
+        double Wn[MTG_PJ];
+        for (int i = 0; i < J; ++i) {
+            double q = 0.0;
+            for (int j = 0; j < J; ++j) q += S[i][j] * U[j];
+            Wn[i] = V[i] - q;
+            D -= U[i] * q;
+            z -= U[i] * f[i];
+        }
+        bad = bad || !(D > 0.0);
+        double *w = wk + n * stride;
+        for (int i = 0; i < J; ++i) { Wn[i] /= D; w[i] = U[i]; w[J + i] = Wn[i]; w[2 * J + i] = ph[i]; Wp[i] = Wn[i]; }
+        w[3 * J] = D; w[3 * J + 1] = z;
+        Dp = D; zp = z;
+    }
+    if (bad) { a.status[e] = MTG_ST_NOTPD; return; }
+
+    // ---- backward sweep: alpha = L^-T D^-1 z and diag(K^-1) -------------------------
+    double g[MTG_PJ], G[MTG_PJ][MTG_PJ];
+    for (int i = 0; i < J; ++i) { g[i] = 0.0; for (int j = 0; j < J; ++j) G[i][j] = 0.0; }
+    double Un[MTG_PJ], phn[MTG_PJ];  // generators of sample n + 1
+    double xn = 0.0;
+    for (int i = 0; i < J; ++i) { Un[i] = 0.0; phn[i] = 0.0; }
+    for (int64_t n = N - 1; n >= 0; --n) {
+        const double *w = wk + n * stride;
+        const double D = w[3 * J], z = w[3 * J + 1];
+        // g_n = Phi_{n+1} (g_{n+1} + U_{n+1} x_{n+1});  x_n = z_n / D_n - W_n^T g_n
+        double x = z / D;
+        for (int i = 0; i < J; ++i) { g[i] = phn[i] * (g[i] + Un[i] * xn); x -= w[J + i] * g[i]; }
+        // (K^-1)_nn = 1/D_n + (Phi_{n+1} W_n)^T G_{n+1} (Phi_{n+1} W_n)
+        double pw[MTG_PJ], kinv = 1.0 / D;
+        for (int i = 0; i < J; ++i) pw[i] = phn[i] * w[J + i];
+        for (int i = 0; i < J; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < J; ++j) s += G[i][j] * pw[j];
+            kinv += pw[i] * s;
+        }
+        const double d = yv[n].y + jitter;
+        const double r = yv[n].x - (slope * dxt[n].y + icpt);
+        a.mu[e * N + n] = (slope * dxt[n].y + icpt) + r - d * x;
+        a.var[e * N + n] = d - d * d * kinv;
+        // G_n = U_n U_n^T / D_n + (I - U_n W_n^T) X (I - W_n U_n^T),  X = Phi_{n+1} G_{n+1} Phi_{n+1}
+        double X[MTG_PJ][MTG_PJ], XW[MTG_PJ], wxw = 0.0;
+        for (int i = 0; i < J; ++i)
+            for (int j = 0; j < J; ++j) X[i][j] = phn[i] * phn[j] * G[i][j];
+        for (int i = 0; i < J; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < J; ++j) s += X[i][j] * w[J + j];
+            XW[i] = s;
+        }
+        for (int i = 0; i < J; ++i) wxw += w[J + i] * XW[i];
+        for (int i = 0; i < J; ++i)
+            for (int j = 0; j < J; ++j)
+                G[i][j] = X[i][j] - w[i] * XW[j] - XW[i] * w[j] + w[i] * w[j] * (wxw + 1.0 / D);
+        for (int i = 0; i < J; ++i) { Un[i] = w[i]; phn[i] = w[2 * J + i]; }
+        xn = x;
+    }
+    a.status[e] = MTG_ST_OK;
+}
+
+void mtg_launch_predict(const void *args_void, hipStream_t s)
+{
+    const MtgPredictArgs &a = *static_cast<const MtgPredictArgs *>(args_void);
+    hipLaunchKernelGGL(mtg_predict_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, s, a);
+}

@@ -27,6 +27,7 @@ EXPORTS = (
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
+    "mtg_predict",
 )
 
 
@@ -96,6 +97,8 @@ def load_library():
     lib.mtg_ensemble_run.argtypes = [c_vp, c_int, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
+    lib.mtg_predict.restype = c_int
+    lib.mtg_predict.argtypes = [c_vp, c_i64, _dp, _ip, _dp, _dp, _ip]
     lib.mtg_math_probe.restype = c_int
     lib.mtg_math_probe.argtypes = [c_vp, c_i64, _dp, _dp, _dp, _dp, _dp]
     lib.mtg_structure_supported.restype = c_int
@@ -295,6 +298,18 @@ class Engine:
         out["iteration"] = int(it.value)
         out["n_not_pd"] = int(bad[0])
         return out
+
+    def predict(self, theta, lc_index=None):
+        """Conditional mean / variance at the training times -> (mu[B][N], var[B][N], status[B]);
+        mu excludes the per-light-curve y_offset, var excludes the jitter."""
+        theta = np.atleast_2d(_f64(theta))
+        B = theta.shape[0]
+        lc = None if lc_index is None else np.ascontiguousarray(lc_index, dtype=np.int32)
+        mu, var = np.full((B, self.N), np.nan), np.full((B, self.N), np.nan)
+        status = np.empty(B, dtype=np.int32)
+        self._check(self._lib.mtg_predict(self._ctx, B, _ptr(theta), _iptr(lc), _ptr(mu), _ptr(var),
+                                          _iptr(status)))
+        return mu, var, status
 
     def math_probe(self, x):
         """Device exp(-x), sin(x), cos(x), 1/x of the kernel's own math (accuracy tests)."""

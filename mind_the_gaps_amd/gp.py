@@ -279,7 +279,25 @@ class GP(ModelSet):
             out[keep], status[keep] = o, s
         return out, status
 
-    def predict(self, *args, **kwargs):
-        raise NotImplementedError(
-            "GP.predict (conditional mean/variance) is outside the log-likelihood hot path "
-            "(SURVEY.md section 8(f), row f3)")
+    def predict(self, y, t=None, return_cov=True, return_var=False):
+        """Conditional mean (and variance) at the training times, celerite.GP.predict as
+        the reference calls it (gpmodelling.py:366: ``return_var=True, return_cov=False``).
+        The variance comes from the O(N J^2) factorisation on the device, not from
+        celerite's dense N x N cross-covariance.  Predicting at other times ``t`` or
+        returning the full covariance is not part of the hot path."""
+        if t is not None:
+            raise NotImplementedError("prediction at new times is outside the log-likelihood hot path")
+        if return_cov and not return_var:
+            raise NotImplementedError("the dense predictive covariance is not computed; use return_var=True")
+        ev = self._ensure_evaluator(y)
+        model = self._device_model()
+        if not model.device_terms or model.mean_kind is None:
+            raise NotImplementedError("predict needs device-expandable terms and a constant or linear mean")
+        eng = ev._bind(model)
+        mu, var, status = eng.predict(model.full[model.free_index][None, :])
+        if status[0] == _engine.ST_NOTPD:
+            raise LinAlgError("failed to factorize or solve matrix")
+        if status[0] == _engine.ST_PRIOR:
+            raise ValueError("the current parameter vector has zero prior probability")
+        mu = mu[0] + (model.y_offset or 0.0)
+        return (mu, var[0]) if return_var else mu

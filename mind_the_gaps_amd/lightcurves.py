@@ -2,9 +2,9 @@
 
 Mirror of the part of /root/reference/mind_the_gaps/lightcurves/gappylightcurve.py
 that ``GPModelling`` reads (constructor :24-70 and the properties :72-171):
-``times, y, dy, exposures, bkg_rate, bkg_rate_err, n, duration, mean``.  File
-readers, truncation/splitting and ``get_simulator`` are outside the hot path
-(SURVEY.md section 2, row 9).
+``times, y, dy, exposures, bkg_rate, bkg_rate_err, n, duration, mean``, plus the CSV
+round trip of :256-262.  Mission file readers,
+truncation/splitting and ``get_simulator`` are outside the hot path.
 """
 import numpy as np
 
@@ -71,3 +71,15 @@ class GappyLightcurve:
     @property
     def mean(self):
         return np.mean(self._y)
+
+    def to_csv(self, outname):
+        """Save the light curve (gappylightcurve.py:256-262: same columns and formats)."""
+        outputs = np.array([self._times, self._y, self._dy, self._exposures, self._bkg_rate, self._bkg_rate_err])
+        np.savetxt(outname, outputs.T, fmt="%.8e\t%.5f\t%.5f\t%.3f\t%.5f\t%.5f",
+                   header="t\trate\terror\texposure\tbkg_rate\tbkg_rate_err")
+
+    @classmethod
+    def from_csv(cls, filename):
+        """Read back what ``to_csv`` wrote."""
+        t, y, dy, exp, bkg, bkg_err = np.loadtxt(filename, unpack=True, ndmin=2)
+        return cls(t, y, dy, exposures=exp if np.any(exp) else None, bkg_rate=bkg, bkg_rate_err=bkg_err)

@@ -189,3 +189,19 @@ def log_prior(kinds, params_full, bounds):
             return -np.inf  # celerite ComplexTerm.log_prior
         off += NPARAMS[kind]
     return 0.0
+
+
+def dense_predict(t, y, dy, coeffs, mean_kind=0, mean_params=(0.0,)):
+    """celerite.GP.predict(y, return_var=True) at the training times by dense algebra:
+    mu = mean + K_s K^-1 r, var = k(0) - diag(K_s K^-1 K_s), K_s the kernel matrix without
+    the noise diagonal (what gpmodelling.py:366 obtains from celerite)."""
+    t = np.asarray(t, dtype=np.float64)
+    mean = mean_value(mean_kind, mean_params, t)
+    r = np.asarray(y, dtype=np.float64) - mean
+    Ks = kernel_value(coeffs, t[:, None] - t[None, :])
+    K = Ks.copy()
+    K[np.diag_indices_from(K)] += (np.asarray(dy, dtype=np.float64) + 1e-12) ** 2 + coeffs[6]
+    sol = np.linalg.solve(K, np.column_stack([r, Ks]))
+    mu = mean + Ks @ sol[:, 0]
+    var = kernel_value(coeffs, 0.0) - np.sum(Ks * sol[:, 1:], axis=0)
+    return mu, var

@@ -206,3 +206,37 @@ def test_derive_posteriors_with_device_sampler():
         g2.derive_posteriors(fit=True, max_steps=250, convergence_steps=100, walkers=12, progress=False)
     a, b = chain[100:].reshape(-1, 2), g2.sampler.get_chain()[100:].reshape(-1, 2)
     assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 3 * (a.std(axis=0) + b.std(axis=0)) / np.sqrt(40))
+
+
+def test_predict_and_standarized_residuals():
+    """GP.predict(return_var=True) / standarized_residuals (gpmodelling.py:353-370) against
+    dense algebra: conditional mean and variance at the training times."""
+    from oracle import dense
+    N = 500
+    t, y, dy = synth.make_lightcurves(N, 1, seed=17)
+    y, dy = y[0], dy[0]
+    kernel = alt_kernel() + terms.JitterTerm(np.log(0.8))
+    g = GPModelling(GappyLightcurve(t, y, dy), kernel)
+    theta = g.gp.get_parameter_vector()
+    kinds = synth.ALT_MODEL + [synth.K_JITTER]
+    co = dense.build_coeffs(kinds, theta)
+    mu_ref, var_ref = dense.dense_predict(t, y, dy, co, 0, [np.mean(y)])
+    mu, var = g.gp.predict(y, return_var=True, return_cov=False)
+    assert np.max(np.abs(mu - mu_ref)) < 1e-8 * np.max(np.abs(mu_ref))
+    assert np.max(np.abs(var - var_ref) / var_ref) < 1e-7
+    res = g.standarized_residuals(include_noise=True)
+    assert np.allclose(res, (y - mu_ref) / np.sqrt(var_ref + co[6]), rtol=1e-6, atol=1e-9)
+    assert np.array_equal(g.gp.predict(y, return_cov=False, return_var=False), mu)
+    # fitted linear mean and an over-damped SHO (two real terms)
+    k2 = DampedRandomWalk(np.log(50.0), np.log(0.2)) + terms.SHOTerm(np.log(20.0), np.log(0.2), np.log(0.5))
+    g2 = GPModelling(GappyLightcurve(t, y + 0.01 * t, dy), k2, mean_model="linear")
+    v = g2.gp.get_parameter_vector()
+    v[-2:] = [0.01, float(np.mean(y))]
+    g2.gp.set_parameter_vector(v)
+    mu2, var2 = g2.gp.predict(y + 0.01 * t, return_var=True, return_cov=False)
+    co2 = dense.build_coeffs([synth.K_DRW, synth.K_SHO], v[:5])
+    mu2_ref, var2_ref = dense.dense_predict(t, y + 0.01 * t, dy, co2, 1, v[-2:])
+    assert np.max(np.abs(mu2 - mu2_ref)) < 1e-8 * np.max(np.abs(mu2_ref))
+    assert np.max(np.abs(var2 - var2_ref) / var2_ref) < 1e-7
+    with pytest.raises(NotImplementedError):
+        g.gp.predict(y, t=np.array([1.0, 2.0]), return_var=True, return_cov=False)

@@ -1,0 +1,33 @@
+"""CPU tests of the post-processing helpers."""
+import numpy as np
+
+from mind_the_gaps_amd import stats
+from mind_the_gaps_amd.lightcurves import GappyLightcurve
+
+
+def test_information_criteria_match_reference_formulas():
+    # /root/reference/mind_the_gaps/stats.py:155-195
+    lnl, n, k = -1234.5, 400, 5
+    assert stats.bic(lnl, n, k) == -2.0 * lnl + k * np.log(n)
+    assert stats.aic(lnl, k) == 2 * k - 2 * lnl
+    assert stats.aicc(lnl, n, k) == stats.aic(lnl, k) + 2 * k * (k + 1) / (n - k - 1)
+
+
+def test_lrt_statistic_and_pvalue():
+    null, alt = np.array([-100.0, -90.0, -80.0]), np.array([-95.0, -90.0, -70.0])
+    assert np.array_equal(stats.lrt_statistic(null, alt), [10.0, 0.0, 20.0])     # tutorial_ppp.ipynb:406-411
+    sims = np.arange(99.0)
+    assert stats.lrt_pvalue(98.0, sims) == 2 / 100 and stats.lrt_pvalue(1e9, sims) == 1 / 100
+    assert stats.lrt_pvalue(-1.0, sims) == 1.0
+
+
+def test_lightcurve_csv_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    t = np.cumsum(rng.uniform(1, 2, 20))
+    lc = GappyLightcurve(t, rng.normal(10, 1, 20), rng.uniform(0.1, 0.2, 20), exposures=0.5)
+    f = tmp_path / "lc.csv"
+    lc.to_csv(str(f))
+    assert open(f).readline().startswith("# t\trate\terror\texposure")
+    back = GappyLightcurve.from_csv(str(f))
+    assert np.allclose(back.times, lc.times, rtol=1e-8) and np.allclose(back.y, lc.y, atol=1e-5)
+    assert np.allclose(back.dy, lc.dy, atol=1e-5) and np.allclose(back.exposures, 0.5)
