@@ -1,0 +1,113 @@
+"""GPU edge cases of the hot path: degenerate sampling, extreme parameters, the OCML
+(large-phase) sweep variant, empty batches, non-finite input."""
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import synthetic as synth
+from oracle import celerite as oracle_c
+from oracle import dense
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_vs_dense(engine, kinds, t, y, dy, thetas, mean, tol=1e-8):
+    full = np.concatenate([thetas[0], [mean]])
+    bounds = np.tile([-np.inf, np.inf], (len(full), 1))
+    engine.set_lightcurves(t, y, dy + 1e-12)
+    engine.set_model(kinds, full, np.arange(len(thetas[0]), dtype=np.int32), bounds)
+    out, st = engine.loglike(np.asarray(thetas), add_prior=False)
+    worst = 0.0
+    for th, o, s in zip(thetas, out, st):
+        want = dense.dense_loglike(t, y, dy, dense.build_coeffs(kinds, th), 0, [mean])
+        assert s == 0 and np.isfinite(want)
+        worst = max(worst, abs(o - want) / abs(want))
+    assert worst <= tol, worst
+    return worst
+
+
+def test_duplicate_timestamps_and_huge_gaps(engine):
+    """dx = 0 (phi = 1, repeated epochs) and gaps long enough for exp(-c dx) to underflow."""
+    rng = np.random.default_rng(1)
+    t = np.sort(np.concatenate([np.cumsum(rng.exponential(1.0, 120)), [3.0, 3.0, 40.0]]))
+    t[60:] += 5000.0                       # c dx ~ 1500 >> 745 for the DRW term
+    t[100:] += 1.0e6
+    y, dy = 10 + rng.standard_normal(len(t)), rng.uniform(0.5, 1.5, len(t))
+    kinds = synth.ALT_MODEL
+    thetas = synth.draw_thetas(kinds, 6, seed=2)
+    hip_vs_dense(engine, kinds, t, y, dy, thetas, float(np.mean(y)))
+
+
+def test_large_phase_increments_take_the_ocml_sweep(engine):
+    """d * max(dx) > 1e5 rad: the wave falls back to the OCML sincos sweep variant."""
+    rng = np.random.default_rng(2)
+    t = np.cumsum(rng.exponential(0.5, 150))
+    t[75:] += 40.0
+    y, dy = rng.standard_normal(150), rng.uniform(0.2, 0.5, 150)
+    kinds = [synth.K_COMPLEX3, synth.K_DRW]
+    base = np.array([np.log(2.0), np.log(0.3), np.log(9000.0), np.log(1.5), np.log(0.2)])   # d = 9000 rad/day
+    thetas = base + 0.01 * rng.standard_normal((5, 5))
+    # mixed wave: some lanes fast-eligible, some not -> the whole wave takes the OCML variant
+    thetas[3:, 2] = np.log(3.0)
+    hip_vs_dense(engine, kinds, t, y, dy, thetas, 0.0, tol=1e-8)
+
+
+def test_prior_box_corners_match_oracle(engine):
+    """Parameters at the edges of the tutorial box (-10, 50) / (-10, 10)."""
+    kinds = synth.NULL_MODEL
+    N = 300
+    t, y, dy = synth.make_lightcurves(N, 1, seed=4)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, free, bounds)
+    th = synth.truth(kinds)
+    corners = []
+    for i in range(len(th)):
+        for edge in bounds[i]:
+            c = th.copy(); c[i] = edge; corners.append(c)
+            c = th.copy(); c[i] = edge + np.sign(edge) * 1e-9; corners.append(c)     # just outside
+    corners = np.array(corners)
+    out, st = engine.loglike(corners, add_prior=True)
+    ref, rst = oracle_c.logprob_batch(t, y[0], dy[0], kinds, np.hstack([corners, np.full((len(corners), 1), y.mean())]),
+                                      bounds=bounds, add_prior=True)
+    assert np.array_equal(st == 1, rst == 1)                 # same prior verdicts (bounds are inclusive)
+    both = (st == 0) & (rst == 0)
+    assert both.sum() >= len(th)
+    assert np.max(np.abs(out[both] - ref[both]) / np.abs(ref[both])) < 1e-8
+    assert np.all(np.isneginf(out[st != 0]))
+
+
+def test_empty_batch_nan_theta_and_state_errors(engine):
+    from mind_the_gaps_amd.engine import Engine, EngineError
+    kinds = [synth.K_DRW]
+    t, y, dy = synth.make_lightcurves(50, 1, seed=5)
+    full, free, bounds = synth.model_spec(kinds, y)
+    engine.set_lightcurves(t, y, dy + 1e-12)
+    engine.set_model(kinds, full, free, bounds)
+    out, st = engine.loglike(np.empty((0, 2)))
+    assert out.shape == (0,) and st.shape == (0,)
+    th = np.array([[np.nan, 0.0], [1.0, np.nan], synth.truth(kinds)])
+    out, st = engine.loglike(th, add_prior=True)             # NaN fails every bound comparison
+    assert list(st) == [1, 1, 0] and np.isneginf(out[0]) and np.isfinite(out[2])
+    out, st = engine.loglike(th, add_prior=False)            # no prior: NaN propagates to a non-finite lnL
+    assert st[0] != 0 and st[1] != 0 and np.isneginf(out[0]) and st[2] == 0
+    with pytest.raises(ValueError):
+        engine.loglike(np.zeros((2, 3)))                     # wrong number of columns
+    with pytest.raises(ValueError):
+        engine.set_lightcurves(t[::-1].copy(), y, dy)        # unsorted times (celerite ValueError)
+    with pytest.raises(EngineError):
+        engine.loglike(th[2:], lc_index=np.array([3]))       # light curve out of range
+    fresh = Engine(0)
+    with pytest.raises(EngineError):
+        fresh.set_model(kinds, full, free, bounds) or fresh.loglike(th[2:])   # no light curves yet
+    fresh.close()
+    with pytest.raises(EngineError):                         # J = 12 > 10: no compiled kernel
+        engine.set_model([synth.K_SHO] * 6, np.zeros(19), np.arange(18, dtype=np.int32),
+                         np.tile([-np.inf, np.inf], (19, 1)))
+    engine.set_lightcurves(t, y, dy + 1e-12)
+
+
+def test_single_sample_and_two_samples(engine):
+    for N in (1, 2):
+        t, y, dy = synth.make_lightcurves(N, 1, seed=6 + N)
+        thetas = synth.draw_thetas(synth.ALT_MODEL, 4, seed=1)
+        hip_vs_dense(engine, synth.ALT_MODEL, t, y[0], dy[0], thetas, float(np.mean(y)))
