@@ -192,6 +192,30 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
 
 /*
+ * Posterior-predictive light-curve simulation, the step before the hot path in the
+ * Protassov loop: GPModelling.generate_from_posteriors (gpmodelling.py:478-539) ->
+ * Simulator.generate_lightcurve + add_noise (simulator.py:300-420, get_fft :468-501),
+ * Gaussian flux PDF (Timmer & Koenig 1995), for S posterior samples theta[S][P] of the
+ * context's model on the context's (shared) sampling of N epochs.
+ *   nfft, sim_dt   length and step of the fine regular grid (len(sim_timestamps), sim_dt)
+ *   seg_len        fine samples in the randomly cut segment (sim_duration / sim_dt)
+ *   win_lo/win_hi  [N] fine-sample ranges [lo, hi) of the segment averaged into every
+ *                  epoch (the `strategy` windows of simulator.py:266-267, 340-367)
+ *   noise_kind     0 none, 1 Gaussian(sigma_noise), 2 Poisson over exposures[N]
+ *   clean          [S][N] noise-free rates or NULL; rates, dy [S][N]: noisy rates and
+ *                  their 1-sigma errors (host buffers); lc_means [S] or NULL
+ *   make_resident  != 0: the simulated set becomes the context's light curves (frozen mean
+ *                  = each curve's average, yerr = dy + 1e-12), ready for
+ *                  mtg_loglike_batch / mtg_ensemble_* with no host round trip
+ * The PSD is celerite's Term.get_psd of the model; the inverse FFTs are one batched hipFFT
+ * plan; random numbers are Philox4x32-10 keyed by `seed`.
+ */
+MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint64_t seed, int64_t nfft,
+                              double sim_dt, double mean_rate, int64_t seg_len, const int32_t *win_lo,
+                              const int32_t *win_hi, int noise_kind, double sigma_noise, const double *exposures,
+                              double *clean, double *rates, double *dy, double *lc_means, int make_resident);
+
+/*
  * celerite.GP.predict(y, return_var=True) at the training times, as
  * GPModelling.standarized_residuals calls it (gpmodelling.py:366): conditional mean
  * mu[b][n] (WITHOUT the per-light-curve y_offset, which the caller adds back) and

@@ -2,6 +2,8 @@
 // One context = one MI355X + resident light curves + model + workspaces.
 #include "mtg_device.h"
 
+#include <hipfft/hipfft.h>
+
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -682,6 +684,123 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     if (n_notpd) HIP_TRY(ctx, hipMemcpyAsync(n_notpd, ctx->ens_notpd.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (iteration) *iteration = ctx->ens_iteration;
+    return MTG_OK;
+}
+
+MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint64_t seed, int64_t nfft,
+                              double sim_dt, double mean_rate, int64_t seg_len, const int32_t *win_lo,
+                              const int32_t *win_hi, int noise_kind, double sigma_noise, const double *exposures,
+                              double *clean, double *rates, double *dy, double *lc_means, int make_resident)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    const int64_t N = ctx->N;
+    if (S <= 0 || nfft < 4 || !(sim_dt > 0.0) || seg_len <= 0 || seg_len > nfft || !win_lo || !win_hi || !rates || !dy ||
+        (!theta && ctx->model.P > 0))
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad arguments");
+    if (noise_kind < 0 || noise_kind > 2 || (noise_kind == 2 && !exposures) || (noise_kind == 1 && !(sigma_noise >= 0.0)))
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad noise specification");
+    for (int64_t n = 0; n < N; ++n)
+        if (win_lo[n] < 0 || win_hi[n] < win_lo[n] || win_hi[n] > seg_len)
+            return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: window %lld = [%d, %d) outside the segment of %lld samples",
+                        (long long)n, win_lo[n], win_hi[n], (long long)seg_len);
+    if (make_resident && (ctx->t_per_lc || S * N >= ((int64_t)1 << 28)))
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: make_resident needs a shared sampling and S * N < 2^28");
+    rc = use_device(ctx);
+    if (rc) return rc;
+    const MtgModel &m = ctx->model;
+    const int P = m.P;
+    MtgCoefLayout lay{m.nr_max, m.nc_max};
+    rc = reserve_workspace(ctx, S, lay.nslots(), 1);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const int64_t nk = nfft / 2 + 1;
+    // chunk the simulations so that spectrum + series stay below ~2 GiB
+    int64_t chunk = (int64_t)(2.0e9 / (16.0 * (double)nfft));
+    if (chunk < 1) chunk = 1;
+    if (chunk > S) chunk = S;
+    DevBuf spec, series, d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means;
+    hipfftHandle plan = 0;
+    bool have_plan = false;
+    hipError_t e = hipSuccess;
+    const char *what = "allocation";
+    auto cleanup = [&]() {
+        if (have_plan) (void)hipfftDestroy(plan);
+        DevBuf *bufs[] = {&spec, &series, &d_lo, &d_hi, &d_expo, &d_clean, &d_rates, &d_dy, &d_sig, &d_means};
+        for (DevBuf *b : bufs) b->release();
+    };
+    HIP_TRY(ctx, ctx->theta.reserve((size_t)S * (P > 0 ? P : 1) * 8));
+    HIP_TRY(ctx, ctx->out.reserve((size_t)S * 8));
+    HIP_TRY(ctx, ctx->status.reserve((size_t)S * 4));
+    e = spec.reserve((size_t)chunk * nk * 16);
+    if (e == hipSuccess) e = series.reserve((size_t)chunk * nfft * 8);
+    if (e == hipSuccess) e = d_lo.reserve((size_t)N * 4);
+    if (e == hipSuccess) e = d_hi.reserve((size_t)N * 4);
+    if (e == hipSuccess) e = d_expo.reserve((size_t)N * 8);
+    if (e == hipSuccess && clean) e = d_clean.reserve((size_t)S * N * 8);
+    if (e == hipSuccess) e = d_rates.reserve((size_t)S * N * 8);
+    if (e == hipSuccess) e = d_dy.reserve((size_t)S * N * 8);
+    if (e == hipSuccess) e = d_sig.reserve((size_t)S * 4);
+    if (e == hipSuccess) e = d_means.reserve((size_t)S * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lo.p, win_lo, (size_t)N * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, win_hi, (size_t)N * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && exposures) e = hipMemcpyAsync(d_expo.p, exposures, (size_t)N * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && P > 0) e = hipMemcpyAsync(ctx->theta.p, theta, (size_t)S * P * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        // theta -> celerite coefficients (no prior: the samples come from the posterior itself)
+        MtgPrepArgs pa;
+        pa.model = m; pa.theta = ctx->theta.as<double>(); pa.B = S; pa.add_prior = 0;
+        pa.coef = ctx->coef.as<double>(); pa.cstride = ctx->cstride; pa.nsig = 1;
+        pa.lists = ctx->lists.as<int>(); pa.counts = ctx->counts.as<int>();
+        pa.out = ctx->out.as<double>(); pa.status = ctx->status.as<int32_t>(); pa.sig = d_sig.as<int32_t>();
+        mtg_launch_prepare(pa, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        what = "hipfftPlan1d";
+        if (hipfftPlan1d(&plan, (int)nfft, HIPFFT_Z2D, (int)chunk) != HIPFFT_SUCCESS || hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
+            cleanup();
+            return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipFFT plan creation failed (nfft = %lld, batch = %lld)",
+                        (long long)nfft, (long long)chunk);
+        }
+        have_plan = true;
+    }
+    // irfft normalisation (hipFFT C2R is unnormalised) and the reference's power scaling
+    const double scale = sqrt((double)nfft * sim_dt * sqrt(2.0 * M_PI)) / (double)nfft;
+    for (int64_t s0 = 0; e == hipSuccess && s0 < S; s0 += chunk) {
+        const int64_t sc = s0 + chunk <= S ? chunk : S - s0;
+        what = "simulation kernels";
+        mtg_launch_tk95_spectrum(sc, s0, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
+                                 d_sig.as<int32_t>(), seed, spec.as<double2>(), s);
+        if (hipfftExecZ2D(plan, (hipfftDoubleComplex *)spec.p, series.as<double>()) != HIPFFT_SUCCESS) {
+            cleanup();
+            return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");
+        }
+        mtg_launch_tk95_observe(sc, s0, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
+                                d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
+                                seed, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+        e = hipGetLastError();
+    }
+    DevBuf yv_tmp;
+    if (e == hipSuccess && (make_resident || lc_means)) {
+        what = "resident set";
+        DevBuf &target = make_resident ? ctx->yv : yv_tmp;  // without make_resident only the means are wanted
+        e = target.reserve((size_t)S * N * 16);
+        if (e == hipSuccess) {
+            mtg_launch_tk95_resident(S, N, d_rates.as<double>(), d_dy.as<double>(), target.as<double2>(),
+                                     d_means.as<double>(), s);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && lc_means) e = hipMemcpyAsync(lc_means, d_means.p, (size_t)S * 8, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess && clean) e = hipMemcpyAsync(clean, d_clean.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(rates, d_rates.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dy, d_dy.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    yv_tmp.release();
+    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95 (%s): %s", what, hipGetErrorString(e));
+    if (make_resident) ctx->L = S;  // the simulated light curves replace the resident set (same sampling)
     return MTG_OK;
 }
 

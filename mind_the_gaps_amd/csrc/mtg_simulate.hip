@@ -1,0 +1,226 @@
+// mtg_simulate.hip -- posterior-predictive light-curve simulation on the device
+// (SURVEY.md 8(f) row f2): the step BEFORE the hot path in the Protassov loop.
+//
+// Timmer & Koenig (1995) as the reference runs it
+// (/root/reference/mind_the_gaps/simulator.py:369-420,468-501 and
+// gpmodelling.py:478-539), for S posterior samples at once:
+//   X_k = (g1 + i g2) sqrt(PSD(w_k) / 2),  k = 1..nfft/2   (Nyquist term real)     get_fft
+//   counts = irfft(X) * sqrt(nfft dt sqrt(2 pi));  rate = counts / dt - <rate> + mean
+//   random segment of the observed duration, bin-average onto the observing pattern  downsample
+//   Gaussian or Poisson noise + error bars                                          noise_models.py
+// The PSD is the celerite one of the context's model (Term.get_psd), evaluated from
+// the coefficient columns mtg_prepare_kernel produced; the inverse FFTs are one batched
+// hipFFT Z2D plan; random numbers are Philox4x32-10 (see mtg_sampler.hip).  The DC term
+// is set to 0 instead of the reference's arbitrary 1e6: the series mean is removed
+// anyway and 0 makes it vanish exactly.
+#include "mtg_device.h"
+
+#include <math.h>
+
+namespace {
+
+struct Philox {
+    uint32_t c[4];
+};
+
+__device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+__device__ inline Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                       uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox{{c0, c1, c2, c3}};
+}
+
+__device__ inline double u01(uint32_t hi, uint32_t lo)
+{
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * 0x1.0p-53;
+}
+
+// two standard normals from one Philox block (Box-Muller; u1 in (0, 1])
+__device__ inline void normal2(const Philox &r, double *g1, double *g2)
+{
+    const double u1 = 1.0 - u01(r.c[0], r.c[1]), u2 = u01(r.c[2], r.c[3]);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    *g1 = rad * c;
+    *g2 = rad * s;
+}
+
+enum { PURPOSE_SPECTRUM = 8, PURPOSE_SHIFT = 9, PURPOSE_NOISE = 10 };
+
+}  // namespace
+
+// celerite Term.get_psd at angular frequency w for simulation s (coefficient columns)
+__device__ inline double mtg_psd(const double *cf, int64_t cs, const MtgCoefLayout &lay, int nr, int nc, double w)
+{
+    const double w2 = w * w;
+    double p = 0.0;
+    for (int j = 0; j < nr; ++j) {
+        const double a = cf[lay.ar(j) * cs], c = cf[lay.cr(j) * cs];
+        p += a * c / (c * c + w2);
+    }
+    for (int k = 0; k < nc; ++k) {
+        const double a = cf[lay.ac(k) * cs], b = cf[lay.bc(k) * cs], c = cf[lay.cc(k) * cs], d = cf[lay.dc(k) * cs];
+        const double w02 = c * c + d * d;
+        p += ((a * c + b * d) * w02 + (a * c - b * d) * w2) / (w2 * w2 + 2.0 * (c * c - d * d) * w2 + w02 * w02);
+    }
+    return 0.79788456080286535588 * p;  // sqrt(2 / pi)
+}
+
+// X[s][k], k = 0..nfft/2 (hipFFT Z2D input layout)
+__global__ void __launch_bounds__(256)
+mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
+                         MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, uint32_t seed_lo,
+                         uint32_t seed_hi, double2 *X)
+{
+    const int64_t nk = nfft / 2 + 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * nk) return;
+    const int64_t s = i / nk, k = i % nk;
+    double re = 0.0, im = 0.0;
+    if (k > 0) {
+        const int64_t sg = s0 + s;
+        const int nr = nr0 + 2 * sig[sg], nc = nc0 - sig[sg];
+        const double w = 6.28318530717958647692 * (double)k / ((double)nfft * dt);
+        const double amp = sqrt(0.5 * mtg_psd(coef + sg, cstride, lay, nr, nc, w));
+        const Philox r = philox4x32_10((uint32_t)k, PURPOSE_SPECTRUM, (uint32_t)sg, (uint32_t)(k >> 32), seed_lo, seed_hi);
+        normal2(r, &re, &im);
+        re *= amp; im *= amp;
+        if (2 * k == nfft) im = 0.0;  // Nyquist term of an even-length series is real
+    }
+    X[i] = make_double2(re, im);
+}
+
+// Segment cut + bin average onto the observing pattern + noise.  One thread per (simulation, epoch).
+__global__ void __launch_bounds__(256)
+mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
+                        double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
+                        int noise_kind, double sigma_noise, const double *exposures, uint32_t seed_lo,
+                        uint32_t seed_hi, double *clean, double *rates, double *dy)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * N) return;
+    const int64_t s = i / N, n = i % N, sg = s0 + s;
+    // cut_random_segment: start ~ U(time[0], time[-1] - duration), first fine sample at or after it
+    const Philox rs = philox4x32_10(0u, PURPOSE_SHIFT, (uint32_t)sg, 0u, seed_lo, seed_hi);
+    const double span = (double)(nfft - 1) - (double)seg_len;  // in units of dt
+    int64_t j0 = span > 0.0 ? (int64_t)ceil(u01(rs.c[0], rs.c[1]) * span) : 0;
+    if (j0 > nfft - seg_len) j0 = nfft - seg_len;
+    if (j0 < 0) j0 = 0;
+    const double *x = series + s * nfft + j0;
+    const int lo = win_lo[n], hi = win_hi[n];
+    double acc = 0.0;
+    for (int j = lo; j < hi; ++j) acc += x[j];
+    // rate = counts / dt with counts = irfft * scale (hipFFT's C2R is unnormalised: 1 / nfft is in `scale`)
+    const double rate = hi > lo ? acc / (double)(hi - lo) * scale / dt + mean_rate : NAN;
+    const int64_t o = sg * N + n;
+    if (clean) clean[o] = rate;
+    double yv = rate, ev = 0.0;
+    if (noise_kind == 1) {  // GaussianNoise (noise_models.py:152-184)
+        const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)sg, 0u, seed_lo, seed_hi);
+        double g1, g2;
+        normal2(r, &g1, &g2);
+        yv = rate + sigma_noise * g1;
+        ev = sigma_noise;
+    } else if (noise_kind == 2) {  // PoissonNoise without background (noise_models.py:29-78)
+        const double expo = exposures[n];
+        const double lam = rate * expo;
+        double counts;
+        if (!(lam >= 0.0)) {
+            counts = NAN;  // numpy.random.poisson raises for lam < 0: flag the epoch instead
+        } else if (lam < 10.0) {  // Knuth's multiplication method
+            const double limit = exp(-lam);
+            double prod = 1.0;
+            int kcount = 0;
+            for (uint32_t ctr = 1; ctr < 64; ++ctr) {
+                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)sg, ctr, seed_lo, seed_hi);
+                prod *= u01(r.c[0], r.c[1]);
+                if (prod <= limit) break;
+                ++kcount;
+                prod *= u01(r.c[2], r.c[3]);
+                if (prod <= limit) break;
+                ++kcount;
+            }
+            counts = (double)kcount;
+        } else {  // transformed rejection (Hoermann 1993, PTRS)
+            const double slam = sqrt(lam), loglam = log(lam);
+            const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+            const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+            counts = floor(lam + 0.5);
+            for (uint32_t ctr = 1; ctr < 256; ++ctr) {
+                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)sg, ctr, seed_lo, seed_hi);
+                const double U = u01(r.c[0], r.c[1]) - 0.5, V = u01(r.c[2], r.c[3]);
+                const double us = 0.5 - fabs(U);
+                const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+                if (us >= 0.07 && V <= vr) { counts = kf; break; }
+                if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+                if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) {
+                    counts = kf;
+                    break;
+                }
+            }
+        }
+        yv = counts / expo;
+        ev = sqrt(counts) / expo;
+    }
+    rates[o] = yv;
+    dy[o] = ev;
+}
+
+// Make the simulated light curves the context's resident set: per-light-curve mean (the frozen
+// ConstantModel(lightcurve.mean) of gpmodelling.py:83-87) and the interleaved (y - mean, (dy + 1e-12)^2)
+// pairs the solve kernel reads (yerr = dy + 1e-12, gpmodelling.py:54).  One workgroup per light curve.
+__global__ void __launch_bounds__(256)
+mtg_tk95_resident_kernel(int64_t N, const double *rates, const double *dy, double2 *yv, double *means)
+{
+    const int64_t l = blockIdx.x;
+    __shared__ double part[256];
+    double acc = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) acc += rates[l * N + n];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double mu = part[0] / (double)N;
+    if (threadIdx.x == 0) means[l] = mu;
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+        const double e = dy[l * N + n] + 1e-12;
+        yv[l * N + n] = make_double2(rates[l * N + n] - mu, e * e);
+    }
+}
+
+void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const double *dy, double2 *yv, double *means,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(mtg_tk95_resident_kernel, dim3((unsigned)L), dim3(256), 0, st, N, rates, dy, yv, means);
+}
+
+void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
+                              MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, uint64_t seed, double2 *X,
+                              hipStream_t st)
+{
+    const int64_t n = S * (nfft / 2 + 1);
+    hipLaunchKernelGGL(mtg_tk95_spectrum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, nfft, dt,
+                       coef, cstride, lay, nr0, nc0, sig, (uint32_t)seed, (uint32_t)(seed >> 32), X);
+}
+
+void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
+                             double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
+                             int noise_kind, double sigma_noise, const double *exposures, uint64_t seed, double *clean,
+                             double *rates, double *dy, hipStream_t st)
+{
+    const int64_t n = S * N;
+    hipLaunchKernelGGL(mtg_tk95_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, N, nfft,
+                       seg_len, dt, scale, mean_rate, series, win_lo, win_hi, noise_kind, sigma_noise, exposures,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), clean, rates, dy);
+}

@@ -27,7 +27,7 @@ EXPORTS = (
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
-    "mtg_predict",
+    "mtg_predict", "mtg_simulate_tk95",
 )
 
 
@@ -97,6 +97,9 @@ def load_library():
     lib.mtg_ensemble_run.argtypes = [c_vp, c_int, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
+    lib.mtg_simulate_tk95.restype = c_int
+    lib.mtg_simulate_tk95.argtypes = [c_vp, c_i64, _dp, ctypes.c_uint64, c_i64, ctypes.c_double, ctypes.c_double,
+                                      c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, c_int]
     lib.mtg_predict.restype = c_int
     lib.mtg_predict.argtypes = [c_vp, c_i64, _dp, _ip, _dp, _dp, _ip]
     lib.mtg_math_probe.restype = c_int
@@ -298,6 +301,27 @@ class Engine:
         out["iteration"] = int(it.value)
         out["n_not_pd"] = int(bad[0])
         return out
+
+    def simulate_tk95(self, theta, seed, nfft, sim_dt, mean_rate, seg_len, win_lo, win_hi, noise_kind=0,
+                      sigma_noise=0.0, exposures=None, want_clean=False, make_resident=False):
+        """TK95 light curves for S posterior samples on the resident sampling ->
+        dict(rates[S][N], dy[S][N], means[S], clean[S][N] or None)."""
+        theta = np.atleast_2d(_f64(theta))
+        S = theta.shape[0]
+        lo = np.ascontiguousarray(win_lo, dtype=np.int32)
+        hi = np.ascontiguousarray(win_hi, dtype=np.int32)
+        if lo.shape != (self.N,) or hi.shape != (self.N,):
+            raise ValueError("win_lo / win_hi must have one entry per epoch")
+        expo = None if exposures is None else _f64(np.broadcast_to(exposures, (self.N,)))
+        rates, dy, means = np.empty((S, self.N)), np.empty((S, self.N)), np.empty(S)
+        clean = np.empty((S, self.N)) if want_clean else None
+        self._check(self._lib.mtg_simulate_tk95(
+            self._ctx, S, _ptr(theta), int(seed) & 0xFFFFFFFFFFFFFFFF, int(nfft), float(sim_dt), float(mean_rate),
+            int(seg_len), _iptr(lo), _iptr(hi), int(noise_kind), float(sigma_noise), _ptr(expo), _ptr(clean),
+            _ptr(rates), _ptr(dy), _ptr(means), int(bool(make_resident))))
+        if make_resident:
+            self.L = S
+        return dict(rates=rates, dy=dy, means=means, clean=clean)
 
     def predict(self, theta, lc_index=None):
         """Conditional mean / variance at the training times -> (mu[B][N], var[B][N], status[B]);

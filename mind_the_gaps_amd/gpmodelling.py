@@ -340,11 +340,23 @@ class GPModelling:
 
     def generate_from_posteriors(self, nsims: int = 10, cpus: int = 8, pdf: str = "Gaussian",
                                  extension_factor: int = 2, sigma_noise=None):
-        """Posterior-predictive light-curve simulation (gpmodelling.py:478-513) is the
-        step BEFORE the hot path (TK95/E13 simulator)."""
+        """Light curves drawn from the MCMC posteriors (gpmodelling.py:478-539): ``nsims``
+        random posterior samples, one Timmer & Koenig realisation each on this light
+        curve's sampling, noise and error bars from its exposures (or ``sigma_noise``).
+        All simulations run in one device call (``cpus`` is accepted and ignored)."""
         if self._mcmc_samples is None:
             raise RuntimeError("Posteriors have not been derived. Please run derive_posteriors prior to "
                                "calling this method.")
-        raise NotImplementedError(
-            "light-curve simulation (mind_the_gaps.simulator) is outside the log-likelihood hot path; "
-            "draw parameters from `mcmc_samples` and simulate with the reference simulator")
+        if nsims >= len(self._mcmc_samples):
+            warnings.warn("The number of simulation requested (%d) is higher than the number of posterior "
+                          "samples (%d), so many samples will be drawn more than once"
+                          % (nsims, len(self._mcmc_samples)))
+        from .simulator import Simulator
+        param_samples = self._mcmc_samples[np.random.randint(len(self._mcmc_samples), size=nsims)]
+        lc = self._lightcurve
+        simulator = Simulator(self.gp.kernel, lc.times, lc.exposures, lc.mean, pdf, lc.bkg_rate, lc.bkg_rate_err,
+                              sigma_noise=sigma_noise, extension_factor=extension_factor,
+                              random_state=np.random.randint(0, 2 ** 31 - 1), device=self.gp.device)
+        nk = self.gp.kernel.vector_size               # the PSD depends on the kernel parameters only
+        out = simulator.simulate(param_samples[:, :nk])
+        return [GappyLightcurve(lc.times, out["rates"][i], out["dy"][i]) for i in range(nsims)]

@@ -25,7 +25,8 @@ from .gp import DeviceModel, LinAlgError, LogProbEvaluator
 from .modeling import ConstantModel
 from .sampler import integrated_time
 
-__all__ = ["EnsembleBatchSampler", "BatchPosteriors", "derive_posteriors_batch", "batched_minimize"]
+__all__ = ["EnsembleBatchSampler", "BatchPosteriors", "derive_posteriors_batch", "batched_minimize",
+           "protassov_test"]
 
 
 class EnsembleBatchSampler:
@@ -358,3 +359,54 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
         discard = np.zeros(L, dtype=int)
     names = tuple("kernel:" + n for n in kernel.get_parameter_names())
     return BatchPosteriors(sampler, tau, discard, thin, fit_x, fit_f, names)
+
+
+def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
+                   sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False):
+    """The whole posterior-predictive likelihood-ratio test of the reference's workflow
+    (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
+
+    1. posteriors of the null and the alternative kernel on the observed light curve,
+       ``T_obs = -2 (max lnL_null - max lnL_alt)``;
+    2. ``nsims`` light curves simulated from the null posteriors (device TK95);
+    3. both kernels refitted to every simulated light curve in lock-step;
+    4. p-value of ``T_obs`` in the simulated distribution.
+
+    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves).
+    """
+    from .gpmodelling import GPModelling
+    from .simulator import Simulator
+    from .stats import lrt_pvalue, lrt_statistic
+    rng = np.random.default_rng(seed)
+
+    def observed(kernel):
+        g = GPModelling(lightcurve, kernel, device=device)
+        state = np.random.get_state()
+        np.random.seed(int(rng.integers(0, 2 ** 31 - 1)))
+        try:
+            g.derive_posteriors(fit=True, max_steps=max_steps, walkers=walkers, progress=progress,
+                                device_sampler=walkers % 2 == 0)
+        finally:
+            np.random.set_state(state)
+        return g
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        null, alt = observed(null_kernel), observed(alt_kernel)
+    t_obs = float(lrt_statistic(null.max_loglikelihood, alt.max_loglikelihood))
+    samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
+    sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
+                    lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
+                    extension_factor=extension_factor, random_state=int(rng.integers(0, 2 ** 31 - 1)), device=device)
+    out = sim.simulate(samples[:, :null_kernel.vector_size])
+    sw = sim_walkers or walkers
+    fits = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kernel in (null_kernel, alt_kernel):
+            fits.append(derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
+                                                max_steps=sim_steps, fit=True, seed=int(rng.integers(0, 2 ** 62)),
+                                                device=device, store_chain=False, quiet=True))
+    t_sim = lrt_statistic(fits[0].max_loglikelihood, fits[1].max_loglikelihood)
+    return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
+                sim_null=fits[0], sim_alt=fits[1], lightcurves=out)

@@ -1,0 +1,173 @@
+"""GPU tests of the device TK95 simulator: exact host replay of the
+Philox-driven pipeline with numpy's FFT, the statistical properties the reference's own
+tests check (tests/simulator_test.py: mean, variance, PSD shape), noise models, residency."""
+import warnings
+
+import numpy as np
+import pytest
+
+import philox_replay
+from mind_the_gaps_amd import synthetic as synth
+from mind_the_gaps_amd import terms
+from mind_the_gaps_amd.gpmodelling import GPModelling
+from mind_the_gaps_amd.lightcurves import GappyLightcurve
+from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
+from mind_the_gaps_amd.simulator import Simulator
+
+pytestmark = pytest.mark.gpu
+SPECTRUM, SHIFT, NOISE = 8, 9, 10
+
+
+def regular_pattern(n=400, dt=1.0, exposure=0.2):
+    return np.arange(0.5, dt * n, dt), exposure
+
+
+def host_replay(sim, kernel, thetas, seed):
+    """The device pipeline restated with numpy (irfft) and the same Philox draws."""
+    nfft, dt = sim.fftndatapoints, sim.sim_dt
+    k = np.arange(1, nfft // 2 + 1)
+    omega = 2 * np.pi * k / (nfft * dt)
+    out = []
+    for s, th in enumerate(thetas):
+        kernel.set_parameter_vector(th)
+        r = philox_replay.philox(k, SPECTRUM, s, k >> 32, seed)
+        u1, u2 = 1.0 - philox_replay.u01(r[0], r[1]), philox_replay.u01(r[2], r[3])
+        rad = np.sqrt(-2.0 * np.log(u1))
+        X = np.zeros(nfft // 2 + 1, dtype=complex)
+        X[1:] = rad * (np.cos(2 * np.pi * u2) + 1j * np.sin(2 * np.pi * u2)) * np.sqrt(0.5 * kernel.get_psd(omega))
+        if nfft % 2 == 0:
+            X[-1] = X[-1].real
+        counts = np.fft.irfft(X, n=nfft) * np.sqrt(nfft * dt * np.sqrt(2 * np.pi))
+        rate = counts / dt + sim.mean
+        rs = philox_replay.philox(0, SHIFT, s, 0, seed)
+        span = (nfft - 1) - sim.seg_len
+        j0 = int(np.ceil(float(philox_replay.u01(rs[0], rs[1])) * span)) if span > 0 else 0
+        j0 = max(0, min(j0, nfft - sim.seg_len))
+        seg = rate[j0:j0 + sim.seg_len]
+        out.append([np.mean(seg[lo:hi]) for lo, hi in zip(sim.win_lo, sim.win_hi)])
+    return np.array(out)
+
+
+def test_device_pipeline_replays_on_the_host():
+    times, exposure = regular_pattern(300)
+    times = np.delete(times, np.arange(100, 140))                     # a gap in the observing pattern
+    kernel = DampedRandomWalk(np.log(100.0), np.log(2 * np.pi / 20)) + Lorentzian(np.log(30.0), np.log(20.0), np.log(0.7))
+    sim = Simulator(kernel, times, exposure, 10.0, "Gaussian", sigma_noise=1.0, extension_factor=3, random_state=1)
+    thetas = kernel.get_parameter_vector() + 0.05 * np.random.default_rng(0).standard_normal((4, 5))
+    out = sim.simulate(thetas, noise=False, seed=0xABCDEF12345)
+    want = host_replay(sim, kernel, thetas, 0xABCDEF12345)
+    assert out["rates"].shape == (4, len(times)) and np.all(out["dy"] == 0)
+    assert np.max(np.abs(out["rates"] - want)) < 1e-9 * np.std(want)
+    assert np.allclose(out["means"], out["rates"].mean(axis=1), rtol=1e-12)
+    # a different seed gives a different realisation; the same seed the same one
+    again = sim.simulate(thetas, noise=False, seed=0xABCDEF12345)["rates"]
+    other = sim.simulate(thetas, noise=False, seed=7)["rates"]
+    assert np.array_equal(again, out["rates"]) and not np.allclose(other, out["rates"])
+
+
+def test_mean_variance_and_psd_shape():
+    """As tests/simulator_test.py: the input mean is recovered, the variance is the integral of
+    the PSD (a e^{-c tau} has variance a), and the ensemble periodogram follows the model."""
+    times, exposure = regular_pattern(1000)
+    variance, bend = 100.0, 20.0
+    kernel = DampedRandomWalk(np.log(variance), np.log(2 * np.pi / bend))
+    sim = Simulator(kernel, times, exposure, 10.0, "Gaussian", sigma_noise=1.0, extension_factor=5,
+                    aliasing_factor=2, random_state=3)
+    S = 400
+    rates = sim.simulate(np.tile(kernel.get_parameter_vector(), (S, 1)), noise=False)["rates"]
+    assert rates.shape == (S, 1000) and np.all(np.isfinite(rates))
+    assert abs(rates.mean() - 10.0) < 4 * np.sqrt(variance / S)                  # ensemble mean
+    var = rates.var(axis=1)
+    assert abs(var.mean() / variance - 1.0) < 0.12                                # long series: close to a
+    # periodogram averaged over the ensemble vs the DRW PSD shape (bend recovered within 25 %)
+    freqs = np.fft.rfftfreq(1000, 1.0)[1:-1]
+    power = np.mean(np.abs(np.fft.rfft(rates - rates.mean(axis=1, keepdims=True), axis=1)[:, 1:-1]) ** 2, axis=0)
+    w = 2 * np.pi * freqs
+    c = 2 * np.pi / bend
+    model = 1.0 / (1.0 + (w / c) ** 2)
+    lo = w < c / 2
+    hi = (w > 3 * c) & (freqs < 0.4)
+    ratio = (power[lo].mean() / model[lo].mean()) / (power[hi].mean() / model[hi].mean())
+    assert 0.75 < ratio < 1.33
+
+
+def test_noise_models():
+    times, exposure = regular_pattern(500, exposure=0.5)
+    kernel = DampedRandomWalk(np.log(4.0), np.log(0.3))
+    theta = np.tile(kernel.get_parameter_vector(), (200, 1))
+    g = Simulator(kernel, times, exposure, 50.0, "Gaussian", sigma_noise=2.5, extension_factor=2, random_state=5)
+    out = g.simulate(theta, want_clean=True)
+    resid = out["rates"] - out["clean"]
+    assert np.all(out["dy"] == 2.5) and abs(resid.std() - 2.5) < 0.03 and abs(resid.mean()) < 0.03
+    assert abs(np.mean(resid ** 3)) < 0.6                                         # symmetric
+    p = Simulator(kernel, times, exposure, 50.0, "Gaussian", extension_factor=2, random_state=6)   # Poisson
+    assert p.noise_name == "Poisson"
+    out = p.simulate(theta, want_clean=True)
+    counts = out["rates"] * exposure
+    assert np.allclose(counts, np.round(counts)) and np.all(counts >= 0)
+    lam = out["clean"] * exposure                                                 # ~25 counts per bin (PTRS branch)
+    assert abs(np.mean(counts - lam)) < 0.05 and abs(np.var(counts - lam) / lam.mean() - 1.0) < 0.03
+    assert np.allclose(out["dy"], np.sqrt(counts) / exposure)
+    low = Simulator(kernel, times, 0.04, 50.0, "Gaussian", extension_factor=2, random_state=7)     # ~2 counts (Knuth branch)
+    out = low.simulate(theta[:50], want_clean=True)
+    counts, lam = out["rates"] * 0.04, out["clean"] * 0.04
+    assert abs(np.mean(counts - lam)) < 0.02 and abs(np.var(counts - lam) / lam.mean() - 1.0) < 0.05
+    # host-side add_noise keeps the reference's single-light-curve API
+    noisy, dy = g.add_noise(np.full(len(times), 50.0))
+    assert noisy.shape == dy.shape == times.shape and np.all(dy == 2.5)
+
+
+def test_constructor_checks_and_single_realisation():
+    times, exposure = regular_pattern(100)
+    kernel = DampedRandomWalk(0.0, 0.0)
+    with pytest.raises(ValueError):
+        Simulator(kernel, times, exposure, 1.0, extension_factor=0.5)
+    with pytest.raises(ValueError):
+        Simulator(kernel, times, 0.0, 1.0)
+    with pytest.raises(ValueError):
+        Simulator(kernel, times, 5.0, 1.0, aliasing_factor=1)        # exposure longer than the spacing
+    with pytest.raises(NotImplementedError):
+        Simulator(kernel, times, exposure, 1.0, pdf="Lognormal")
+    with pytest.raises(ValueError):
+        Simulator(lambda w: w, times, exposure, 1.0)
+    sim = Simulator(kernel.get_psd, times, exposure, 1.0, sigma_noise=0.1, random_state=2)
+    rate = sim.generate_lightcurve()
+    assert rate.shape == (100,) and np.all(np.isfinite(rate))
+    assert sim.fftndatapoints == len(sim.sim_timestamps) and sim.sim_dt == 0.1
+
+
+def test_simulated_set_stays_resident_and_generate_from_posteriors(engine):
+    """make_resident: the simulated curves are fitted without leaving the GPU, and give the same
+    likelihoods as uploading them; GPModelling.generate_from_posteriors returns light curves."""
+    times, exposure = regular_pattern(300)
+    th = synth.truth([synth.K_DRW])
+    kernel = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)])
+    sim = Simulator(kernel, times, exposure, 100.0, sigma_noise=1.5, extension_factor=2, random_state=4)
+    S = 6
+    thetas = np.tile(th, (S, 1))
+    out = sim.simulate(thetas, make_resident=True, seed=11)
+    from mind_the_gaps_amd.gp import get_engine
+    eng = get_engine(0)
+    lc = np.arange(S, dtype=np.int32)
+    resident, st = eng.loglike(thetas, lc, add_prior=False)
+    engine.set_lightcurves(times, out["rates"], out["dy"] + 1e-12, y_offset=out["rates"].mean(axis=1))
+    full, free, bounds = synth.model_spec([synth.K_DRW], out["rates"], per_lc_mean=True)
+    engine.set_model([synth.K_DRW], full, free, bounds)
+    uploaded, st2 = engine.loglike(thetas, lc, add_prior=False)
+    assert np.all(st == 0) and np.all(st2 == 0)
+    assert np.max(np.abs(resident - uploaded) / np.abs(uploaded)) < 1e-12
+    # the facade
+    y = out["rates"][0]
+    g = GPModelling(GappyLightcurve(times, y, out["dy"][0], exposures=exposure), kernel)
+    np.random.seed(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g.derive_posteriors(fit=False, max_steps=60, convergence_steps=30, walkers=8, progress=False)
+        lcs = g.generate_from_posteriors(nsims=5, sigma_noise=1.5)
+    assert len(lcs) == 5 and all(isinstance(l, GappyLightcurve) for l in lcs)
+    assert all(l.n == 300 and np.all(l.dy == 1.5) and np.all(np.isfinite(l.y)) for l in lcs)
+    assert abs(np.mean([l.mean for l in lcs]) - np.mean(y)) < 15.0
+    g0 = GPModelling(GappyLightcurve(times, y, out["dy"][0]), kernel)      # no exposures given
+    g0._mcmc_samples = g._mcmc_samples
+    with pytest.raises(ValueError):                       # "Some exposure times are 0!" (simulator.py:201-202)
+        g0.generate_from_posteriors(2)
