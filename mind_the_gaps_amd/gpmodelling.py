@@ -208,6 +208,11 @@ class GPModelling:
             tau = sampler.get_autocorr_time(tol=0)
         self._tau = tau
         mean_tau = np.mean(tau)
+        if not np.isfinite(mean_tau):
+            # a parameter that never moved (very short chains) has an undefined autocorrelation
+            # time; the reference would crash on int(nan) below
+            warnings.warn("The autocorrelation time could not be estimated; keeping every sample")
+            mean_tau = 0.0
         if not self.converged:
             warnings.warn(f"The chains did not converge after {sampler.iteration} iterations!")
             thin = int(mean_tau / 4)
