@@ -155,6 +155,13 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
                                int mean_kind, const double *mean_params, const int32_t *lc_index,
                                double *out, int32_t *status);
 
+/*
+ * Kernel choice for mtg_loglike_batch[_device] / mtg_ensemble_*: 0 = always one lane per
+ * evaluation (throughput kernel), 1 = one wave per evaluation, parallel in time, whenever the
+ * structure has that kernel (J <= 6), 2 = automatic (default): time-parallel for batches of at
+ * most 2048 evaluations of light curves with at least 1024 samples.
+ */
+MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
 /* Block until everything enqueued on the context's stream has finished. */
 MTG_API int mtg_synchronize(mtg_ctx *ctx);
 /* Device time (ms, HIP events on the launch stream) of the last

@@ -63,6 +63,9 @@ struct mtg_ctx {
     // staging for the host-pointer entry points
     DevBuf theta, lc, out, status;
 
+    // small batches: one wave per evaluation, parallel in time (0 never, 1 whenever compiled, 2 auto)
+    int tp_mode = 2;
+
     // device-resident ensembles (mtg_ensemble_*)
     int64_t ens_E = 0;
     int ens_W = 0, ens_P = 0;
@@ -191,13 +194,17 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     // the mean vanishes identically when it is a frozen constant equal to 0 (the
     // per-light-curve frozen mean lives in y_offset)
     sa.has_mean = !(m.mean_kind == MTG_MEAN_CONSTANT && m.src[m.nk] < 0 && m.defaults[m.nk] == 0.0);
+    // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
+    // steps: give every evaluation a whole wave instead (mtg_timeparallel.hip).
+    const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && B <= 2048 && ctx->N >= 1024);
     for (int k = 0; k < nsig; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
         mtg_solve_launcher fn = mtg_find_solver(nr, nc);
         if (!fn) continue;
+        mtg_solve_launcher tp = small ? mtg_find_tp_solver(nr, nc) : nullptr;
         sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
         sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
-        fn(sa, B, s);
+        (tp ? tp : fn)(sa, B, s);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
@@ -886,6 +893,13 @@ MTG_API int mtg_math_probe(mtg_ctx *ctx, int64_t n, const double *x, double *exp
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     buf.release();
     if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_math_probe: %s", hipGetErrorString(e));
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MTG_E_ARG;
+    ctx->tp_mode = mode;
     return MTG_OK;
 }
 

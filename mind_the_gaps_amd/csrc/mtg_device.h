@@ -98,6 +98,9 @@ struct MtgPredictArgs {
 typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStream_t);
 // Table lookup of the compiled <NR, NC> instantiations (mtg_kernels.hip).
 mtg_solve_launcher mtg_find_solver(int nr, int nc);
+// Time-parallel (one wave per evaluation) instantiations, J <= 6 (mtg_timeparallel.hip); the
+// launcher's second argument is the number of evaluations.
+mtg_solve_launcher mtg_find_tp_solver(int nr, int nc);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
                          const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,

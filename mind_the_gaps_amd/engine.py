@@ -27,7 +27,7 @@ EXPORTS = (
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
-    "mtg_predict", "mtg_simulate_tk95",
+    "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel",
 )
 
 
@@ -100,6 +100,8 @@ def load_library():
     lib.mtg_simulate_tk95.restype = c_int
     lib.mtg_simulate_tk95.argtypes = [c_vp, c_i64, _dp, ctypes.c_uint64, c_i64, ctypes.c_double, ctypes.c_double,
                                       c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, c_int]
+    lib.mtg_set_time_parallel.restype = c_int
+    lib.mtg_set_time_parallel.argtypes = [c_vp, c_int]
     lib.mtg_predict.restype = c_int
     lib.mtg_predict.argtypes = [c_vp, c_i64, _dp, _ip, _dp, _dp, _ip]
     lib.mtg_math_probe.restype = c_int
@@ -341,6 +343,10 @@ class Engine:
         outs = [np.empty_like(x) for _ in range(4)]
         self._check(self._lib.mtg_math_probe(self._ctx, len(x), _ptr(x), *[_ptr(o) for o in outs]))
         return outs
+
+    def set_time_parallel(self, mode):
+        """0 = throughput kernel only, 1 = time-parallel kernel whenever available, 2 = auto (default)."""
+        self._check(self._lib.mtg_set_time_parallel(self._ctx, int(mode)))
 
     def synchronize(self):
         self._check(self._lib.mtg_synchronize(self._ctx))

@@ -1,0 +1,74 @@
+"""GPU parity of the time-parallel kernel (one wave per evaluation, mtg_timeparallel.hip)
+against the oracle and against the throughput kernel."""
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import synthetic as synth
+from oracle import celerite as oracle_c
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {
+    "drw": [synth.K_DRW],
+    "drw+sho": [synth.K_DRW, synth.K_SHO],
+    "drw+sho+lor": [synth.K_DRW, synth.K_SHO, synth.K_LORENTZIAN],
+    "bpl+jitter": [synth.K_BPL, synth.K_JITTER],
+    "cosinus+drw": [synth.K_COSINUS, synth.K_DRW],
+    "matern32+real": [synth.K_MATERN32, synth.K_REAL],
+    "3sho": [synth.K_SHO] * 3,
+}
+
+
+@pytest.mark.parametrize("name", sorted(MODELS))
+@pytest.mark.parametrize("N", [1, 3, 70, 1000, 4097])
+def test_time_parallel_vs_oracle(engine, name, N):
+    kinds = MODELS[name]
+    L, B = 2, 24
+    t, y, dy = synth.make_lightcurves(N, L, seed=200 + N)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    y_mean = y.mean(axis=1)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds)
+    theta = synth.draw_thetas(kinds, B, seed=17)
+    if name == "3sho":
+        theta[::2, 4] = np.log(0.3)                       # some over-damped: mixed signatures
+    lc = (np.arange(B) % L).astype(np.int32)
+    try:
+        engine.set_time_parallel(1)
+        out, st = engine.loglike(theta, lc, add_prior=True)
+        engine.set_time_parallel(0)
+        thr, st_thr = engine.loglike(theta, lc, add_prior=True)
+    finally:
+        engine.set_time_parallel(2)
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, y_mean[lc][:, None]]), bounds=bounds,
+                                      lc_index=lc, add_prior=True, nthreads=4)
+    assert np.array_equal(st, rst) and np.array_equal(st_thr, rst)
+    ok = st == 0
+    assert ok.sum() > B // 2
+    assert np.max(np.abs(out[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
+    assert np.max(np.abs(out[ok] - thr[ok]) / np.abs(thr[ok])) <= 1e-9
+
+
+def test_time_parallel_linear_mean_and_per_lc_times(engine):
+    kinds = [synth.K_DRW, synth.K_SHO]
+    N, L, B = 900, 3, 12
+    rng = np.random.default_rng(4)
+    t = np.vstack([synth.make_times(N, rng, offset=50.0 * i) for i in range(L)])
+    dy = rng.uniform(0.5, 2.0, (L, N))
+    y = 100.0 + 10.0 * rng.standard_normal((L, N)) + 0.02 * (t - t[:, :1])
+    full = np.concatenate([synth.truth(kinds), [0.02, 100.0]])
+    bounds = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)] * 2])
+    engine.set_lightcurves(t, y, dy + 1e-12)
+    engine.set_model(kinds, full, np.arange(len(full), dtype=np.int32), bounds, mean_kind=1)
+    theta = np.hstack([synth.draw_thetas(kinds, B, seed=9), np.tile([0.02, 100.0], (B, 1))])
+    lc = (np.arange(B) % L).astype(np.int32)
+    try:
+        engine.set_time_parallel(1)
+        out, st = engine.loglike(theta, lc, add_prior=False)
+    finally:
+        engine.set_time_parallel(2)
+    ref = np.empty(B)
+    for l in range(L):
+        sel = lc == l
+        ref[sel] = oracle_c.logprob_batch(t[l], y[l], dy[l], kinds, theta[sel], mean_kind=1)[0]
+    assert np.all(st == 0) and np.max(np.abs(out - ref) / np.abs(ref)) <= 1e-8
