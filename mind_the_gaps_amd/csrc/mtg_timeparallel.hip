@@ -14,12 +14,19 @@
 // Sarkka & Garcia-Fernandez (2021): the N samples are cut into 64 chunks, one per lane;
 //   pass 1  every lane composes the elements (A, b, C, eta, J) of its chunk -- a
 //           rank-one (Sherman-Morrison) composition per step, O(J^2);
-//   pass 2  the filtered state (m, C) at every chunk boundary: lane 0 applies the 64 chunk
-//           elements in turn (one small LU solve each), through LDS;
+//   pass 2  an inclusive scan of the 64 chunk elements across the lanes (Hillis-Steele through
+//           LDS, six rounds of the general element combination, one J x J inverse each);
+//           every lane then applies the prefix of the earlier chunks to the state after
+//           sample 0: its chunk's start state;
 //   pass 3  every lane runs the ordinary Kalman filter over its chunk from its start
 //           state and accumulates ln prod D and sum z^2 / D; a wave reduction finishes.
-// Work is ~3x the serial sweep, depth N/64 + 64 instead of N.
+// Work is ~3x the serial sweep, depth ~2 N/64 + 6 combinations instead of N.
 #include "mtg_device.h"
+
+// 256-entry tables here (2 KiB + 4 KiB): LDS is needed for the chunk elements
+#define MTG_EXP_BITS 8
+#define MTG_TRIG_BITS 8
+#include "mtg_math.h"
 
 #include <math.h>
 
@@ -46,16 +53,26 @@ template <int NR, int NC> struct TpTrans {
     double ec[NC > 0 ? NC : 1], es[NC > 0 ? NC : 1];  // e cos(d dx), e sin(d dx)
 };
 
-template <int NR, int NC>
-__device__ __forceinline__ void tp_transition(const TpModel<NR, NC> &M, double dx, TpTrans<NR, NC> &T)
+// FAST: table exp / sincos (every d_k * dx of this wave is inside the table reduction's range)
+template <int NR, int NC, bool FAST>
+__device__ __forceinline__ void tp_transition(const TpModel<NR, NC> &M, double dx, TpTrans<NR, NC> &T,
+                                              const MtgMathTables *tab)
 {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) T.phi[j] = exp(-M.cr[j] * dx);
+    for (int j = 0; j < NR; ++j)
+        T.phi[j] = FAST ? mtg_exp_cdx(-M.cr[j], M.cr[j] * -MTG_EXP_CSCALE, dx, tab) : exp(-M.cr[j] * dx);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        const double e = exp(-M.cc[k] * dx);
-        double s, c;
-        sincos(M.dc[k] * dx, &s, &c);
+        double e, s, c;
+        if (FAST) {
+            e = mtg_exp_cdx(-M.cc[k], M.cc[k] * -MTG_EXP_CSCALE, dx, tab);
+            double r0 = 0.0;
+            int m0 = 0;
+            mtg_phase_step(M.dc[k], dx, r0, m0, &s, &c, tab);
+        } else {
+            e = exp(-M.cc[k] * dx);
+            sincos(M.dc[k] * dx, &s, &c);
+        }
         T.ec[k] = e * c;
         T.es[k] = e * s;
     }
@@ -384,46 +401,198 @@ __device__ __forceinline__ void tp_apply_elem(const TpElem<J> &e, double *m, Sym
         }
 }
 
+// e2 <- e1 o e2 (e1 earlier in time): the general combination of two filtering elements
+//   G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2
+//   eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1
+template <int J>
+__device__ __forceinline__ void tp_combine(const TpElem<J> &e1, TpElem<J> &e2)
+{
+    // Gi = (I + C1 J2)^-1 by Gauss-Jordan (similar to a symmetric positive definite matrix: no pivoting)
+    double G[J][J], Gi[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double g = i == j ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) g = fma(e1.C(i, k), e2.Jm(k, j), g);
+            G[i][j] = g;
+            Gi[i][j] = i == j ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+        const double ip = 1.0 / G[p][p];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { G[p][j] *= ip; Gi[p][j] *= ip; }
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            if (i == p) continue;
+            const double f = G[i][p];
+#pragma unroll
+            for (int j = 0; j < J; ++j) { G[i][j] = fma(-f, G[p][j], G[i][j]); Gi[i][j] = fma(-f, Gi[p][j], Gi[i][j]); }
+        }
+    }
+    // information part (uses A1, b1, eta1, J1 and the OLD eta2, J2)
+    double t[J], yeta[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = e2.eta[i];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(-e2.Jm(i, k), e1.b[k], s);
+        t[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) {  // G^-T t
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(Gi[k][i], t[k], s);
+        yeta[i] = s;
+    }
+    double YJ[J][J], Z[J][J];  // YJ = G^-T J2 ; Z = YJ A1
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(Gi[k][i], e2.Jm(k, j), s);
+            YJ[i][j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(YJ[i][k], e1.A[k][j], s);
+            Z[i][j] = s;
+        }
+    double eta_new[J];
+    Sym<J> J_new;
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = e1.eta[i];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(e1.A[k][i], yeta[k], s);
+        eta_new[i] = s;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double u = 0.0, v = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) { u = fma(e1.A[k][i], Z[k][j], u); v = fma(e1.A[k][j], Z[k][i], v); }
+            J_new(i, j) = 0.5 * (u + v) + e1.Jm(i, j);
+        }
+    }
+    // state part: XA = Gi A1, Xb = Gi (b1 + C1 eta2), XC = Gi C1
+    double w[J], Xb[J], XA[J][J], XC[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = e1.b[i];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(e1.C(i, k), e2.eta[k], s);
+        w[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(Gi[i][k], w[k], s);
+        Xb[i] = s;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) { a = fma(Gi[i][k], e1.A[k][j], a); c = fma(Gi[i][k], e1.C(k, j), c); }
+            XA[i][j] = a;
+            XC[i][j] = c;
+        }
+    }
+    double A_new[J][J], b_new[J], Y[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = e2.b[i];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(e2.A[i][k], Xb[k], s);
+        b_new[i] = s;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) { a = fma(e2.A[i][k], XA[k][j], a); c = fma(e2.A[i][k], XC[k][j], c); }
+            A_new[i][j] = a;
+            Y[i][j] = c;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double u = 0.0, v = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) { u = fma(Y[i][k], e2.A[j][k], u); v = fma(Y[j][k], e2.A[i][k], v); }
+            e2.C(i, j) = 0.5 * (u + v) + e2.C(i, j);
+        }
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        e2.b[i] = b_new[i];
+        e2.eta[i] = eta_new[i];
+#pragma unroll
+        for (int j = 0; j < J; ++j) e2.A[i][j] = A_new[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e2.Jm.v[i] = J_new.v[i];
+}
+
+template <int J>
+__device__ __forceinline__ void tp_store(const TpElem<J> &e, double *slot)
+{
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) slot[o++] = e.A[i][j];
+#pragma unroll
+    for (int i = 0; i < J; ++i) slot[o++] = e.b[i];
+#pragma unroll
+    for (int i = 0; i < J; ++i) slot[o++] = e.eta[i];
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[o++] = e.C.v[i];
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[o++] = e.Jm.v[i];
+}
+
+template <int J>
+__device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
+{
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) e.A[i][j] = slot[o++];
+#pragma unroll
+    for (int i = 0; i < J; ++i) e.b[i] = slot[o++];
+#pragma unroll
+    for (int i = 0; i < J; ++i) e.eta[i] = slot[o++];
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e.C.v[i] = slot[o++];
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e.Jm.v[i] = slot[o++];
+}
+
 }  // namespace
 
 // one wave per evaluation; lane = chunk
-template <int NR, int NC>
-__global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
+template <int NR, int NC, bool FAST>
+__device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
+                                            double icpt, int64_t ev, int64_t lc, const MtgMathTables *tab, double *sh)
 {
     constexpr int J = NR + 2 * NC;
     constexpr int ELEM = J * J + 2 * J + J * (J + 1);  // doubles per element
-    __shared__ double sh[MTG_TP_LANES * (J * J + 2 * J + J * (J + 1)) + 8];
     const int lane = threadIdx.x;
-    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
-    if ((int64_t)blockIdx.x >= count) return;
-    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
-    if (!a.list && a.status[ev] != MTG_ST_OK) return;
-
-    // ---- model of this evaluation (same for every lane) ------------------------------
-    TpModel<NR, NC> M;
-    const double *cf = a.coef + ev;
-    const int64_t cs = a.cstride;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) { M.ar[j] = cf[a.lay.ar(j) * cs]; M.cr[j] = cf[a.lay.cr(j) * cs]; }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const double aa = cf[a.lay.ac(k) * cs], bb = cf[a.lay.bc(k) * cs], c = cf[a.lay.cc(k) * cs], d = cf[a.lay.dc(k) * cs];
-        M.ac[k] = aa; M.bc[k] = bb; M.cc[k] = c; M.dc[k] = d;
-        // free entry of P_inf: the value maximising det(noise covariance) (proto/kalman_scan.py)
-        M.pc[k] = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
-    }
-    double ksum = 0.0;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) ksum += M.ar[j];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) ksum += M.ac[k];
-    const double jitter = cf[a.lay.asum() * cs] - ksum;
-    const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
-    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
     const int64_t N = a.N;
     const double2 *yv = a.yv + lc * N, *dxt = a.dxt + lc * a.t_stride;
 
-    // chunk of this lane: samples [lo, hi), sample 0 belongs to the prior update below
+    // chunk of this lane: samples [lo, hi); sample 0 is the prior update below
     const int64_t per = (N + MTG_TP_LANES - 1) / MTG_TP_LANES;
     int64_t lo = (int64_t)lane * per, hi = lo + per;
     if (lo > N) lo = N;
@@ -435,96 +604,63 @@ __global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     tp_identity<J>(e);
     for (int64_t n = lo; n < hi; ++n) {
         TpTrans<NR, NC> T;
-        tp_transition<NR, NC>(M, dxt[n].x, T);
+        tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
         const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
         tp_compose_step<NR, NC, J>(M, T, r, yv[n].y + jitter, e);
     }
-    double *mine = sh + lane * ELEM;
-    {
-        int o = 0;
-#pragma unroll
-        for (int i = 0; i < J; ++i)
-#pragma unroll
-            for (int j = 0; j < J; ++j) mine[o++] = e.A[i][j];
-#pragma unroll
-        for (int i = 0; i < J; ++i) mine[o++] = e.b[i];
-#pragma unroll
-        for (int i = 0; i < J; ++i) mine[o++] = e.eta[i];
-#pragma unroll
-        for (int i = 0; i < J * (J + 1) / 2; ++i) mine[o++] = e.C.v[i];
-#pragma unroll
-        for (int i = 0; i < J * (J + 1) / 2; ++i) mine[o++] = e.Jm.v[i];
-    }
-    __syncthreads();
 
-    // ---- pass 2: filtered state at every chunk start (lane 0, serial over the 64 elements) ----
-    // the start states overwrite the elements in LDS: [m (J) | C (J(J+1)/2)] per lane
-    double first_ld = 0.0, first_dot = 0.0;
-    if (lane == 0) {
-        double m[J];
-        Sym<J> C;
-#pragma unroll
-        for (int i = 0; i < J; ++i) m[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < J * (J + 1) / 2; ++i) C.v[i] = 0.0;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) C(j, j) = M.ar[j];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const int o = NR + 2 * k;
-            C(o, o) = M.ac[k]; C(o + 1, o) = -M.bc[k]; C(o + 1, o + 1) = M.pc[k];
-        }
-        // sample 0: update of the stationary prior
-        double ch[J];
-        tp_C_h<NR, NC, J>(C, ch);
-        const double D0 = tp_h_dot<NR, NC>(ch) + yv[0].y + jitter;
-        const double z0 = yv[0].x - fma(slope, dxt[0].y, icpt);
-#pragma unroll
-        for (int i = 0; i < J; ++i) m[i] = ch[i] * z0 / D0;
-#pragma unroll
-        for (int i = 0; i < J; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) C(i, j) -= ch[i] * ch[j] / D0;
-        first_ld = log(D0);
-        first_dot = z0 * z0 / D0;
-        for (int c = 0; c < MTG_TP_LANES; ++c) {
-            double *slot = sh + c * ELEM;
-            TpElem<J> ec;
-            int o = 0;
-#pragma unroll
-            for (int i = 0; i < J; ++i)
-#pragma unroll
-                for (int j = 0; j < J; ++j) ec.A[i][j] = slot[o++];
-#pragma unroll
-            for (int i = 0; i < J; ++i) ec.b[i] = slot[o++];
-#pragma unroll
-            for (int i = 0; i < J; ++i) ec.eta[i] = slot[o++];
-#pragma unroll
-            for (int i = 0; i < J * (J + 1) / 2; ++i) ec.C.v[i] = slot[o++];
-#pragma unroll
-            for (int i = 0; i < J * (J + 1) / 2; ++i) ec.Jm.v[i] = slot[o++];
-            // store the start state of chunk c, then advance over it
-#pragma unroll
-            for (int i = 0; i < J; ++i) slot[i] = m[i];
-#pragma unroll
-            for (int i = 0; i < J * (J + 1) / 2; ++i) slot[J + i] = C.v[i];
-            tp_apply_elem<J>(ec, m, C);
-        }
-    }
+    // ---- pass 2: inclusive scan of the 64 chunk elements (Hillis-Steele through LDS) ------
+    double *buf0 = sh, *buf1 = sh + MTG_TP_LANES * ELEM;
+    double *cur = buf0, *nxt = buf1;
+    tp_store<J>(e, cur + lane * ELEM);
     __syncthreads();
-
-    // ---- pass 3: ordinary Kalman filter over the chunk from its start state -------------
+    for (int off = 1; off < MTG_TP_LANES; off <<= 1) {
+        if (lane >= off) {
+            TpElem<J> prev;
+            tp_load<J>(prev, cur + (lane - off) * ELEM);
+            tp_combine<J>(prev, e);
+        }
+        tp_store<J>(e, nxt + lane * ELEM);
+        __syncthreads();
+        double *t = cur; cur = nxt; nxt = t;
+    }
+    // filtered state after sample 0 (update of the stationary prior), identical on every lane
     double m[J];
     Sym<J> C;
 #pragma unroll
-    for (int i = 0; i < J; ++i) m[i] = mine[i];
+    for (int i = 0; i < J; ++i) m[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) C.v[i] = mine[J + i];
-    double dot = first_dot, dprod = 1.0, dmin = INFINITY;
+    for (int i = 0; i < J * (J + 1) / 2; ++i) C.v[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) C(j, j) = M.ar[j];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int o = NR + 2 * k;
+        C(o, o) = M.ac[k]; C(o + 1, o) = -M.bc[k]; C(o + 1, o + 1) = M.pc[k];
+    }
+    double ch[J];
+    tp_C_h<NR, NC, J>(C, ch);
+    const double D0 = tp_h_dot<NR, NC>(ch) + yv[0].y + jitter;
+    const double z0 = yv[0].x - fma(slope, dxt[0].y, icpt);
+#pragma unroll
+    for (int i = 0; i < J; ++i) m[i] = ch[i] * z0 / D0;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) C(i, j) -= ch[i] * ch[j] / D0;
+    // start state of this lane's chunk: the prefix of the earlier chunks applied to it
+    if (lane > 0) {
+        TpElem<J> pre;
+        tp_load<J>(pre, cur + (lane - 1) * ELEM);
+        tp_apply_elem<J>(pre, m, C);
+    }
+
+    // ---- pass 3: ordinary Kalman filter over the chunk from its start state -------------
+    double dot = lane == 0 ? z0 * z0 / D0 : 0.0, dprod = 1.0, dmin = lane == 0 ? D0 : INFINITY;
     int dexp = 0;
     for (int64_t n = lo; n < hi; ++n) {
         TpTrans<NR, NC> T;
-        tp_transition<NR, NC>(M, dxt[n].x, T);
+        tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
         const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
         double D, z;
         tp_filter_step<NR, NC, J>(M, T, r, yv[n].y + jitter, m, C, D, z);
@@ -534,8 +670,7 @@ __global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
         dprod = __builtin_amdgcn_frexp_mant(pr);
         dexp += __builtin_amdgcn_frexp_exp(pr);
     }
-    double ld = first_ld + log(dprod) + (double)dexp * 0.69314718055994530942;
-    // wave reduction
+    double ld = (lane == 0 ? log(D0) : 0.0) + log(dprod) + (double)dexp * 0.69314718055994530942;
     for (int off = 32; off > 0; off >>= 1) {
         dot += __shfl_down(dot, off);
         ld += __shfl_down(ld, off);
@@ -549,6 +684,48 @@ __global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
         a.out[ev] = ll;
         a.status[ev] = st;
     }
+}
+
+template <int NR, int NC>
+__global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
+{
+    constexpr int J = NR + 2 * NC;
+    __shared__ double sh[2 * MTG_TP_LANES * (J * J + 2 * J + J * (J + 1))];
+    __shared__ MtgMathTables tab;
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if ((int64_t)blockIdx.x >= count) return;
+    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
+    if (!a.list && a.status[ev] != MTG_ST_OK) return;
+    mtg_fill_tables(&tab, threadIdx.x, MTG_TP_LANES);
+    __syncthreads();
+
+    // ---- model of this evaluation (same on every lane) ------------------------------------
+    TpModel<NR, NC> M;
+    const double *cf = a.coef + ev;
+    const int64_t cs = a.cstride;
+    double dmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { M.ar[j] = cf[a.lay.ar(j) * cs]; M.cr[j] = cf[a.lay.cr(j) * cs]; }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const double aa = cf[a.lay.ac(k) * cs], bb = cf[a.lay.bc(k) * cs], c = cf[a.lay.cc(k) * cs], d = cf[a.lay.dc(k) * cs];
+        M.ac[k] = aa; M.bc[k] = bb; M.cc[k] = c; M.dc[k] = d;
+        // free entry of P_inf: the value maximising det(noise covariance) (proto/kalman_scan.py)
+        M.pc[k] = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
+        dmax = fmax(dmax, fabs(d));
+    }
+    double ksum = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) ksum += M.ar[j];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) ksum += M.ac[k];
+    const double jitter = cf[a.lay.asum() * cs] - ksum;
+    const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
+    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+    if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
+        mtg_tp_body<NR, NC, true>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
+    else
+        mtg_tp_body<NR, NC, false>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
 }
 
 template <int NR, int NC>
