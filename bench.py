@@ -85,6 +85,41 @@ def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds):
                       "threads, oracle/celerite_ref.c" % (done, len(t), el, cores)}
 
 
+def single_lightcurve_configs():
+    """BASELINE configs[1] and [2] (one light curve, N = 1e4): stretch-move iterations/s through
+    GPModelling.derive_posteriors with the device-resident sampler; small batches take the
+    time-parallel kernel.  Reported next to the headline, not part of `value`."""
+    import warnings
+    from mind_the_gaps_amd import synthetic as synth, terms
+    from mind_the_gaps_amd.gpmodelling import GPModelling
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
+    amp, other = (-10, 50), (-10, 10)
+    th = synth.truth(synth.ALT_MODEL)
+
+    def null_kernel():
+        return DampedRandomWalk(th[0], th[1], bounds=[amp, other]) + terms.SHOTerm(th[2], th[3], th[4],
+                                                                                   bounds=[amp, other, other])
+    out = {}
+    t, y, dy = synth.make_lightcurves(10000, 1, seed=20250704 + 2)
+    for name, kernel, walkers in (("configs[1] DRW+SHO N=1e4 128 walkers", null_kernel(), 128),
+                                  ("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers",
+                                   null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other]), 256)):
+        g = GPModelling(GappyLightcurve(t, y[0], dy[0]), kernel)
+        np.random.seed(1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g.derive_posteriors(fit=False, max_steps=10, convergence_steps=10, walkers=walkers, progress=False,
+                                device_sampler=True)
+            steps = 200
+            t0 = time.perf_counter()
+            g.derive_posteriors(fit=False, max_steps=steps, convergence_steps=steps, walkers=walkers,
+                                progress=False, device_sampler=True)
+            el = time.perf_counter() - t0
+        out[name] = {"iterations_per_s": steps / el, "evals_per_s": steps * walkers / el}
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -209,6 +244,10 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds)
+            try:
+                line["other_configs"] = single_lightcurve_configs()
+            except Exception as exc:  # never let the side measurements break the headline line
+                line["other_configs"] = {"error": repr(exc)}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

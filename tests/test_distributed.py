@@ -88,3 +88,46 @@ def test_two_rank_gloo_sharding(tmp_path):
         assert np.array_equal(r["lnp"], want) and np.array_equal(r["st"], wst)       # every rank has the full vector
         assert np.array_equal(r["best"], want.reshape(5, 6).max(axis=1))
     assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 3, 3, 5)
+
+
+def _ppp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import celerite as oracle_c
+    from mind_the_gaps_amd.models import DampedRandomWalk
+    from mind_the_gaps_amd.ppp import derive_posteriors_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kinds = [synth.K_DRW]
+    t, y, dy = synth.make_lightcurves(60, 5, seed=21)
+    shard = mdist.LightcurveShard(5)
+    yl, dyl = y[shard.lo:shard.hi], dy[shard.lo:shard.hi]
+
+    def evaluate(theta, lc, add_prior):           # this rank's "engine": only its own light curves
+        full = np.hstack([theta, yl.mean(axis=1)[lc][:, None]])
+        b = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)]])
+        return oracle_c.logprob_batch(t, yl, dyl, kinds, full, bounds=b, lc_index=np.asarray(lc, np.int32),
+                                      add_prior=add_prior)
+
+    th = synth.truth(kinds)
+    kernel = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)])
+    best, local, sh = derive_posteriors_sharded(t, y, dy, kernel, walkers=8, max_steps=25, fit=False, seed=3,
+                                                evaluate=evaluate, store_chain=False)
+    np.savez(os.path.join(out_dir, "ppp%d.npz" % rank), best=best, local=local.max_loglikelihood, lo=sh.lo, hi=sh.hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_posteriors(tmp_path):
+    """Light-curve sharded lock-step fit on 2 gloo ranks: every rank ends with the full
+    max-lnL vector, made of each rank's own block."""
+    import torch.multiprocessing as mp
+    from oracle import celerite as oracle_c
+    oracle_c.lib()
+    world, port = 2, _free_port()
+    mp.spawn(_ppp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / ("ppp%d.npz" % r)) for r in range(world))
+    assert np.array_equal(r0["best"], r1["best"]) and r0["best"].shape == (5,)
+    assert np.array_equal(r0["best"][:3], r0["local"]) and np.array_equal(r0["best"][3:], r1["local"])
+    assert np.all(np.isfinite(r0["best"]))
