@@ -17,9 +17,13 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
+struct DevBuf {  // owning device allocation; locals free themselves on every return path
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
