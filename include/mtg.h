@@ -158,9 +158,9 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
 /*
  * Kernel choice for mtg_loglike_batch[_device] / mtg_ensemble_*: 0 = always one lane per
  * evaluation (throughput kernel), 1 = one wave per evaluation, parallel in time, whenever the
- * structure has that kernel (J <= 6), 2 = automatic (default): time-parallel for batches of at
- * most 1024 evaluations of light curves with at least 256 samples (measured crossover: 4-10x
- * faster there, slower above ~4096 evaluations).
+ * structure has that kernel (J <= 6, and the J = 10 structures of five SHO terms), 2 = automatic
+ * (default): time-parallel for light curves of at least 256 samples and batches of at most 1024
+ * evaluations (J <= 6: 4-10x faster there) or 128 evaluations (J = 10: ~3x faster).
  */
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
 /* Block until everything enqueued on the context's stream has finished. */

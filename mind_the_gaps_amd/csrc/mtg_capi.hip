@@ -200,7 +200,10 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     sa.has_mean = !(m.mean_kind == MTG_MEAN_CONSTANT && m.src[m.nk] < 0 && m.defaults[m.nk] == 0.0);
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
     // steps: give every evaluation a whole wave instead (mtg_timeparallel.hip).
-    const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && B <= 1024 && ctx->N >= 256);
+    // (measured crossovers: J <= 6 elements live in registers, the J = 10 ones spill to scratch)
+    const int Jmodel = m.nr0 + 2 * m.nc0;
+    const bool small = ctx->tp_mode == 1 ||
+                       (ctx->tp_mode == 2 && ctx->N >= 256 && B <= (Jmodel <= 6 ? 1024 : 128));
     for (int k = 0; k < nsig; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
         mtg_solve_launcher fn = mtg_find_solver(nr, nc);

@@ -1,0 +1,11 @@
+// mtg_timeparallel_big.hip -- ONE J = 10 instance of the time-parallel kernel per compilation:
+//   hipcc -DMTG_TP_BIG_NR=<nr> -DMTG_TP_BIG_NC=<nc> -c mtg_timeparallel_big.hip
+#include "mtg_timeparallel.h"
+
+#define MTG_CAT2(a, b, c, d) a##b##c##d
+#define MTG_CAT(a, b, c, d) MTG_CAT2(a, b, c, d)
+
+void MTG_CAT(mtg_launch_tp_big_, MTG_TP_BIG_NR, _, MTG_TP_BIG_NC)(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
+{
+    mtg_launch_tp<MTG_TP_BIG_NR, MTG_TP_BIG_NC>(a, nevals, s);
+}

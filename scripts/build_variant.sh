@@ -1,9 +1,11 @@
 #!/bin/bash
-# build_variant.sh NAME "-DFLAG=..."  ->  gpurun_out/variants/libmtg_NAME.so  (kernel A/B experiments)
+# build_variant.sh NAME "-DFLAG=..."  ->  variants/libmtg_NAME.so  (kernel A/B experiments)
 set -e
 NAME=$1; shift
 OUT=/root/repo/variants
+WORK=/tmp/mtg_variant_$NAME
 mkdir -p $OUT
-cd /root/repo/mind_the_gaps_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 "$@" -shared -o $OUT/libmtg_$NAME.so mtg_kernels.hip mtg_sampler.hip mtg_simulate.hip mtg_timeparallel.hip mtg_capi.hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib
+rm -rf $WORK && mkdir -p $WORK/a/b && cp -r /root/repo/mind_the_gaps_amd/csrc $WORK/a/b/csrc && cp -r /root/repo/include $WORK/include
+make -C $WORK/a/b/csrc clean >/dev/null
+make -C $WORK/a/b/csrc -j8 HIPFLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $*" OUT=$OUT/libmtg_$NAME.so 2>&1 | grep -E "error" || true
 echo built $OUT/libmtg_$NAME.so
