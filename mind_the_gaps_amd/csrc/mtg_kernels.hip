@@ -319,6 +319,7 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         }
         // -- S <- (phi phi^T) o (S + D W W^T) ;  f <- phi o (f + W z) ----------
         const double zs = L.z * L.invD;
+        L.dot = fma(L.z, zs, L.dot);  // z_{n-1}^2 / D_{n-1}: the previous sample's term of r^T K^-1 r
         double wd[J];
 #pragma unroll
         for (int i = 0; i < J; ++i) wd[i] = L.Wt[i] * L.invD;
@@ -351,7 +352,6 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         L.dmin_hi = min(L.dmin_hi, __double2hiint(D));  // sign / zero test on the high dword
         L.invD = mtg_rcp(D);
         L.z = zn;
-        L.dot = fma(zn * zn, L.invD, L.dot);
         L.dprod *= D;  // ln det K = ln prod D_n, exponent peeled off by the caller
     };
     // ln det: the pivot product is renormalised every two steps (D in (1e-70, 1e70))
@@ -378,6 +378,7 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         step(dtA, yvA);
         renorm();
     }
+    L.dot = fma(L.z * L.z, L.invD, L.dot);  // the last sample's term
 }
 
 #define MTG_BLOCK 256
