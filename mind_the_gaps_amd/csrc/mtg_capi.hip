@@ -209,6 +209,8 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
         mtg_solve_launcher fn = mtg_find_solver(nr, nc);
         if (!fn) continue;
         mtg_solve_launcher tp = small ? mtg_find_tp_solver(nr, nc) : nullptr;
+        if (tp && B <= 256 && ctx->N >= 4096 && mtg_find_tp_wide_solver(nr, nc))
+            tp = mtg_find_tp_wide_solver(nr, nc);  // four waves per evaluation
         sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
         sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
         (tp ? tp : fn)(sa, B, s);

@@ -101,6 +101,8 @@ mtg_solve_launcher mtg_find_solver(int nr, int nc);
 // Time-parallel (one wave per evaluation) instantiations, J <= 6 (mtg_timeparallel.hip); the
 // launcher's second argument is the number of evaluations.
 mtg_solve_launcher mtg_find_tp_solver(int nr, int nc);
+// Same with 256 chunks (four waves) per evaluation, J <= 5: for batches of at most a few hundred.
+mtg_solve_launcher mtg_find_tp_wide_solver(int nr, int nc);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
                          const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,

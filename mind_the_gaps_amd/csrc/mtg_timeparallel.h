@@ -32,7 +32,6 @@
 #include <math.h>
 
 #define MTG_LN_2PI 1.8378770664093454835606594728112
-#define MTG_TP_LANES 64
 
 namespace {
 
@@ -583,10 +582,13 @@ __device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
 }  // namespace
 
 // one wave per evaluation; lane = chunk
-template <int NR, int NC, bool FAST>
+// LANES = chunks per evaluation = workgroup size: 64 (one wave) or 256 (four waves, for the
+// smallest batches: the scan then crosses waves through LDS and workgroup barriers)
+template <int NR, int NC, bool FAST, int LANES>
 __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
                                             double icpt, int64_t ev, int64_t lc, const MtgMathTables *tab, double *sh)
 {
+    constexpr int MTG_TP_LANES = LANES;
     constexpr int J = NR + 2 * NC;
     constexpr int ELEM = J * J + 2 * J + J * (J + 1);  // doubles per element
     const int lane = threadIdx.x;
@@ -677,6 +679,13 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
         ld += __shfl_down(ld, off);
         dmin = fmin(dmin, __shfl_down(dmin, off));
     }
+    if (LANES > 64) {  // combine the waves' partial sums through LDS (the element buffer is free now)
+        __syncthreads();
+        if ((lane & 63) == 0) { sh[3 * (lane >> 6)] = dot; sh[3 * (lane >> 6) + 1] = ld; sh[3 * (lane >> 6) + 2] = dmin; }
+        __syncthreads();
+        if (lane == 0)
+            for (int w = 1; w < LANES / 64; ++w) { dot += sh[3 * w]; ld += sh[3 * w + 1]; dmin = fmin(dmin, sh[3 * w + 2]); }
+    }
     if (lane == 0) {
         double ll = -0.5 * (dot + ld + (double)N * MTG_LN_2PI);
         int st = MTG_ST_OK;
@@ -687,10 +696,11 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     }
 }
 
-template <int NR, int NC>
-__global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
+template <int NR, int NC, int LANES>
+__global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;
+    constexpr int MTG_TP_LANES = LANES;
     __shared__ double sh[MTG_TP_LANES * (J * J + 2 * J + J * (J + 1))];
     __shared__ MtgMathTables tab;
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
@@ -724,14 +734,14 @@ __global__ void __launch_bounds__(MTG_TP_LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
     const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
     if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
-        mtg_tp_body<NR, NC, true>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
+        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
     else
-        mtg_tp_body<NR, NC, false>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
+        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
 }
 
-template <int NR, int NC>
+template <int NR, int NC, int LANES = 64>
 static void mtg_launch_tp(const MtgSolveArgs &a, int64_t nevals, hipStream_t stream)
 {
     if (nevals <= 0) return;
-    hipLaunchKernelGGL((mtg_tp_kernel<NR, NC>), dim3((unsigned)nevals), dim3(MTG_TP_LANES), 0, stream, a);
+    hipLaunchKernelGGL((mtg_tp_kernel<NR, NC, LANES>), dim3((unsigned)nevals), dim3(LANES), 0, stream, a);
 }

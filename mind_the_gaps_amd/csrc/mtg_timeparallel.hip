@@ -13,6 +13,21 @@ struct MtgTpSel<NR, NC, false> { static constexpr mtg_solve_launcher fn = nullpt
 static const mtg_solve_launcher mtg_tp_table[7][4] = {MTG_TP_ROW(0), MTG_TP_ROW(1), MTG_TP_ROW(2), MTG_TP_ROW(3),
                                                       MTG_TP_ROW(4), MTG_TP_ROW(5), MTG_TP_ROW(6)};
 
+// 256 chunks per evaluation (four waves) for the smallest batches: J <= 5 (LDS: 256 elements)
+template <int NR, int NC, bool OK = (NR + NC > 0 && NR + 2 * NC <= 5)>
+struct MtgTpWideSel { static constexpr mtg_solve_launcher fn = mtg_launch_tp<NR, NC, 256>; };
+template <int NR, int NC>
+struct MtgTpWideSel<NR, NC, false> { static constexpr mtg_solve_launcher fn = nullptr; };
+#define MTG_TPW_ROW(nr) { MtgTpWideSel<(nr), 0>::fn, MtgTpWideSel<(nr), 1>::fn, MtgTpWideSel<(nr), 2>::fn }
+static const mtg_solve_launcher mtg_tp_wide_table[6][3] = {MTG_TPW_ROW(0), MTG_TPW_ROW(1), MTG_TPW_ROW(2),
+                                                           MTG_TPW_ROW(3), MTG_TPW_ROW(4), MTG_TPW_ROW(5)};
+
+mtg_solve_launcher mtg_find_tp_wide_solver(int nr, int nc)
+{
+    if (nr < 0 || nc < 0 || nr > 5 || nc > 2) return nullptr;
+    return mtg_tp_wide_table[nr][nc];
+}
+
 void mtg_launch_tp_big_0_5(const MtgSolveArgs &, int64_t, hipStream_t);
 void mtg_launch_tp_big_2_4(const MtgSolveArgs &, int64_t, hipStream_t);
 void mtg_launch_tp_big_4_3(const MtgSolveArgs &, int64_t, hipStream_t);

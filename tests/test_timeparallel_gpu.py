@@ -1,5 +1,6 @@
-"""GPU parity of the time-parallel kernel (one wave per evaluation, mtg_timeparallel.hip)
-against the oracle and against the throughput kernel."""
+"""GPU parity of the time-parallel kernel (one wave per evaluation; four waves per evaluation
+for B <= 256, N >= 4096, J <= 5 -- mtg_timeparallel.hip) against the oracle and against the
+throughput kernel."""
 import numpy as np
 import pytest
 
@@ -20,7 +21,7 @@ MODELS = {
 
 
 @pytest.mark.parametrize("name", sorted(MODELS))
-@pytest.mark.parametrize("N", [1, 3, 70, 1000, 4097])
+@pytest.mark.parametrize("N", [1, 3, 70, 1000, 4095, 4096, 4097, 20011])
 def test_time_parallel_vs_oracle(engine, name, N):
     kinds = MODELS[name]
     L, B = 2, 24
