@@ -61,6 +61,7 @@ extern "C" {
 #define MTG_MAX_TERMS 12
 #define MTG_MAX_PARAMS 40     /* full parameter vector: kernel + mean parameters        */
 #define MTG_MAX_J 10          /* celerite rank J = n_real + 2 n_complex                 */
+#define MTG_MAX_WALKERS 4096  /* walkers per ensemble of the device sampler             */
 
 typedef struct mtg_ctx mtg_ctx;
 
@@ -183,7 +184,8 @@ MTG_API int mtg_profile_read(mtg_ctx *ctx, int capacity, double *prepare_ms, dou
  * ensembles of W walkers with state, random numbers (Philox4x32-10 keyed by `seed`)
  * and accept/reject on the GPU; one iteration = 2 x W/2 evaluations per ensemble, no
  * host synchronisation inside mtg_ensemble_run.
- *   coords          [E][W][P] initial walkers (host), e.g. from spread_walkers
+ *   coords          [E][W][P] initial walkers (host), e.g. from spread_walkers; W even,
+ *                   2 P <= W <= MTG_MAX_WALKERS
  *   lc_of_ensemble  [E] light curve of every ensemble; NULL = ensemble e -> light
  *                   curve e (E == L), or all -> 0 when one light curve is resident
  *   chain/lnp_chain [steps][E][W][P] / [steps][E][W] host buffers or NULL (emcee's

@@ -204,16 +204,27 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     const int Jmodel = m.nr0 + 2 * m.nc0;
     const bool small = ctx->tp_mode == 1 ||
                        (ctx->tp_mode == 2 && ctx->N >= 256 && B <= (Jmodel <= 6 ? 1024 : 128));
-    for (int k = 0; k < nsig; ++k) {
-        const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
-        mtg_solve_launcher fn = mtg_find_solver(nr, nc);
-        if (!fn) continue;
-        mtg_solve_launcher tp = small ? mtg_find_tp_solver(nr, nc) : nullptr;
-        if (tp && B <= 256 && ctx->N >= 4096 && mtg_find_tp_wide_solver(nr, nc))
-            tp = mtg_find_tp_wide_solver(nr, nc);  // four waves per evaluation
-        sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
-        sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
-        (tp ? tp : fn)(sa, B, s);
+    const bool wide = B <= 256 && ctx->N >= 4096;  // four waves per evaluation
+    mtg_solve_launcher fused = nullptr;
+    if (small && nsig > 1) {
+        if (wide) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256);
+        if (!fused) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 64);
+    }
+    if (fused) {  // every signature in one launch
+        sa.list = ctx->lists.as<int>();
+        sa.count_ptr = ctx->counts.as<int>();
+        fused(sa, B, s);
+    } else {
+        for (int k = 0; k < nsig; ++k) {
+            const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
+            mtg_solve_launcher fn = mtg_find_solver(nr, nc);
+            if (!fn) continue;
+            mtg_solve_launcher tp = small ? mtg_find_tp_solver(nr, nc) : nullptr;
+            if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
+            sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
+            sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
+            (tp ? tp : fn)(sa, B, s);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
@@ -590,6 +601,8 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
     if (W < 2 * P)
         return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: fewer walkers (%d) than twice the dimension (%d)", W, 2 * P);
     if (E * (int64_t)W > INT32_MAX) return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: too many walkers");
+    if (W > MTG_MAX_WALKERS)
+        return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: at most %d walkers per ensemble", MTG_MAX_WALKERS);
     if (!lc_of_ensemble && E != ctx->L && ctx->L != 1)
         return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: %lld ensembles but %lld light curves and no map",
                     (long long)E, (long long)ctx->L);

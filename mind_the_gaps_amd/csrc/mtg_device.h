@@ -103,6 +103,9 @@ mtg_solve_launcher mtg_find_solver(int nr, int nc);
 mtg_solve_launcher mtg_find_tp_solver(int nr, int nc);
 // Same with 256 chunks (four waves) per evaluation, J <= 5: for batches of at most a few hundred.
 mtg_solve_launcher mtg_find_tp_wide_solver(int nr, int nc);
+// All nsig = (SHO terms + 1) structures (nr0 + 2k, nc0 - k) of a model in one launch: the launcher
+// takes list = base of the per-structure lists, count_ptr = base of the counts; lanes 64 or 256.
+mtg_solve_launcher mtg_find_tp_fused_solver(int nr0, int nc0, int nsig, int lanes);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
                          const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,

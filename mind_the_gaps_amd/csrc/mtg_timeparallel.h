@@ -696,20 +696,11 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     }
 }
 
+// One evaluation `ev` of structure <NR, NC> by the whole workgroup: load its model, pick the
+// trigonometric path, run the three passes.
 template <int NR, int NC, int LANES>
-__global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
+__device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab, double *sh)
 {
-    constexpr int J = NR + 2 * NC;
-    constexpr int MTG_TP_LANES = LANES;
-    __shared__ double sh[MTG_TP_LANES * (J * J + 2 * J + J * (J + 1))];
-    __shared__ MtgMathTables tab;
-    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
-    if ((int64_t)blockIdx.x >= count) return;
-    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
-    if (!a.list && a.status[ev] != MTG_ST_OK) return;
-    mtg_fill_tables(&tab, threadIdx.x, MTG_TP_LANES);
-    __syncthreads();
-
     // ---- model of this evaluation (same on every lane) ------------------------------------
     TpModel<NR, NC> M;
     const double *cf = a.coef + ev;
@@ -734,9 +725,24 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
     const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
     if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
-        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
+        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, sh);
     else
-        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, &tab, sh);
+        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, sh);
+}
+
+template <int NR, int NC, int LANES>
+__global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
+{
+    constexpr int J = NR + 2 * NC;
+    __shared__ double sh[LANES * (J * J + 2 * J + J * (J + 1))];
+    __shared__ MtgMathTables tab;
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if ((int64_t)blockIdx.x >= count) return;
+    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
+    if (!a.list && a.status[ev] != MTG_ST_OK) return;
+    mtg_fill_tables(&tab, threadIdx.x, LANES);
+    __syncthreads();
+    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, sh);
 }
 
 template <int NR, int NC, int LANES = 64>
@@ -744,4 +750,46 @@ static void mtg_launch_tp(const MtgSolveArgs &a, int64_t nevals, hipStream_t str
 {
     if (nevals <= 0) return;
     hipLaunchKernelGGL((mtg_tp_kernel<NR, NC, LANES>), dim3((unsigned)nevals), dim3(LANES), 0, stream, a);
+}
+
+// ---- every signature of a model with SHO terms in ONE launch -------------------------------
+// A model with S SHOTerms has S + 1 structures (NR0 + 2k, NC0 - k), all of rank J; the prepare
+// kernel sorts the evaluations into one list per structure.  Launching the structures one after
+// the other leaves the GPU to a few dozen workgroups S + 1 times; here workgroup b walks the
+// list lengths to find its (structure, evaluation) -- a.list is the base of the lists (stride
+// a.cstride), a.count_ptr the base of the counts -- and the launch has B workgroups.
+template <int NR0, int NC0, int K, int NSIG, int LANES>
+__device__ __forceinline__ void mtg_tp_dispatch(int k, const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab,
+                                                double *sh)
+{
+    if (k == K) mtg_tp_eval<NR0 + 2 * K, NC0 - K, LANES>(a, ev, tab, sh);
+    else if constexpr (K + 1 < NSIG) mtg_tp_dispatch<NR0, NC0, K + 1, NSIG, LANES>(k, a, ev, tab, sh);
+}
+
+template <int NR0, int NC0, int NSIG, int LANES>
+__global__ void __launch_bounds__(LANES, 1) mtg_tp_fused_kernel(MtgSolveArgs a)
+{
+    constexpr int J = NR0 + 2 * NC0;
+    static_assert(NSIG >= 2 && NSIG - 1 <= NC0, "one structure per number of over-damped SHO terms");
+    __shared__ double sh[LANES * (J * J + 2 * J + J * (J + 1))];
+    __shared__ MtgMathTables tab;
+    int64_t r = blockIdx.x;
+    int k = 0;
+    for (; k < NSIG; ++k) {
+        const int64_t c = a.count_ptr[k];
+        if (r < c) break;
+        r -= c;
+    }
+    if (k == NSIG) return;  // beyond the evaluations that passed the prior
+    const int64_t ev = a.list[(int64_t)k * a.cstride + r];
+    mtg_fill_tables(&tab, threadIdx.x, LANES);
+    __syncthreads();
+    mtg_tp_dispatch<NR0, NC0, 0, NSIG, LANES>(k, a, ev, &tab, sh);
+}
+
+template <int NR0, int NC0, int NSIG, int LANES>
+static void mtg_launch_tp_fused(const MtgSolveArgs &a, int64_t nevals, hipStream_t stream)
+{
+    if (nevals <= 0) return;
+    hipLaunchKernelGGL((mtg_tp_fused_kernel<NR0, NC0, NSIG, LANES>), dim3((unsigned)nevals), dim3(LANES), 0, stream, a);
 }

@@ -28,6 +28,20 @@ mtg_solve_launcher mtg_find_tp_wide_solver(int nr, int nc)
     return mtg_tp_wide_table[nr][nc];
 }
 
+mtg_solve_launcher mtg_find_tp_fused_nc1(int nr0, int nsig, int lanes);
+mtg_solve_launcher mtg_find_tp_fused_nc2(int nr0, int nsig, int lanes);
+mtg_solve_launcher mtg_find_tp_fused_nc3(int nr0, int nsig, int lanes);
+
+mtg_solve_launcher mtg_find_tp_fused_solver(int nr0, int nc0, int nsig, int lanes)
+{
+    switch (nc0) {
+    case 1: return mtg_find_tp_fused_nc1(nr0, nsig, lanes);
+    case 2: return mtg_find_tp_fused_nc2(nr0, nsig, lanes);
+    case 3: return mtg_find_tp_fused_nc3(nr0, nsig, lanes);
+    }
+    return nullptr;
+}
+
 void mtg_launch_tp_big_0_5(const MtgSolveArgs &, int64_t, hipStream_t);
 void mtg_launch_tp_big_2_4(const MtgSolveArgs &, int64_t, hipStream_t);
 void mtg_launch_tp_big_4_3(const MtgSolveArgs &, int64_t, hipStream_t);

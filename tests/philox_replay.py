@@ -25,16 +25,10 @@ def u01(hi, lo):
 
 
 def split(E, W, iteration, seed):
-    perm = np.tile(np.arange(W, dtype=np.int64), (E, 1))
-    e = np.arange(E)
-    for i in range(W - 1, 0, -2):
-        r = philox(iteration, SPLIT, e, i, seed)
-        j = (u01(r[0], r[1]) * (i + 1)).astype(np.int64)
-        perm[e, i], perm[e, j] = perm[e, j].copy(), perm[e, i].copy()
-        if i - 1 > 0:
-            j = (u01(r[2], r[3]) * i).astype(np.int64)
-            perm[e, i - 1], perm[e, j] = perm[e, j].copy(), perm[e, i - 1].copy()
-    return perm
+    """Random permutation per ensemble: walkers ranked by their 64-bit Philox key."""
+    r = philox(iteration, SPLIT, np.arange(E)[:, None], np.arange(W)[None, :], seed)
+    keys = (r[0] << np.uint64(32)) | r[1]
+    return np.argsort(keys, axis=1, kind="stable").astype(np.int64)
 
 
 def run(coords, lnp, log_prob_fn, steps, seed, a=2.0, start_iteration=0):

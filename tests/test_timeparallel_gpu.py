@@ -17,7 +17,10 @@ MODELS = {
     "cosinus+drw": [synth.K_COSINUS, synth.K_DRW],
     "matern32+real": [synth.K_MATERN32, synth.K_REAL],
     "3sho": [synth.K_SHO] * 3,
+    "drw+lor+cosinus": [synth.K_DRW, synth.K_LORENTZIAN, synth.K_COSINUS],   # (1, 2) without SHO terms
 }
+# models with SHO terms run every signature in one launch (mtg_tp_fused_kernel): give them mixed ones
+OVERDAMP = {"drw+sho": [3], "drw+sho+lor": [3], "3sho": [4]}
 
 
 @pytest.mark.parametrize("name", sorted(MODELS))
@@ -31,8 +34,10 @@ def test_time_parallel_vs_oracle(engine, name, N):
     engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
     engine.set_model(kinds, full, free, bounds)
     theta = synth.draw_thetas(kinds, B, seed=17)
+    for col in OVERDAMP.get(name, []):
+        theta[::2, col] = np.log(0.3)                     # some over-damped: mixed signatures
     if name == "3sho":
-        theta[::2, 4] = np.log(0.3)                       # some over-damped: mixed signatures
+        theta[::3, 1] = np.log(0.2)
     lc = (np.arange(B) % L).astype(np.int32)
     try:
         engine.set_time_parallel(1)
