@@ -75,6 +75,7 @@ struct mtg_ctx {
     int ens_W = 0, ens_P = 0;
     uint64_t ens_seed = 0;
     uint32_t ens_iteration = 0;
+    int64_t ens_L = 0, ens_N = 0;  // shape of the resident set the ensembles index into
     DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
         ens_naccept, ens_best_lnp, ens_best_coords, ens_notpd, ens_chain, ens_lnp_chain;
 
@@ -331,7 +332,7 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     HIP_TRY(ctx, ctx->y_tmp.reserve((size_t)L * N * 8));
     HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)L * N * 8));
     HIP_TRY(ctx, ctx->dxmax.reserve(64));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dxmax.p, 0, 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dxmax.p, 0, 16, ctx->stream));  // [0] max dx, [1] "unsorted" flag
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t_tmp.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->y_tmp.p, y, (size_t)L * N * 8, kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr, (size_t)L * N * 8, kind, ctx->stream));
@@ -345,7 +346,13 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
                         ctx->dy_tmp.as<double>(), d_off, ctx->dxt.as<double2>(), ctx->yv.as<double2>(),
                         ctx->dxmax.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
+    uint64_t flags[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->dxmax.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags[1]) {  // device-resident times cannot be checked on the host
+        ctx->N = 0; ctx->L = 0;
+        return fail(ctx, MTG_E_ARG, "the input coordinates must be sorted");
+    }
     ctx->N = N; ctx->L = L; ctx->t_per_lc = t_per_lc ? 1 : 0;
     return MTG_OK;
 }
@@ -644,6 +651,7 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));  // lc_full / lc_half live on this stack frame
     ctx->ens_E = E; ctx->ens_W = W; ctx->ens_P = P; ctx->ens_seed = seed; ctx->ens_iteration = 0;
+    ctx->ens_L = ctx->L; ctx->ens_N = ctx->N;
     return MTG_OK;
 }
 
@@ -654,6 +662,8 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     if (ctx->ens_E <= 0) return fail(ctx, MTG_E_STATE, "mtg_ensemble_init has not been called");
     if (steps < 0) return fail(ctx, MTG_E_ARG, "mtg_ensemble_run: negative step count");
     if (ctx->ens_P != ctx->model.P) return fail(ctx, MTG_E_STATE, "the model changed since mtg_ensemble_init");
+    if (ctx->ens_L != ctx->L || ctx->ens_N != ctx->N)
+        return fail(ctx, MTG_E_STATE, "the resident light curves changed shape since mtg_ensemble_init");
     rc = use_device(ctx);
     if (rc) return rc;
     const int E = (int)ctx->ens_E, W = ctx->ens_W, P = ctx->ens_P, H = W / 2;
@@ -724,6 +734,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
     int rc = check_ready(ctx, true);
     if (rc) return rc;
     const int64_t N = ctx->N;
+    if (nfft > ((int64_t)1 << 30)) return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: nfft above 2^30");
     if (S <= 0 || nfft < 4 || !(sim_dt > 0.0) || seg_len <= 0 || seg_len > nfft || !win_lo || !win_hi || !rates || !dy ||
         (!theta && ctx->model.P > 0))
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad arguments");

@@ -43,14 +43,17 @@ mtg_lc_setup_kernel(int64_t N, int64_t L, int64_t t_rows, const double *__restri
         yv[i] = make_double2(y[i] - mu, s * s);
     }
     double mx = 0.0;
+    bool sorted = true;
     for (int64_t i = i0; i < t_rows * N; i += stride) {
         const int64_t n = i % N;
         const double d = n == 0 ? 0.0 : t[i] - t[i - 1];
         dxt[i] = make_double2(d, t[i]);
+        sorted = sorted && d >= 0.0;  // NaN times count as unsorted
         mx = fmax(mx, d);
     }
     // max over the grid: non-negative doubles order like their bit patterns
     atomicMax(dxmax_bits, (unsigned long long)__double_as_longlong(mx));
+    if (!sorted) dxmax_bits[1] = 1ull;  // celerite.GP.compute raises ValueError for unsorted times
 }
 
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
@@ -449,6 +452,9 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     int st = MTG_ST_OK;
     if (L.dmin_hi <= 0) { st = MTG_ST_NOTPD; ll = -INFINITY; }
     else if (!isfinite(ll)) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
+    // a device-side lc_index outside the resident set (the host cannot see it): the buffer loads
+    // returned zeros instead of faulting; do not report a likelihood for them
+    if (((uint64_t)lc + 1u) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
     a.out[e] = ll;
     a.status[e] = st;
 }

@@ -724,6 +724,12 @@ __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, c
     const double jitter = cf[a.lay.asum() * cs] - ksum;
     const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
     const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+    // a device-side lc_index cannot be validated by the host: this kernel reads through raw
+    // pointers (the throughput kernel's buffer loads are bounds-checked by the hardware)
+    if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) {
+        if (threadIdx.x == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
+        return;
+    }
     if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
         mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, sh);
     else

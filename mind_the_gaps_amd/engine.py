@@ -6,7 +6,9 @@ entry point raises (``EngineUnavailable``) -- a likelihood is never computed
 on the host.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -46,11 +48,37 @@ _ip = ctypes.POINTER(ctypes.c_int32)
 _lib = None
 
 
+def _adopt_pytorch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 /
+    libhsa-runtime64 (RPATH $ORIGIN, same SONAMEs as /opt/rocm's); if libmtg_hip.so pulled in
+    the system copies first, a later `import torch` would bring a second runtime that finds the
+    GPUs taken ("No HIP GPUs are available").  So when PyTorch is installed, its copies are
+    loaded first -- located without importing torch -- and the dynamic linker resolves
+    libmtg_hip.so's libamdhip64.so.7 / libhipfft.so.0 to them by SONAME."""
+    if "torch" in sys.modules:
+        return  # already resident: the linker will reuse torch's copies
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libamdhip64.so", "libhipfft.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return  # a broken wheel is torch's problem; fall back to /opt/rocm
+
+
 def load_library():
     """dlopen libmtg_hip.so and declare the prototypes (no GPU needed)."""
     global _lib
     if _lib is not None:
         return _lib
+    _adopt_pytorch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -111,3 +111,74 @@ def test_single_sample_and_two_samples(engine):
         t, y, dy = synth.make_lightcurves(N, 1, seed=6 + N)
         thetas = synth.draw_thetas(synth.ALT_MODEL, 4, seed=1)
         hip_vs_dense(engine, synth.ALT_MODEL, t, y[0], dy[0], thetas, float(np.mean(y)))
+
+
+def test_device_pointer_entry_points(engine):
+    """mtg_set_lightcurves_device / mtg_loglike_batch_device (torch tensors as the owner of
+    the device memory) against the host-pointer calls; device-side argument checks."""
+    import torch
+    from mind_the_gaps_amd.engine import EngineError
+    kinds = synth.NULL_MODEL
+    N, L, B = 300, 3, 40
+    t, y, dy = synth.make_lightcurves(N, L, seed=31)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    off = y.mean(axis=1)
+    theta = synth.draw_thetas(kinds, B, seed=2)
+    lc = (np.arange(B) % L).astype(np.int32)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=off)
+    engine.set_model(kinds, full, free, bounds)
+    ref, rst = engine.loglike(theta, lc)
+
+    dev = torch.device("cuda:0")
+    d_t, d_y, d_dy, d_off = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (t, y, dy + 1e-12, off))
+    engine.set_lightcurves_device(N, L, d_t.data_ptr(), d_y.data_ptr(), d_dy.data_ptr(), t_per_lc=False,
+                                  y_offset_ptr=d_off.data_ptr())
+    d_theta, d_lc = torch.from_numpy(theta).to(dev), torch.from_numpy(lc).to(dev)
+    d_out = torch.empty(B, dtype=torch.float64, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for mode in (0, 1):                                      # throughput and time-parallel kernels
+        try:
+            engine.set_time_parallel(mode)
+            engine.loglike_device(B, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(), d_st.data_ptr())
+            engine.synchronize()
+        finally:
+            engine.set_time_parallel(2)
+        assert np.array_equal(d_st.cpu().numpy(), rst)
+        assert np.allclose(d_out.cpu().numpy(), ref, rtol=1e-10, atol=0)
+
+    # a light-curve index the host cannot see: no fault, a non-OK status
+    bad = torch.full((B,), 7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for mode in (0, 1):
+        try:
+            engine.set_time_parallel(mode)
+            engine.loglike_device(B, d_theta.data_ptr(), bad.data_ptr(), d_out.data_ptr(), d_st.data_ptr())
+            engine.synchronize()
+        finally:
+            engine.set_time_parallel(2)
+        assert np.all(d_st.cpu().numpy() != 0) and np.all(np.isneginf(d_out.cpu().numpy()))
+
+    # unsorted device-resident times are found by the set-up kernel
+    d_bad_t = torch.from_numpy(np.ascontiguousarray(t[::-1])).to(dev)
+    torch.cuda.synchronize()
+    with pytest.raises(EngineError, match="sorted"):
+        engine.set_lightcurves_device(N, L, d_bad_t.data_ptr(), d_y.data_ptr(), d_dy.data_ptr())
+    engine.set_lightcurves(t, y, dy + 1e-12)
+
+
+def test_ensemble_guards(engine):
+    from mind_the_gaps_amd.engine import EngineError
+    kinds = [synth.K_DRW]
+    t, y, dy = synth.make_lightcurves(100, 2, seed=8)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, free, bounds)
+    p0 = np.stack([synth.draw_thetas(kinds, 8, seed=s) for s in (1, 2)])
+    engine.ensemble_init(p0, seed=3)
+    engine.ensemble_run(2)
+    engine.set_lightcurves(t, y[:1], dy[:1] + 1e-12)          # the ensembles index light curve 1
+    with pytest.raises(EngineError, match="changed shape"):
+        engine.ensemble_run(1)
+    with pytest.raises(EngineError, match="walkers"):
+        engine.ensemble_init(np.zeros((1, 4098, 2)), seed=1)
