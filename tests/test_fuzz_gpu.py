@@ -1,0 +1,83 @@
+"""Seeded random sweep of the HIP path against the oracle: random sums of terms (every term
+kind, J <= 10), sizes, batch shapes, light-curve maps, priors on/off, both kernels (throughput
+and time-parallel).  Tolerance 1e-8 relative (BASELINE.json north_star); statuses must agree."""
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import synthetic as synth
+from oracle import celerite as oracle_c
+
+pytestmark = pytest.mark.gpu
+
+RANK = {synth.K_REAL: 1, synth.K_DRW: 1, synth.K_JITTER: 0}   # everything else is one complex term (2)
+
+
+def random_model(rng, jmax, ncmax):
+    pool = [synth.K_REAL, synth.K_COMPLEX3, synth.K_COMPLEX4, synth.K_SHO, synth.K_MATERN32, synth.K_JITTER,
+            synth.K_DRW, synth.K_LORENTZIAN, synth.K_COSINUS, synth.K_BPL]
+    while True:
+        kinds = list(rng.choice(pool, size=rng.integers(1, 7)))
+        nr = sum(1 for k in kinds if RANK.get(k, 2) == 1)
+        nc = sum(1 for k in kinds if RANK.get(k, 2) == 2)
+        # compiled structures: J <= 10, at most 5 complex terms; the time-parallel kernel J <= 6
+        if 0 < nr + nc and nr + 2 * nc <= jmax and nc <= ncmax and kinds.count(synth.K_JITTER) <= 1:
+            return [int(k) for k in kinds]
+
+
+@pytest.mark.parametrize("case", range(120))
+def test_random_model_vs_oracle(engine, case):
+    rng = np.random.default_rng(9000 + case)
+    tp_mode = int(rng.integers(0, 2))
+    kinds = random_model(rng, *((6, 3) if tp_mode else (10, 5)))
+    linear_mean = bool(rng.integers(0, 3) == 0)
+    N = int(rng.choice([1, 2, 5, 37, 256, 257, 800, 2500, 4096, 5001]))
+    L = int(rng.integers(1, 5))
+    B = int(rng.choice([1, 3, 64, 65, 200, 700]))
+    per_lc_t = bool(rng.integers(0, 2)) and L > 1
+    add_prior = bool(rng.integers(0, 2))
+    t, y, dy = synth.make_lightcurves(N, L, seed=1000 + case)
+    if per_lc_t:
+        t = np.vstack([synth.make_times(N, rng, offset=float(10 * i)) for i in range(L)])
+    if linear_mean:   # fitted LinearModel mean: two more free parameters (slope, intercept), no y_offset
+        y = y + 0.01 * (t - t.min())
+        full, free, bounds = synth.model_spec(kinds, y, mean_kind=1, fit_mean=True)
+        y_mean = None
+    else:
+        full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+        y_mean = y.mean(axis=1)
+    theta = synth.draw_thetas(kinds, B, seed=case, percent=0.25)
+    # push a few rows across SHO's Q = 1/2 and outside the box
+    off = 0
+    for k in kinds:
+        if k == synth.K_SHO:
+            theta[rng.random(B) < 0.4, off + 1] = np.log(rng.uniform(0.05, 0.45))
+        off += synth.NPARAMS[k]
+    theta[rng.random(B) < 0.1, 0] = 60.0
+    lc = rng.integers(0, L, B).astype(np.int32)
+    if linear_mean:
+        theta = np.hstack([theta, 0.01 + 0.002 * rng.standard_normal((B, 1)), 100.0 + rng.standard_normal((B, 1))])
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds, mean_kind=1 if linear_mean else 0)
+    try:
+        engine.set_time_parallel(tp_mode)
+        out, st = engine.loglike(theta, lc, add_prior=add_prior)
+    finally:
+        engine.set_time_parallel(2)
+    full_b = theta if linear_mean else np.hstack([theta, y_mean[lc][:, None]])
+    okw = dict(bounds=bounds, add_prior=add_prior, nthreads=4, mean_kind=1 if linear_mean else 0)
+    if per_lc_t:
+        ref, rst = np.empty(B), np.empty(B, dtype=np.int32)
+        for l in range(L):
+            sel = lc == l
+            if sel.any():
+                ref[sel], rst[sel] = oracle_c.logprob_batch(t[l], y[l], dy[l], kinds, full_b[sel], **okw)
+    else:
+        ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, full_b, lc_index=lc, **okw)
+    label = "kinds=%s N=%d L=%d B=%d per_lc_t=%s prior=%s tp=%d linear_mean=%s" % (
+        kinds, N, L, B, per_lc_t, add_prior, tp_mode, linear_mean)
+    assert np.array_equal(st, rst), label
+    ok = st == 0
+    assert np.all(np.isneginf(out[~ok])), label
+    if ok.any():
+        err = np.max(np.abs(out[ok] - ref[ok]) / np.abs(ref[ok]))
+        assert err <= 1e-8, "%s: %.3g" % (label, err)
