@@ -200,11 +200,14 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     // per-light-curve frozen mean lives in y_offset)
     sa.has_mean = !(m.mean_kind == MTG_MEAN_CONSTANT && m.src[m.nk] < 0 && m.defaults[m.nk] == 0.0);
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
-    // steps: give every evaluation a whole wave instead (mtg_timeparallel.hip).
-    // (measured crossovers: J <= 6 elements live in registers, the J = 10 ones spill to scratch)
+    // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip).
+    // Measured crossovers: J <= 6 (elements in registers) pays up to ~1000 evaluations; the J = 10
+    // kernels (elements spill, 64 chunks only) cost ~0.14 us x N + 0.6 ms per 256 evaluations against
+    // ~1.05 us x N for the serial sweep.
     const int Jmodel = m.nr0 + 2 * m.nc0;
-    const bool small = ctx->tp_mode == 1 ||
-                       (ctx->tp_mode == 2 && ctx->N >= 256 && B <= (Jmodel <= 6 ? 1024 : 128));
+    const bool pays = Jmodel <= 6 ? (ctx->N >= 256 && B <= 1024)
+                                  : ((ctx->N >= 1024 && B <= 256) || (ctx->N >= 8192 && B <= 1024));
+    const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
     const bool wide = B <= 256 && ctx->N >= 4096;  // four waves per evaluation
     mtg_solve_launcher fused = nullptr;
     if (small && nsig > 1) {

@@ -12,8 +12,8 @@
 // D_n = h^T C_n h + sigma_n^2 and residuals z_n (lnL = -1/2 sum(ln 2 pi D_n + z_n^2/D_n)).
 // The filter recursion is made parallel with the associative filtering elements of
 // Sarkka & Garcia-Fernandez (2021): the N samples are cut into 64 chunks, one per lane;
-//   pass 1  every lane composes the elements (A, b, C, eta, J) of its chunk -- a
-//           rank-one (Sherman-Morrison) composition per step, O(J^2);
+//   pass 1  every lane composes the element (A, b, C, eta, J) of its chunk: a Kalman filter
+//           started from (0, 0) that also carries A, eta and J along, O(J^2) per step;
 //   pass 2  an inclusive scan of the 64 chunk elements across the lanes (Hillis-Steele through
 //           LDS, six rounds of the general element combination, one J x J inverse each);
 //           every lane then applies the prefix of the earlier chunks to the state after
@@ -121,37 +121,79 @@ __device__ __forceinline__ void tp_left_F(const TpTrans<NR, NC> &T, double (&X)[
     }
 }
 
-// C <- F C F^T + Q with Q = P_inf - F P_inf F^T, i.e. C <- P_inf + F (C - P_inf) F^T
+// Covariances are propagated as their deviation from the stationary one, Dv = C - P_inf: the
+// prediction C <- F C F^T + Q with Q = P_inf - F P_inf F^T is then Dv <- F Dv F^T, done block by
+// block of the (real | 2-d complex) structure of F on the lower triangle only.
 template <int NR, int NC, int J>
-__device__ __forceinline__ void tp_predict_cov(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, Sym<J> &C)
+__device__ __forceinline__ void tp_sub_pinf(const TpModel<NR, NC> &M, Sym<J> &C)
 {
-    double X[J][J];
 #pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) X[i][j] = C(i, j);
-    // subtract P_inf (block diagonal)
-#pragma unroll
-    for (int j = 0; j < NR; ++j) X[j][j] -= M.ar[j];
+    for (int j = 0; j < NR; ++j) C(j, j) -= M.ar[j];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         const int o = NR + 2 * k;
-        X[o][o] -= M.ac[k]; X[o][o + 1] += M.bc[k]; X[o + 1][o] += M.bc[k]; X[o + 1][o + 1] -= M.pc[k];
+        C(o, o) -= M.ac[k]; C(o + 1, o) += M.bc[k]; C(o + 1, o + 1) -= M.pc[k];
     }
-    tp_left_F<NR, NC, J>(T, X);  // F X
-    // (F X) F^T: F acts on the columns -> apply F to every row
-#pragma unroll
-    for (int i = 0; i < J; ++i) tp_apply_F<NR, NC>(T, X[i]);
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) C(i, j) = 0.5 * (X[i][j] + X[j][i]);
+}
+
+template <int NR, int NC, int J>
+__device__ __forceinline__ void tp_add_pinf(const TpModel<NR, NC> &M, Sym<J> &C)
+{
 #pragma unroll
     for (int j = 0; j < NR; ++j) C(j, j) += M.ar[j];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         const int o = NR + 2 * k;
         C(o, o) += M.ac[k]; C(o + 1, o) -= M.bc[k]; C(o + 1, o + 1) += M.pc[k];
+    }
+}
+
+template <int NR, int NC, int J>
+__device__ __forceinline__ void tp_predict_dev(const TpTrans<NR, NC> &T, Sym<J> &Dv)
+{
+    // real x real
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Dv(i, j) *= T.phi[i] * T.phi[j];
+    // complex x real: a 2-vector rotated by F_k and scaled by phi_j
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int o = NR + 2 * k;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const double ecj = T.ec[k] * T.phi[j], esj = T.es[k] * T.phi[j];
+            const double x0 = Dv(o, j), x1 = Dv(o + 1, j);
+            Dv(o, j) = ecj * x0 - esj * x1;
+            Dv(o + 1, j) = esj * x0 + ecj * x1;
+        }
+    }
+    // complex k x complex l < k: full 2 x 2 block B <- F_k B F_l^T
+#pragma unroll
+    for (int k = 1; k < NC; ++k) {
+        const int ok = NR + 2 * k;
+#pragma unroll
+        for (int l = 0; l < k; ++l) {
+            const int ol = NR + 2 * l;
+            const double b00 = Dv(ok, ol), b01 = Dv(ok, ol + 1), b10 = Dv(ok + 1, ol), b11 = Dv(ok + 1, ol + 1);
+            const double y00 = T.ec[k] * b00 - T.es[k] * b10, y01 = T.ec[k] * b01 - T.es[k] * b11;
+            const double y10 = T.es[k] * b00 + T.ec[k] * b10, y11 = T.es[k] * b01 + T.ec[k] * b11;
+            Dv(ok, ol) = y00 * T.ec[l] - y01 * T.es[l];
+            Dv(ok, ol + 1) = y00 * T.es[l] + y01 * T.ec[l];
+            Dv(ok + 1, ol) = y10 * T.ec[l] - y11 * T.es[l];
+            Dv(ok + 1, ol + 1) = y10 * T.es[l] + y11 * T.ec[l];
+        }
+    }
+    // complex k x complex k: symmetric 2 x 2 block
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int o = NR + 2 * k;
+        const double d00 = Dv(o, o), d10 = Dv(o + 1, o), d11 = Dv(o + 1, o + 1);
+        const double y00 = T.ec[k] * d00 - T.es[k] * d10, y01 = T.ec[k] * d10 - T.es[k] * d11;
+        const double y10 = T.es[k] * d00 + T.ec[k] * d10, y11 = T.es[k] * d10 + T.ec[k] * d11;
+        Dv(o, o) = y00 * T.ec[k] - y01 * T.es[k];
+        Dv(o + 1, o) = y10 * T.ec[k] - y11 * T.es[k];
+        Dv(o + 1, o + 1) = y10 * T.es[k] + y11 * T.ec[k];
     }
 }
 
@@ -181,25 +223,32 @@ __device__ __forceinline__ void tp_C_h(const Sym<J> &C, double *out)
     }
 }
 
-// one Kalman filter step from the FILTERED state of the previous sample:
-// predict with T, update with (r, R); returns the pivot D and the residual z
+// One Kalman filter step from the FILTERED state of the previous sample (mean m, covariance
+// P_inf + Dv): predict with T, update with (r, R).  Returns the pivot D, its reciprocal, the
+// residual z and the gain kd = (P_pred h) / D.
 template <int NR, int NC, int J>
 __device__ __forceinline__ void tp_filter_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double r, double R,
-                                               double *m, Sym<J> &C, double &D, double &z)
+                                               double *m, Sym<J> &Dv, double &D, double &inv, double &z, double *kd)
 {
     tp_apply_F<NR, NC>(T, m);
-    tp_predict_cov<NR, NC, J>(M, T, C);
-    double ch[J];
-    tp_C_h<NR, NC, J>(C, ch);
+    tp_predict_dev<NR, NC, J>(T, Dv);
+    double ch[J];  // (P_inf + Dv) h
+    tp_C_h<NR, NC, J>(Dv, ch);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) ch[j] += M.ar[j];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { ch[NR + 2 * k] += M.ac[k]; ch[NR + 2 * k + 1] -= M.bc[k]; }
     D = tp_h_dot<NR, NC>(ch) + R;
     z = r - tp_h_dot<NR, NC>(m);
-    const double inv = 1.0 / D;
+    inv = mtg_rcp(D);
 #pragma unroll
-    for (int i = 0; i < J; ++i) m[i] = fma(ch[i], z * inv, m[i]);
+    for (int i = 0; i < J; ++i) kd[i] = ch[i] * inv;
+#pragma unroll
+    for (int i = 0; i < J; ++i) m[i] = fma(kd[i], z, m[i]);
 #pragma unroll
     for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j <= i; ++j) C(i, j) = fma(-ch[i] * inv, ch[j], C(i, j));
+        for (int j = 0; j <= i; ++j) Dv(i, j) = fma(-kd[i], ch[j], Dv(i, j));
 }
 
 // filtering element of a chunk: x_out | x_in ~ N(A x_in + b, C), p(y_chunk | x_in) ~ N_I(eta, Jm)
@@ -222,116 +271,42 @@ __device__ __forceinline__ void tp_identity(TpElem<J> &e)
     for (int i = 0; i < J * (J + 1) / 2; ++i) { e.C.v[i] = 0.0; e.Jm.v[i] = 0.0; }
 }
 
-// e <- e o step(T, r, R): the single-step element has a rank-one information part, so the
-// composition is Sherman-Morrison algebra, O(J^2) (see the header of this file)
+// e <- e o step(T, r, R).  Combining an element with a single-step element is the Kalman filter
+// itself: (b, C) of the chunk are the mean and covariance of the filter started from (0, 0), and
+// with K its gain, g = (h F A)^T, D its pivot and z its residual,
+//   A <- (I - K h) F A,   eta <- eta + g z / D,   Jm <- Jm + g g^T / D
+// (the general combination's (I + C J)^-1 with the step's rank-one J is that filter update).
+// Dv = C - P_inf is carried by the caller across the steps of a chunk.
 template <int NR, int NC, int J>
 __device__ __forceinline__ void tp_compose_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double y, double R,
-                                                TpElem<J> &e)
+                                                TpElem<J> &e, Sym<J> &Dv)
 {
-    // single-step quantities: Q = P_inf - F P_inf F^T, S2 = h^T Q h + R, K2 = Q h / S2, v = F^T h
-    Sym<J> Q;
-#pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) Q.v[i] = 0.0;
-    tp_predict_cov<NR, NC, J>(M, T, Q);  // with C = 0: P_inf - F P_inf F^T
-    double qh[J];
-    tp_C_h<NR, NC, J>(Q, qh);
-    const double S2 = tp_h_dot<NR, NC>(qh) + R;
-    double K2[J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) K2[i] = qh[i] / S2;
-    double v[J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) v[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) v[j] = 1.0;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) v[NR + 2 * k] = 1.0;
-    tp_apply_Ft<NR, NC>(T, v);
-    // u = C1 v, gamma = S2 + v^T u, a = A1^T v, va = v^T A1 (row vector)
-    double u[J], a[J];
-    double gamma = S2;
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < J; ++j) s = fma(e.C(i, j), v[j], s);
-        u[i] = s;
-        gamma = fma(v[i], s, gamma);
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < J; ++i) s = fma(e.A[i][j], v[i], s);
-        a[j] = s;
-    }
-    const double ig = 1.0 / gamma;
-    double vb = 0.0;
-#pragma unroll
-    for (int i = 0; i < J; ++i) vb = fma(v[i], e.b[i], vb);
-    // information part first (uses the OLD A1, b1)
-    const double kappa = (y - vb) * ig;
-#pragma unroll
-    for (int i = 0; i < J; ++i) e.eta[i] = fma(a[i], kappa, e.eta[i]);
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) e.Jm(i, j) = fma(a[i] * ig, a[j], e.Jm(i, j));
-    // XA = A1 - u a^T / gamma ; Xb = w - u (v^T w) / gamma with w = b1 + u y / S2 ; XC = C1 - u u^T / gamma
-    double w[J], vw = 0.0;
-#pragma unroll
-    for (int i = 0; i < J; ++i) { w[i] = fma(u[i], y / S2, e.b[i]); vw = fma(v[i], w[i], vw); }
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        w[i] = fma(-u[i], vw * ig, w[i]);
-#pragma unroll
-        for (int j = 0; j < J; ++j) e.A[i][j] = fma(-u[i] * ig, a[j], e.A[i][j]);
-    }
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) e.C(i, j) = fma(-u[i] * ig, u[j], e.C(i, j));
-    // A <- (I - K2 h^T) F XA ; b <- (I - K2 h^T) F Xb + K2 y
     tp_left_F<NR, NC, J>(T, e.A);
+    double g[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        double hg = 0.0;  // h^T (F XA)[:, j]
-#pragma unroll
-        for (int r = 0; r < NR; ++r) hg += e.A[r][j];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) hg += e.A[NR + 2 * k][j];
-#pragma unroll
-        for (int i = 0; i < J; ++i) e.A[i][j] = fma(-K2[i], hg, e.A[i][j]);
-    }
-    tp_apply_F<NR, NC>(T, w);
-    const double hw = tp_h_dot<NR, NC>(w);
-#pragma unroll
-    for (int i = 0; i < J; ++i) e.b[i] = fma(K2[i], y - hw, w[i]);
-    // C <- (I - K2 h^T) F XC F^T (I - h K2^T) + C2,  C2 = Q - K2 K2^T S2
-    double X[J][J];
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) X[i][j] = e.C(i, j);
-    tp_left_F<NR, NC, J>(T, X);
-#pragma unroll
-    for (int i = 0; i < J; ++i) tp_apply_F<NR, NC>(T, X[i]);
-    double th[J], hth = 0.0;  // T h and h^T T h for T = F XC F^T
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
         double s = 0.0;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) s += X[i][r];
+        for (int r = 0; r < NR; ++r) s += e.A[r][j];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) s += X[i][NR + 2 * k];
-        th[i] = s;
+        for (int k = 0; k < NC; ++k) s += e.A[NR + 2 * k][j];
+        g[j] = s;
     }
-    hth = tp_h_dot<NR, NC>(th);
+    double D, inv, z, kd[J];
+    tp_filter_step<NR, NC, J>(M, T, y, R, e.b, Dv, D, inv, z, kd);
 #pragma unroll
     for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j <= i; ++j)
-            e.C(i, j) = 0.5 * (X[i][j] + X[j][i]) - K2[i] * th[j] - th[i] * K2[j] + K2[i] * K2[j] * (hth - S2) + Q(i, j);
+        for (int j = 0; j < J; ++j) e.A[i][j] = fma(-kd[i], g[j], e.A[i][j]);
+    const double zi = z * inv;
+#pragma unroll
+    for (int j = 0; j < J; ++j) e.eta[j] = fma(g[j], zi, e.eta[j]);
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const double gi = g[i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) e.Jm(i, j) = fma(gi, g[j], e.Jm(i, j));
+    }
 }
 
 // (m, C) <- element applied to the filtered state (m, C):
@@ -401,11 +376,181 @@ __device__ __forceinline__ void tp_apply_elem(const TpElem<J> &e, double *m, Sym
         }
 }
 
+// View of an element stored by tp_store (A | b | eta | C | Jm)
+template <int J> struct TpSlot {
+    double *p;
+    static constexpr int OB = J * J, OE = OB + J, OC = OE + J, OJ = OC + J * (J + 1) / 2;
+    __device__ __forceinline__ static int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+    __device__ __forceinline__ double &A(int i, int j) const { return p[i * J + j]; }
+    __device__ __forceinline__ double &b(int i) const { return p[OB + i]; }
+    __device__ __forceinline__ double &eta(int i) const { return p[OE + i]; }
+    __device__ __forceinline__ double &C(int i, int j) const { return p[OC + tri(i, j)]; }
+    __device__ __forceinline__ double &Jm(int i, int j) const { return p[OJ + tri(i, j)]; }
+};
+
 // e2 <- e1 o e2 (e1 earlier in time): the general combination of two filtering elements
 //   G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2
 //   eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1
+// e1 is in registers (it had to be read before the barrier); e2 stays in this lane's own LDS
+// slot and is read and overwritten piece by piece: both in registers would be 4 J (J + 1.5)
+// VGPRs plus the temporaries and spill to scratch from J = 5 on.
+// G^-T J2 = (J2^-1 + C1)^-1 and G^-1 C1 are symmetric, so the two congruences fill one triangle.
 template <int J>
-__device__ __forceinline__ void tp_combine(const TpElem<J> &e1, TpElem<J> &e2)
+__device__ __forceinline__ void tp_combine(const TpElem<J> &e1, double *slot2)
+{
+    const TpSlot<J> e2{slot2};
+    // Gi = (I + C1 J2)^-1 by Gauss-Jordan (similar to a symmetric positive definite matrix: no pivoting)
+    double G[J][J], Gi[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double g = i == j ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) g = fma(e1.C(i, k), e2.Jm(k, j), g);
+            G[i][j] = g;
+            Gi[i][j] = i == j ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+        const double ip = 1.0 / G[p][p];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { G[p][j] *= ip; Gi[p][j] *= ip; }
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            if (i == p) continue;
+            const double f = G[i][p];
+#pragma unroll
+            for (int j = 0; j < J; ++j) { G[i][j] = fma(-f, G[p][j], G[i][j]); Gi[i][j] = fma(-f, Gi[p][j], Gi[i][j]); }
+        }
+    }
+    // w = b1 + C1 eta2 (state part, needs the OLD eta2)
+    double w[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = e1.b[i];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(e1.C(i, k), e2.eta(k), s);
+        w[i] = s;
+    }
+    // ---- information part: eta, Jm (uses A1, b1, eta1, J1 and the OLD eta2, J2) ------------
+    {
+        double t[J], yeta[J];
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double s = e2.eta(i);
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(-e2.Jm(i, k), e1.b[k], s);
+            t[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < J; ++i) {  // G^-T t
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(Gi[k][i], t[k], s);
+            yeta[i] = s;
+        }
+        double YJ[J][J], Z[J][J];  // YJ = G^-T J2 ; Z = YJ A1
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) s = fma(Gi[k][i], e2.Jm(k, j), s);
+                YJ[i][j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) s = fma(YJ[i][k], e1.A[k][j], s);
+                Z[i][j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double s = e1.eta[i];
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(e1.A[k][i], yeta[k], s);
+            e2.eta(i) = s;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double u = e1.Jm(i, j);
+#pragma unroll
+                for (int k = 0; k < J; ++k) u = fma(e1.A[k][i], Z[k][j], u);
+                e2.Jm(i, j) = u;
+            }
+        }
+    }
+    // ---- state part: XA = Gi A1, Xb = Gi w, XC = Gi C1 ---------------------------------------
+    double Xb[J], XA[J][J], XC[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(Gi[i][k], w[k], s);
+        Xb[i] = s;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) { a = fma(Gi[i][k], e1.A[k][j], a); c = fma(Gi[i][k], e1.C(k, j), c); }
+            XA[i][j] = a;
+            XC[i][j] = c;
+        }
+    }
+    // C <- A2 XC A2^T + C2 (needs the OLD A2), then A <- A2 XA and b <- A2 Xb + b2 row by row
+    double A2[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) A2[i][j] = e2.A(i, j);
+    {
+        double Y[J][J];
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double c = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) c = fma(A2[i][k], XC[k][j], c);
+                Y[i][j] = c;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double u = e2.C(i, j);
+#pragma unroll
+                for (int k = 0; k < J; ++k) u = fma(Y[i][k], A2[j][k], u);
+                e2.C(i, j) = u;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = e2.b(i);
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(A2[i][k], Xb[k], s);
+        e2.b(i) = s;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) a = fma(A2[i][k], XA[k][j], a);
+            e2.A(i, j) = a;
+        }
+    }
+}
+
+// The same combination with both elements in registers: for J = 10 neither variant fits the
+// register file, and the compiler's scratch spills of this one are cheaper than re-reading e2's
+// entries from LDS inside the J^3 loops.
+//   G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2
+//   eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1
+template <int J>
+__device__ __forceinline__ void tp_combine_regs(const TpElem<J> &e1, TpElem<J> &e2)
 {
     // Gi = (I + C1 J2)^-1 by Gauss-Jordan (similar to a symmetric positive definite matrix: no pivoting)
     double G[J][J], Gi[J][J];
@@ -605,12 +750,14 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     // ---- pass 1: element of the chunk ---------------------------------------------------
     TpElem<J> e;
     tp_identity<J>(e);
+    tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
     for (int64_t n = lo; n < hi; ++n) {
         TpTrans<NR, NC> T;
         tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
         const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
-        tp_compose_step<NR, NC, J>(M, T, r, yv[n].y + jitter, e);
+        tp_compose_step<NR, NC, J>(M, T, r, yv[n].y + jitter, e, e.C);
     }
+    tp_add_pinf<NR, NC, J>(M, e.C);
 
     // ---- pass 2: inclusive scan of the 64 chunk elements (Hillis-Steele through LDS) ------
     double *buf = sh;
@@ -621,8 +768,12 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
         if (lane >= off) tp_load<J>(prev, buf + (lane - off) * ELEM);
         __syncthreads();  // everybody has read its partner before anybody overwrites
         if (lane >= off) {
-            tp_combine<J>(prev, e);
-            tp_store<J>(e, buf + lane * ELEM);
+            if (J <= 6) {
+                tp_combine<J>(prev, buf + lane * ELEM);  // own element stays in its LDS slot
+            } else {
+                tp_combine_regs<J>(prev, e);
+                tp_store<J>(e, buf + lane * ELEM);
+            }
         }
         __syncthreads();
     }
@@ -661,13 +812,14 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     // ---- pass 3: ordinary Kalman filter over the chunk from its start state -------------
     double dot = lane == 0 ? z0 * z0 / D0 : 0.0, dprod = 1.0, dmin = lane == 0 ? D0 : INFINITY;
     int dexp = 0;
+    tp_sub_pinf<NR, NC, J>(M, C);  // deviation form from here on
     for (int64_t n = lo; n < hi; ++n) {
         TpTrans<NR, NC> T;
         tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
         const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
-        double D, z;
-        tp_filter_step<NR, NC, J>(M, T, r, yv[n].y + jitter, m, C, D, z);
-        dot = fma(z * z, 1.0 / D, dot);
+        double D, inv, z, kd[J];
+        tp_filter_step<NR, NC, J>(M, T, r, yv[n].y + jitter, m, C, D, inv, z, kd);
+        dot = fma(z * z, inv, dot);
         dmin = fmin(dmin, D);
         const double pr = dprod * D;
         dprod = __builtin_amdgcn_frexp_mant(pr);

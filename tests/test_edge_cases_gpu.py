@@ -113,10 +113,41 @@ def test_single_sample_and_two_samples(engine):
         hip_vs_dense(engine, synth.ALT_MODEL, t, y[0], dy[0], thetas, float(np.mean(y)))
 
 
+class _Hip:
+    """hipMalloc / hipMemcpy through ctypes on the HIP runtime the engine already loaded: the
+    `_device` entry points take plain device pointers, whoever owns them."""
+
+    def __init__(self):
+        import ctypes
+        self.c = ctypes
+        self.lib = ctypes.CDLL("libamdhip64.so.7")       # resolves to the copy already in the process
+        self.lib.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.lib.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.lib.hipFree.argtypes = [ctypes.c_void_p]
+        self.owned = []
+
+    def put(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.c.c_void_p()
+        assert self.lib.hipMalloc(self.c.byref(p), max(a.nbytes, 8)) == 0
+        assert self.lib.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0           # hipMemcpyHostToDevice
+        self.owned.append(p)
+        return p.value
+
+    def get(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert self.lib.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0    # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        for p in self.owned:
+            self.lib.hipFree(p)
+        self.owned = []
+
+
 def test_device_pointer_entry_points(engine):
-    """mtg_set_lightcurves_device / mtg_loglike_batch_device (torch tensors as the owner of
-    the device memory) against the host-pointer calls; device-side argument checks."""
-    import torch
+    """mtg_set_lightcurves_device / mtg_loglike_batch_device on caller-owned device memory
+    against the host-pointer calls; device-side argument checks."""
     from mind_the_gaps_amd.engine import EngineError
     kinds = synth.NULL_MODEL
     N, L, B = 300, 3, 40
@@ -129,42 +160,40 @@ def test_device_pointer_entry_points(engine):
     engine.set_model(kinds, full, free, bounds)
     ref, rst = engine.loglike(theta, lc)
 
-    dev = torch.device("cuda:0")
-    d_t, d_y, d_dy, d_off = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (t, y, dy + 1e-12, off))
-    engine.set_lightcurves_device(N, L, d_t.data_ptr(), d_y.data_ptr(), d_dy.data_ptr(), t_per_lc=False,
-                                  y_offset_ptr=d_off.data_ptr())
-    d_theta, d_lc = torch.from_numpy(theta).to(dev), torch.from_numpy(lc).to(dev)
-    d_out = torch.empty(B, dtype=torch.float64, device=dev)
-    d_st = torch.empty(B, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-    for mode in (0, 1):                                      # throughput and time-parallel kernels
-        try:
-            engine.set_time_parallel(mode)
-            engine.loglike_device(B, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(), d_st.data_ptr())
-            engine.synchronize()
-        finally:
-            engine.set_time_parallel(2)
-        assert np.array_equal(d_st.cpu().numpy(), rst)
-        assert np.allclose(d_out.cpu().numpy(), ref, rtol=1e-10, atol=0)
+    hip = _Hip()
+    try:
+        d_t, d_y, d_dy, d_off = (hip.put(a) for a in (t, y, dy + 1e-12, off))
+        engine.set_lightcurves_device(N, L, d_t, d_y, d_dy, t_per_lc=False, y_offset_ptr=d_off)
+        d_theta, d_lc = hip.put(theta), hip.put(lc)
+        d_out, d_st = hip.put(np.zeros(B)), hip.put(np.zeros(B, dtype=np.int32))
+        for mode in (0, 1):                                  # throughput and time-parallel kernels
+            try:
+                engine.set_time_parallel(mode)
+                engine.loglike_device(B, d_theta, d_lc, d_out, d_st)
+                engine.synchronize()
+            finally:
+                engine.set_time_parallel(2)
+            assert np.array_equal(hip.get(d_st, B, np.int32), rst)
+            assert np.allclose(hip.get(d_out, B, np.float64), ref, rtol=1e-10, atol=0)
 
-    # a light-curve index the host cannot see: no fault, a non-OK status
-    bad = torch.full((B,), 7, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-    for mode in (0, 1):
-        try:
-            engine.set_time_parallel(mode)
-            engine.loglike_device(B, d_theta.data_ptr(), bad.data_ptr(), d_out.data_ptr(), d_st.data_ptr())
-            engine.synchronize()
-        finally:
-            engine.set_time_parallel(2)
-        assert np.all(d_st.cpu().numpy() != 0) and np.all(np.isneginf(d_out.cpu().numpy()))
+        # a light-curve index the host cannot see: no fault, a non-OK status
+        d_bad = hip.put(np.full(B, 7, dtype=np.int32))
+        for mode in (0, 1):
+            try:
+                engine.set_time_parallel(mode)
+                engine.loglike_device(B, d_theta, d_bad, d_out, d_st)
+                engine.synchronize()
+            finally:
+                engine.set_time_parallel(2)
+            assert np.all(hip.get(d_st, B, np.int32) != 0) and np.all(np.isneginf(hip.get(d_out, B, np.float64)))
 
-    # unsorted device-resident times are found by the set-up kernel
-    d_bad_t = torch.from_numpy(np.ascontiguousarray(t[::-1])).to(dev)
-    torch.cuda.synchronize()
-    with pytest.raises(EngineError, match="sorted"):
-        engine.set_lightcurves_device(N, L, d_bad_t.data_ptr(), d_y.data_ptr(), d_dy.data_ptr())
-    engine.set_lightcurves(t, y, dy + 1e-12)
+        # unsorted device-resident times are found by the set-up kernel
+        d_bad_t = hip.put(t[::-1])
+        with pytest.raises(EngineError, match="sorted"):
+            engine.set_lightcurves_device(N, L, d_bad_t, d_y, d_dy)
+    finally:
+        engine.set_lightcurves(t, y, dy + 1e-12)
+        hip.free()
 
 
 def test_ensemble_guards(engine):

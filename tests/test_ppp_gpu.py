@@ -63,8 +63,8 @@ def test_lrt_statistic_null_vs_alternative():
     t, y, dy = synth.make_lightcurves(N, L, seed=41)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        null = derive_posteriors_batch(t, y, dy, null_kernel(), walkers=W, max_steps=60, seed=1, store_chain=False)
-        alt = derive_posteriors_batch(t, y, dy, alt_kernel(), walkers=W, max_steps=60, seed=2, store_chain=False)
+        null = derive_posteriors_batch(t, y, dy, null_kernel(), walkers=W, max_steps=200, seed=1, store_chain=False)
+        alt = derive_posteriors_batch(t, y, dy, alt_kernel(), walkers=W, max_steps=200, seed=2, store_chain=False)
     T = -2.0 * (null.max_loglikelihood - alt.max_loglikelihood)
     assert T.shape == (L,) and np.all(np.isfinite(T)) and np.all(T > -3.0)
 
