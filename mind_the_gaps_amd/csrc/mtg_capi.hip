@@ -62,7 +62,7 @@ struct mtg_ctx {
     MtgModel model;
 
     // workspaces
-    DevBuf coef, lists, counts;
+    DevBuf coef, lists, counts, tp_ws;
     int64_t cstride = 0;
     // staging for the host-pointer entry points
     DevBuf theta, lc, out, status;
@@ -202,15 +202,32 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
     // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip).
     // Measured crossovers: J <= 6 (elements in registers) pays up to ~1000 evaluations; the J = 10
-    // kernels (elements spill, 64 chunks only) cost ~0.14 us x N + 0.6 ms per 256 evaluations against
-    // ~1.05 us x N for the serial sweep.
+    // kernels (elements spill) cost ~0.14 us x N + 0.6 ms per 256 evaluations with 64 chunks and
+    // ~0.05 us x N + 6 ms with 256 chunks, against ~1.05 us x N for the serial sweep.
     const int Jmodel = m.nr0 + 2 * m.nc0;
-    const bool pays = Jmodel <= 6 ? (ctx->N >= 256 && B <= 1024)
-                                  : ((ctx->N >= 1024 && B <= 256) || (ctx->N >= 8192 && B <= 1024));
+    bool pays;
+    if (Jmodel <= 6) {
+        pays = ctx->N >= 256 && B <= 1024;
+    } else {  // microseconds per 256 evaluations against the serial sweep's ~1.05 us x N
+        const double n = (double)ctx->N, rounds = (double)((B + 255) / 256);
+        const double tp = n >= MTG_TP_BIG_WIDE_MIN_N ? 0.05 * n + 6000.0 : 0.14 * n + 600.0;
+        pays = rounds * tp < 1.05 * n;
+    }
     const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
+    sa.tp_ws = nullptr;
+    bool small_ok = small;
+    if (small && Jmodel > 6 && ctx->N >= MTG_TP_BIG_WIDE_MIN_N) {  // 256 chunks: elements in global memory
+        const size_t need = (size_t)B * MTG_TP_BIG_LANES * MTG_TP_ELEM(Jmodel) * sizeof(double);
+        for (int k = 0; k < nsig; ++k)
+            if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
+        if (small_ok && need <= ((size_t)8 << 30)) {  // else (forced mode, huge batch): the 64-chunk shape
+            HIP_TRY(ctx, ctx->tp_ws.reserve(need));
+            sa.tp_ws = ctx->tp_ws.as<double>();
+        }
+    }
     const bool wide = B <= 256 && ctx->N >= 4096;  // four waves per evaluation
     mtg_solve_launcher fused = nullptr;
-    if (small && nsig > 1) {
+    if (small_ok && nsig > 1) {
         if (wide) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256);
         if (!fused) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 64);
     }
@@ -223,7 +240,7 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
             const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
             mtg_solve_launcher fn = mtg_find_solver(nr, nc);
             if (!fn) continue;
-            mtg_solve_launcher tp = small ? mtg_find_tp_solver(nr, nc) : nullptr;
+            mtg_solve_launcher tp = small_ok ? mtg_find_tp_solver(nr, nc) : nullptr;
             if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
             sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
             sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
@@ -297,7 +314,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
-                      &ctx->counts, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
+                      &ctx->counts, &ctx->tp_ws, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
                       &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
                       &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_naccept,
                       &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,
@@ -589,6 +606,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
     sa.mean_kind = mean_kind;
     sa.has_mean = mean_params != nullptr;
+    sa.tp_ws = nullptr;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
     fn(sa, B, s);

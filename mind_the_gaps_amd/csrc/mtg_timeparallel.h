@@ -24,6 +24,9 @@
 #pragma once
 #include "mtg_device.h"
 
+// the chunk elements of a workgroup sit in LDS when they fit (160 KiB per CU), else in a.tp_ws
+#define MTG_TP_IN_LDS(J, LANES) ((LANES) * MTG_TP_ELEM(J) * 8 <= 150 * 1024)
+
 // 256-entry tables here (2 KiB + 4 KiB): LDS is needed for the chunk elements
 #define MTG_EXP_BITS 8
 #define MTG_TRIG_BITS 8
@@ -89,20 +92,6 @@ __device__ __forceinline__ void tp_apply_F(const TpTrans<NR, NC> &T, double *x)
         const double x0 = x[NR + 2 * k], x1 = x[NR + 2 * k + 1];
         x[NR + 2 * k] = T.ec[k] * x0 - T.es[k] * x1;
         x[NR + 2 * k + 1] = T.es[k] * x0 + T.ec[k] * x1;
-    }
-}
-
-// y <- F^T x
-template <int NR, int NC>
-__device__ __forceinline__ void tp_apply_Ft(const TpTrans<NR, NC> &T, double *x)
-{
-#pragma unroll
-    for (int j = 0; j < NR; ++j) x[j] *= T.phi[j];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const double x0 = x[NR + 2 * k], x1 = x[NR + 2 * k + 1];
-        x[NR + 2 * k] = T.ec[k] * x0 + T.es[k] * x1;
-        x[NR + 2 * k + 1] = -T.es[k] * x0 + T.ec[k] * x1;
     }
 }
 
@@ -688,40 +677,42 @@ __device__ __forceinline__ void tp_combine_regs(const TpElem<J> &e1, TpElem<J> &
     for (int i = 0; i < J * (J + 1) / 2; ++i) e2.Jm.v[i] = J_new.v[i];
 }
 
-template <int J>
+// Element <-> memory.  ST = distance between consecutive entries: 1 for the lane-major LDS slots,
+// the lane count for the entry-major global buffer of the J = 10 kernels (coalesced across lanes).
+template <int J, int ST = 1>
 __device__ __forceinline__ void tp_store(const TpElem<J> &e, double *slot)
 {
     int o = 0;
 #pragma unroll
     for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j < J; ++j) slot[o++] = e.A[i][j];
+        for (int j = 0; j < J; ++j) slot[ST * o++] = e.A[i][j];
 #pragma unroll
-    for (int i = 0; i < J; ++i) slot[o++] = e.b[i];
+    for (int i = 0; i < J; ++i) slot[ST * o++] = e.b[i];
 #pragma unroll
-    for (int i = 0; i < J; ++i) slot[o++] = e.eta[i];
+    for (int i = 0; i < J; ++i) slot[ST * o++] = e.eta[i];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[o++] = e.C.v[i];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[ST * o++] = e.C.v[i];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[o++] = e.Jm.v[i];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[ST * o++] = e.Jm.v[i];
 }
 
-template <int J>
+template <int J, int ST = 1>
 __device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
 {
     int o = 0;
 #pragma unroll
     for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j < J; ++j) e.A[i][j] = slot[o++];
+        for (int j = 0; j < J; ++j) e.A[i][j] = slot[ST * o++];
 #pragma unroll
-    for (int i = 0; i < J; ++i) e.b[i] = slot[o++];
+    for (int i = 0; i < J; ++i) e.b[i] = slot[ST * o++];
 #pragma unroll
-    for (int i = 0; i < J; ++i) e.eta[i] = slot[o++];
+    for (int i = 0; i < J; ++i) e.eta[i] = slot[ST * o++];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) e.C.v[i] = slot[o++];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e.C.v[i] = slot[ST * o++];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) e.Jm.v[i] = slot[o++];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e.Jm.v[i] = slot[ST * o++];
 }
 
 }  // namespace
@@ -729,13 +720,21 @@ __device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
 // one wave per evaluation; lane = chunk
 // LANES = chunks per evaluation = workgroup size: 64 (one wave) or 256 (four waves, for the
 // smallest batches: the scan then crosses waves through LDS and workgroup barriers)
+// `elems`: LANES element slots -- LDS for J <= 6, this workgroup's slice of a.tp_ws (global
+// memory, workgroup-scope visibility through the barriers) for the J = 10 structures;
+// `red`: a few doubles of LDS for the final cross-wave reduction.
 template <int NR, int NC, bool FAST, int LANES>
 __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
-                                            double icpt, int64_t ev, int64_t lc, const MtgMathTables *tab, double *sh)
+                                            double icpt, int64_t ev, int64_t lc, const MtgMathTables *tab, double *elems,
+                                            double *red)
 {
+    double *sh = elems;
     constexpr int MTG_TP_LANES = LANES;
     constexpr int J = NR + 2 * NC;
-    constexpr int ELEM = J * J + 2 * J + J * (J + 1);  // doubles per element
+    constexpr int ELEM = MTG_TP_ELEM(J);  // doubles per element
+    constexpr bool IN_LDS = MTG_TP_IN_LDS(J, LANES);
+    constexpr int ST = IN_LDS ? 1 : LANES;            // entry stride of an element in the buffer
+    constexpr int SLOT = IN_LDS ? ELEM : 1;           // distance between the elements of two lanes
     const int lane = threadIdx.x;
     const int64_t N = a.N;
     const double2 *yv = a.yv + lc * N, *dxt = a.dxt + lc * a.t_stride;
@@ -761,18 +760,18 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
 
     // ---- pass 2: inclusive scan of the 64 chunk elements (Hillis-Steele through LDS) ------
     double *buf = sh;
-    tp_store<J>(e, buf + lane * ELEM);
+    tp_store<J, ST>(e, buf + lane * SLOT);
     __syncthreads();
     for (int off = 1; off < MTG_TP_LANES; off <<= 1) {
         TpElem<J> prev;
-        if (lane >= off) tp_load<J>(prev, buf + (lane - off) * ELEM);
+        if (lane >= off) tp_load<J, ST>(prev, buf + (lane - off) * SLOT);
         __syncthreads();  // everybody has read its partner before anybody overwrites
         if (lane >= off) {
             if (J <= 6) {
                 tp_combine<J>(prev, buf + lane * ELEM);  // own element stays in its LDS slot
             } else {
                 tp_combine_regs<J>(prev, e);
-                tp_store<J>(e, buf + lane * ELEM);
+                tp_store<J, ST>(e, buf + lane * SLOT);
             }
         }
         __syncthreads();
@@ -805,7 +804,7 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     // start state of this lane's chunk: the prefix of the earlier chunks applied to it
     if (lane > 0) {
         TpElem<J> pre;
-        tp_load<J>(pre, cur + (lane - 1) * ELEM);
+        tp_load<J, ST>(pre, cur + (lane - 1) * SLOT);
         tp_apply_elem<J>(pre, m, C);
     }
 
@@ -831,12 +830,12 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
         ld += __shfl_down(ld, off);
         dmin = fmin(dmin, __shfl_down(dmin, off));
     }
-    if (LANES > 64) {  // combine the waves' partial sums through LDS (the element buffer is free now)
+    if (LANES > 64) {  // combine the waves' partial sums through LDS
         __syncthreads();
-        if ((lane & 63) == 0) { sh[3 * (lane >> 6)] = dot; sh[3 * (lane >> 6) + 1] = ld; sh[3 * (lane >> 6) + 2] = dmin; }
+        if ((lane & 63) == 0) { red[3 * (lane >> 6)] = dot; red[3 * (lane >> 6) + 1] = ld; red[3 * (lane >> 6) + 2] = dmin; }
         __syncthreads();
         if (lane == 0)
-            for (int w = 1; w < LANES / 64; ++w) { dot += sh[3 * w]; ld += sh[3 * w + 1]; dmin = fmin(dmin, sh[3 * w + 2]); }
+            for (int w = 1; w < LANES / 64; ++w) { dot += red[3 * w]; ld += red[3 * w + 1]; dmin = fmin(dmin, red[3 * w + 2]); }
     }
     if (lane == 0) {
         double ll = -0.5 * (dot + ld + (double)N * MTG_LN_2PI);
@@ -851,7 +850,8 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
 // One evaluation `ev` of structure <NR, NC> by the whole workgroup: load its model, pick the
 // trigonometric path, run the three passes.
 template <int NR, int NC, int LANES>
-__device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab, double *sh)
+__device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab, double *elems,
+                                            double *red)
 {
     // ---- model of this evaluation (same on every lane) ------------------------------------
     TpModel<NR, NC> M;
@@ -883,16 +883,18 @@ __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, c
         return;
     }
     if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
-        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, sh);
+        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red);
     else
-        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, sh);
+        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red);
 }
 
 template <int NR, int NC, int LANES>
 __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;
-    __shared__ double sh[LANES * (J * J + 2 * J + J * (J + 1))];
+    constexpr bool IN_LDS = MTG_TP_IN_LDS(J, LANES);  // 256 J = 10 elements live in a.tp_ws
+    __shared__ double sh[IN_LDS ? LANES * MTG_TP_ELEM(J) : 1];
+    __shared__ double red[3 * (LANES / 64)];
     __shared__ MtgMathTables tab;
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
     if ((int64_t)blockIdx.x >= count) return;
@@ -900,7 +902,8 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     if (!a.list && a.status[ev] != MTG_ST_OK) return;
     mtg_fill_tables(&tab, threadIdx.x, LANES);
     __syncthreads();
-    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, sh);
+    double *elems = IN_LDS ? sh : a.tp_ws + (int64_t)blockIdx.x * (LANES * MTG_TP_ELEM(J));
+    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, elems, red);
 }
 
 template <int NR, int NC, int LANES = 64>
@@ -918,10 +921,10 @@ static void mtg_launch_tp(const MtgSolveArgs &a, int64_t nevals, hipStream_t str
 // a.cstride), a.count_ptr the base of the counts -- and the launch has B workgroups.
 template <int NR0, int NC0, int K, int NSIG, int LANES>
 __device__ __forceinline__ void mtg_tp_dispatch(int k, const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab,
-                                                double *sh)
+                                                double *elems, double *red)
 {
-    if (k == K) mtg_tp_eval<NR0 + 2 * K, NC0 - K, LANES>(a, ev, tab, sh);
-    else if constexpr (K + 1 < NSIG) mtg_tp_dispatch<NR0, NC0, K + 1, NSIG, LANES>(k, a, ev, tab, sh);
+    if (k == K) mtg_tp_eval<NR0 + 2 * K, NC0 - K, LANES>(a, ev, tab, elems, red);
+    else if constexpr (K + 1 < NSIG) mtg_tp_dispatch<NR0, NC0, K + 1, NSIG, LANES>(k, a, ev, tab, elems, red);
 }
 
 template <int NR0, int NC0, int NSIG, int LANES>
@@ -929,7 +932,8 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_fused_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR0 + 2 * NC0;
     static_assert(NSIG >= 2 && NSIG - 1 <= NC0, "one structure per number of over-damped SHO terms");
-    __shared__ double sh[LANES * (J * J + 2 * J + J * (J + 1))];
+    __shared__ double sh[LANES * MTG_TP_ELEM(J)];
+    __shared__ double red[3 * (LANES / 64)];
     __shared__ MtgMathTables tab;
     int64_t r = blockIdx.x;
     int k = 0;
@@ -942,7 +946,7 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_fused_kernel(MtgSolveArgs a)
     const int64_t ev = a.list[(int64_t)k * a.cstride + r];
     mtg_fill_tables(&tab, threadIdx.x, LANES);
     __syncthreads();
-    mtg_tp_dispatch<NR0, NC0, 0, NSIG, LANES>(k, a, ev, &tab, sh);
+    mtg_tp_dispatch<NR0, NC0, 0, NSIG, LANES>(k, a, ev, &tab, sh, red);
 }
 
 template <int NR0, int NC0, int NSIG, int LANES>

@@ -78,3 +78,36 @@ def test_time_parallel_linear_mean_and_per_lc_times(engine):
         sel = lc == l
         ref[sel] = oracle_c.logprob_batch(t[l], y[l], dy[l], kinds, theta[sel], mean_kind=1)[0]
     assert np.all(st == 0) and np.max(np.abs(out - ref) / np.abs(ref)) <= 1e-8
+
+
+@pytest.mark.parametrize("N", [3, 300, 5000, 8192, 9001])
+def test_time_parallel_five_sho(engine, N):
+    """The J = 10 structures (BASELINE configs[4]): 64 chunks per evaluation with the elements in
+    LDS below 8192 samples, 256 chunks with the elements exchanged through global memory from
+    there on; all six signatures in one batch."""
+    kinds = [synth.K_SHO] * 5
+    L, B = 2, 18
+    t, y, dy = synth.make_lightcurves(N, L, seed=900 + N)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    y_mean = y.mean(axis=1)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds)
+    theta = synth.draw_thetas(kinds, B, seed=23)
+    for b in range(B):                                       # b % 6 over-damped oscillators
+        for k in range(b % 6):
+            theta[b, 3 * k + 1] = np.log(0.1 + 0.05 * k)
+    lc = (np.arange(B) % L).astype(np.int32)
+    try:
+        engine.set_time_parallel(1)
+        out, st = engine.loglike(theta, lc, add_prior=True)
+        engine.set_time_parallel(0)
+        thr, st_thr = engine.loglike(theta, lc, add_prior=True)
+    finally:
+        engine.set_time_parallel(2)
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, y_mean[lc][:, None]]), bounds=bounds,
+                                      lc_index=lc, add_prior=True, nthreads=4)
+    assert np.array_equal(st, rst) and np.array_equal(st_thr, rst)
+    ok = st == 0
+    assert ok.sum() >= B // 2
+    assert np.max(np.abs(out[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
+    assert np.max(np.abs(out[ok] - thr[ok]) / np.abs(thr[ok])) <= 1e-9
