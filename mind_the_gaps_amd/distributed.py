@@ -48,6 +48,9 @@ def all_gather_rows(local, counts, group=None, device=None):
     world = dist.get_world_size(group)
     counts = [int(c) for c in counts]
     assert len(counts) == world and len(local) == counts[dist.get_rank(group)]
+    if device is None and dist.get_backend(group) == "nccl":
+        # RCCL moves device buffers only: stage on this process's GPU (torch.cuda.set_device)
+        device = torch.device("cuda", torch.cuda.current_device())
     width = max(counts) if counts else 0
     dtype = torch.float64 if np.asarray(local).dtype.kind == "f" else torch.int32
     buf = torch.zeros(width, dtype=dtype, device=device)

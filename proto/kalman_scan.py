@@ -139,3 +139,72 @@ if __name__ == "__main__":
         seq = sequential(t, r, var, blocks, jitter)
         out = [chunked(t, r, var, blocks, jitter, c) for c in (7, 64, 500)]
         print(kinds, "dense", want, "seq err", abs(seq - want) / abs(want), "chunk errs", [abs(o - want) / abs(want) for o in out])
+
+
+# ---- likelihood as a REDUCTION: elements carry ell = ln p(y_chunk | x_start = 0) -------------
+def combine_ll(e1, e2):
+    """(A, b, C, eta, J, ell) o (A, b, C, eta, J, ell): the five-component rule plus
+    ell = ell1 + ell2 - 1/2 ln det G + 1/2 [eta2' G^-1 C1 eta2 + 2 eta2' G^-1 b1 - b1' J2 G^-1 b1],
+    G = I + C1 J2 (Gaussian integral of e2's information form against N(A1 x + b1, C1))."""
+    A, b, C, eta, Jm = combine(e1[:5], e2[:5])
+    b1, C1, eta2, J2 = e1[1], e1[2], e2[3], e2[4]
+    G = np.eye(len(b1)) + C1 @ J2
+    Gi_b1 = np.linalg.solve(G, b1)
+    Gi_C1_eta2 = np.linalg.solve(G, C1 @ eta2)
+    sign, logdet = np.linalg.slogdet(G)
+    ell = e1[5] + e2[5] - 0.5 * logdet + 0.5 * (eta2 @ Gi_C1_eta2 + 2.0 * eta2 @ Gi_b1 - b1 @ J2 @ Gi_b1)
+    return A, b, C, eta, Jm, ell
+
+
+def reduced(t, r, var, blocks, jitter, nchunks):
+    """pass 1: per-chunk element by the Kalman recursion (deviation-free form for clarity), the
+    first chunk absorbing the prior; then a tree reduction of the chunk elements.  No pass 3."""
+    N = len(t)
+    F0, Pinf, h = build(blocks, 0.0)
+    J = len(h)
+    bounds = np.linspace(0, N, nchunks + 1).astype(int)
+    elems = []
+    for c in range(nchunks):
+        if c == 0:   # prior update at sample 0: A = 0, (b, C) = filtered state, ell = ln p(y_0)
+            A = np.zeros((J, J)); C = Pinf.copy()
+            S = h @ C @ h + var[0] + jitter
+            ell = -0.5 * (np.log(2 * np.pi * S) + r[0] ** 2 / S)
+            K = C @ h / S
+            b = K * r[0]; C = C - np.outer(K, K) * S
+        else:
+            A = np.eye(J); b = np.zeros(J); C = np.zeros((J, J)); ell = 0.0
+        eta = np.zeros(J); Jm = np.zeros((J, J))
+        for n in range(max(bounds[c], 1), bounds[c + 1]):
+            F, _, _ = build(blocks, t[n] - t[n - 1])
+            FA = F @ A
+            g = h @ FA
+            b = F @ b; C = F @ C @ F.T + (Pinf - F @ Pinf @ F.T)
+            D = h @ C @ h + var[n] + jitter
+            z = r[n] - h @ b
+            K = C @ h / D
+            b = b + K * z; C = C - np.outer(K, K) * D
+            A = FA - np.outer(K, g)
+            eta = eta + g * z / D
+            Jm = Jm + np.outer(g, g) / D
+            ell += -0.5 * (np.log(2 * np.pi * D) + z * z / D)
+        elems.append((A, b, C, eta, Jm, ell))
+    while len(elems) > 1:   # pairwise tree
+        nxt = [combine_ll(elems[i], elems[i + 1]) for i in range(0, len(elems) - 1, 2)]
+        if len(elems) % 2:
+            nxt.append(elems[-1])
+        elems = nxt
+    return elems[0][5]
+
+
+if __name__ == "__main__":
+    print("-- reduction form")
+    for kinds in (synth.ALT_MODEL, [synth.K_SHO], [synth.K_DRW, synth.K_BPL], [synth.K_COSINUS, synth.K_DRW], [synth.K_MATERN32]):
+        N = 3000
+        t, y, dy = synth.make_lightcurves(N, 1, seed=3)
+        th = synth.draw_thetas(kinds, 1, seed=2)[0]
+        co = dense.build_coeffs(kinds, th)
+        blocks, jitter = model_matrices(co)
+        r = y[0] - y[0].mean(); var = (dy[0] + 1e-12) ** 2
+        want = dense.dense_loglike(t, y[0], dy[0], co, 0, [y[0].mean()])
+        out = [reduced(t, r, var, blocks, jitter, c) for c in (1, 7, 64, 256, 1000)]
+        print(kinds, "reduction errs", [abs(o - want) / abs(want) for o in out])
