@@ -21,6 +21,7 @@ import numpy as np
 from scipy.optimize import minimize
 
 from . import engine as _engine
+from . import walkers as _walkers
 from .gp import GP, LinAlgError
 from .lightcurves import GappyLightcurve
 from .modeling import ConstantModel
@@ -238,30 +239,13 @@ class GPModelling:
 
     def spread_walkers(self, walkers: int, parameters, bounds: List[Tuple[float, float]],
                        percent: float = 0.1, max_attempts: int = 20):
-        """Spread the walkers with a Gaussian around ``parameters``
-        (gpmodelling.py:289-350): resample a walker while it is out of bounds (at most
-        ``max_attempts`` times), then clamp what is still outside next to the bound."""
-        if percent < 0 or percent > 1:
-            raise ValueError("The 'percent' parameter must be between 0 and 1 (inclusive).")
-        std = np.abs(parameters) * percent
-        initial_samples = np.random.normal(parameters, std, size=(walkers, len(parameters)))
+        """Spread the walkers with a Gaussian around ``parameters`` (gpmodelling.py:289-350;
+        the law is in ``walkers.spread``, draws from numpy's global generator like the
+        reference)."""
         bounds = np.array([(-np.inf if lower is None else lower, np.inf if upper is None else upper)
-                           for lower, upper in bounds])
-        factors_lower = np.where(bounds[:, 0] > 0, 1.05, 0.95)
-        factors_upper = np.where(bounds[:, 1] > 0, 0.95, 1.05)
-        for i in range(walkers):
-            for attempt in range(max_attempts):
-                inside = np.logical_and(bounds[:, 0] <= initial_samples[i], initial_samples[i] <= bounds[:, 1])
-                if np.all(inside):
-                    break
-                initial_samples[i] = np.random.normal(parameters, std)
-            if attempt == max_attempts - 1:
-                warnings.warn("Some walkers are out of bounds! Setting them to values close to the bounds")
-                below = initial_samples[i] < bounds[:, 0]
-                above = initial_samples[i] > bounds[:, 1]
-                initial_samples[i][below] = (bounds[:, 0] * factors_lower)[below]
-                initial_samples[i][above] = (bounds[:, 1] * factors_upper)[above]
-        return initial_samples
+                           for lower, upper in bounds], dtype=np.float64)
+        return _walkers.spread(np.random.normal, np.asarray(parameters, dtype=np.float64)[None, :], bounds[:, 0],
+                               bounds[:, 1], walkers, percent=percent, max_attempts=max_attempts)[0]
 
     def standarized_residuals(self, include_noise: bool = True):
         """Standardised residuals (gpmodelling.py:353-370) need ``GP.predict`` -- outside

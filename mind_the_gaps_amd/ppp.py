@@ -21,6 +21,7 @@ import warnings
 import numpy as np
 
 from . import engine as _engine
+from . import walkers as _walkers
 from .gp import DeviceModel, LinAlgError, LogProbEvaluator
 from .modeling import ConstantModel
 from .sampler import integrated_time
@@ -247,23 +248,7 @@ class BatchPosteriors:
 
 def _spread(rng, centers, lower, upper, walkers, percent=0.1, max_attempts=20):
     """spread_walkers (gpmodelling.py:289-350) for every light curve at once."""
-    L, P = centers.shape
-    std = np.abs(centers) * percent
-    p0 = rng.normal(centers[:, None, :], std[:, None, :], size=(L, walkers, P))
-    for _ in range(max_attempts):
-        out = np.any((p0 < lower) | (p0 > upper), axis=2)
-        if not out.any():
-            break
-        li, wi = np.nonzero(out)
-        p0[li, wi] = rng.normal(centers[li], std[li])
-    below, above = p0 < lower, p0 > upper
-    if below.any() or above.any():
-        warnings.warn("Some walkers are out of bounds! Setting them to values close to the bounds")
-        lo_f = np.where(lower > 0, 1.05, 0.95) * lower
-        hi_f = np.where(upper > 0, 0.95, 1.05) * upper
-        p0 = np.where(below, np.broadcast_to(lo_f, p0.shape), p0)
-        p0 = np.where(above, np.broadcast_to(hi_f, p0.shape), p0)
-    return p0
+    return _walkers.spread(rng.normal, centers, lower, upper, walkers, percent=percent, max_attempts=max_attempts)
 
 
 class _DeviceBatch:
