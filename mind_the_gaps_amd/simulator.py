@@ -16,7 +16,6 @@ flux PDFs (``pdf="lognormal" | "uniform"``) and the Kraft low-count posterior no
 """
 import numpy as np
 
-from . import engine as _engine
 from .gp import DeviceModel, LogProbEvaluator
 from .modeling import ConstantModel
 from .terms import Term

@@ -3,7 +3,6 @@ include/mtg.h declares, and fails loudly (never falls back) without a GPU."""
 import os
 import re
 
-import numpy as np
 import pytest
 
 from mind_the_gaps_amd import engine

@@ -6,7 +6,6 @@ import pytest
 
 from mind_the_gaps_amd import synthetic as synth
 from oracle import celerite as oracle_c
-from oracle import dense
 
 pytestmark = pytest.mark.gpu
 

@@ -5,7 +5,7 @@ import pytest
 
 from mind_the_gaps_amd import terms
 from mind_the_gaps_amd.gp import GP, DeviceModel
-from mind_the_gaps_amd.modeling import ConstantModel, Model
+from mind_the_gaps_amd.modeling import ConstantModel
 from mind_the_gaps_amd.models import (BendingPowerlaw, Cosinus, DampedRandomWalk, LinearModel, Lorentzian)
 from mind_the_gaps_amd.models import celerite_models
 from oracle import dense

@@ -8,7 +8,6 @@ import pytest
 
 import philox_replay
 from mind_the_gaps_amd import synthetic as synth
-from mind_the_gaps_amd import terms
 from mind_the_gaps_amd.gpmodelling import GPModelling
 from mind_the_gaps_amd.lightcurves import GappyLightcurve
 from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
