@@ -253,7 +253,6 @@ struct MtgLane {
     double S[J * (J + 1) / 2];
     double Wt[J];  // V_n - S U_n  (W_n = Wt / D_n)
     double f[J];
-    double cs[NC > 0 ? NC : 1], sn[NC > 0 ? NC : 1];  // cos/sin d_k (t_n - t_0)   (OCML path)
     double pr[NC > 0 ? NC : 1];                        // phase d_k (t_n - t_0) = pm pi/32 + pr
     int pm[NC > 0 ? NC : 1];                           //   pm = 16 * (m mod N_trig) (table path)
     double ncr[NR > 0 ? NR : 1], cr64[NR > 0 ? NR : 1];  // -c and -c 8 N_exp/ln2 of the real terms
@@ -288,6 +287,7 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
         return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
 
+    const double t0 = ld(rdt, toff, 0).y;  // phases are measured from the first sample
     // One step of the recurrence for the sample (dxc, tc, yc, vc): a single basic block.
     auto step = [&](const double2 dtc, const double2 yvc) __attribute__((always_inline)) {
         const double dxc = dtc.x, tc = dtc.y, yc = yvc.x, vc = yvc.y;
@@ -308,12 +308,12 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
             double cn, sn;
             if (FAST) {
                 mtg_phase_step(L.dc[k], dxc, L.pr[k], L.pm[k], &sn, &cn, tab);
-            } else {  // huge d_k dx somewhere in this wave: OCML sincos + rotation
-                double sd, cd;
-                sincos(L.dc[k] * dxc, &sd, &cd);
-                cn = L.cs[k] * cd - L.sn[k] * sd;
-                sn = L.sn[k] * cd + L.cs[k] * sd;
-                L.cs[k] = cn; L.sn[k] = sn;
+            } else {
+                // huge d_k dx somewhere in this wave: evaluate at the elapsed time the way celerite
+                // does at the absolute one.  (Rotating the previous pair by sincos(d dx) instead
+                // lets the pair drift by ~1e-16 per step, which an ill-conditioned covariance --
+                // amplitude >> noise -- amplifies far beyond celerite's own error.)
+                sincos(L.dc[k] * (tc - t0), &sn, &cn);
             }
             U[NR + 2 * k] = L.ac[k] * cn + L.bc[k] * sn;
             U[NR + 2 * k + 1] = L.ac[k] * sn - L.bc[k] * cn;
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     for (int i = 0; i < J; ++i) { L.Wt[i] = 0.0; L.f[i] = 0.0; }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        L.cs[k] = 1.0; L.sn[k] = 0.0; L.pr[k] = 0.0; L.pm[k] = 0;
+        L.pr[k] = 0.0; L.pm[k] = 0;
         L.ncc[k] = -L.cc[k]; L.cc64[k] = L.cc[k] * -MTG_EXP_CSCALE;
     }
 #pragma unroll

@@ -104,7 +104,9 @@ __device__ __forceinline__ void mtg_sincos_small(double r, double *s, double *c)
 
 // Largest phase increment d * dx the table sincos reduces exactly: the 24-bit head of
 // 2 pi / (16 N) times md16 = 16 rint(x N / 2 pi) must be an exact product (md16 < 2^29).
+#ifndef MTG_TRIG_FAST_MAX
 #define MTG_TRIG_FAST_MAX 1.0e5
+#endif
 
 // ---------------------------------------------------------------------------
 // Every VALU instruction costs the wave the same 4-cycle issue slot, FP64 or not,
