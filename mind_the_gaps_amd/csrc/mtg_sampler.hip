@@ -241,9 +241,8 @@ __global__ void __launch_bounds__(64) mtg_predict_kernel(MtgPredictArgs a)
 
     // ---- forward sweep: factorisation + z = L^-1 r, generators stored -------------
     double S[MTG_PJ][MTG_PJ], f[MTG_PJ], Wp[MTG_PJ], U[MTG_PJ], V[MTG_PJ], ph[MTG_PJ];
-    double cs_[MTG_PJ / 2], sn_[MTG_PJ / 2];
+    const double t_first = dxt[0].y;
     for (int i = 0; i < J; ++i) { f[i] = 0.0; Wp[i] = 0.0; for (int j = 0; j < J; ++j) S[i][j] = 0.0; }
-    for (int k = 0; k < NC; ++k) { cs_[k] = 1.0; sn_[k] = 0.0; }
     double Dp = 1.0, zp = 0.0;
     bool bad = false;
     for (int64_t n = 0; n < N; ++n) {
@@ -251,10 +250,10 @@ __global__ void __launch_bounds__(64) mtg_predict_kernel(MtgPredictArgs a)
         for (int j = 0; j < NR; ++j) { ph[j] = exp(-cr[j] * dx); U[j] = ar[j]; V[j] = 1.0; }
         for (int k = 0; k < NC; ++k) {
             const double p = exp(-cc[k] * dx);
-            double sd, cd;
-            sincos(dc[k] * dx, &sd, &cd);
-            const double cn = cs_[k] * cd - sn_[k] * sd, sn = sn_[k] * cd + cs_[k] * sd;
-            cs_[k] = cn; sn_[k] = sn;
+            // at the elapsed time, as celerite does at the absolute one: a (cos, sin) pair rotated
+            // step by step drifts, and an ill-conditioned covariance amplifies the drift
+            double sn, cn;
+            sincos(dc[k] * (t - t_first), &sn, &cn);
             ph[NR + 2 * k] = ph[NR + 2 * k + 1] = p;
             U[NR + 2 * k] = ac[k] * cn + bc[k] * sn; U[NR + 2 * k + 1] = ac[k] * sn - bc[k] * cn;
             V[NR + 2 * k] = cn; V[NR + 2 * k + 1] = sn;
