@@ -155,14 +155,21 @@ class GPModelling:
 
     def derive_posteriors(self, initial_chain_params=None, fit: bool = True, converge: bool = True,
                           max_steps: int = 10000, convergence_steps: int = 500, walkers: int = 12,
-                          cores: int = 6, progress: bool = True, device_sampler: bool = False):
+                          cores: int = 6, progress: bool = True, device_sampler: bool = None):
         """Derive GP posteriors (gpmodelling.py:197-286): optional fit, walker
         spreading, stretch-move MCMC with an autocorrelation-time convergence check
         every ``convergence_steps`` iterations, then burn-in and thinning.
 
         ``device_sampler`` (new, optional): keep walkers, random numbers and the
         accept/reject step on the GPU (``mtg_ensemble_*``); the host only sees the chain
-        every ``convergence_steps`` iterations.  Needs an even number of walkers."""
+        every ``convergence_steps`` iterations.  Needs an even number of walkers and terms the
+        device can expand.  Default (None): on whenever that holds -- 2-3x the iteration rate of
+        the host-side sampler; like emcee's, the run is reproducible from ``np.random.seed``
+        (the Philox key is drawn from numpy's global generator).  False: the host-side sampler
+        with emcee's own use of numpy's global generator."""
+        if device_sampler is None:
+            model = self.gp._device_model()
+            device_sampler = walkers % 2 == 0 and bool(model.device_terms) and model.mean_kind is not None
         if initial_chain_params is None:
             if not fit:
                 initial_params = self.initial_params

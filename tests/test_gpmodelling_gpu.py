@@ -139,7 +139,8 @@ def test_derive_posteriors_matches_oracle_driven_chain():
     np.random.seed(123)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        g.derive_posteriors(fit=False, max_steps=120, convergence_steps=60, walkers=12, cores=1, progress=False)
+        g.derive_posteriors(fit=False, max_steps=120, convergence_steps=60, walkers=12, cores=1, progress=False,
+                            device_sampler=False)
     assert g.sampler.iteration == 120 and len(g.autocorr) == 2 and not g.converged
     assert g.mcmc_samples.shape[1] == 2 and len(g.loglikelihoods) == len(g.mcmc_samples)
     assert g.max_loglikelihood == np.max(g.loglikelihoods)
@@ -203,7 +204,8 @@ def test_derive_posteriors_with_device_sampler():
     np.random.seed(6)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        g2.derive_posteriors(fit=True, max_steps=250, convergence_steps=100, walkers=12, progress=False)
+        g2.derive_posteriors(fit=True, max_steps=250, convergence_steps=100, walkers=12, progress=False,
+                             device_sampler=False)
     a, b = chain[100:].reshape(-1, 2), g2.sampler.get_chain()[100:].reshape(-1, 2)
     assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 3 * (a.std(axis=0) + b.std(axis=0)) / np.sqrt(40))
 
