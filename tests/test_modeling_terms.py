@@ -10,34 +10,36 @@ from mind_the_gaps_amd.models import (BendingPowerlaw, Cosinus, DampedRandomWalk
 from mind_the_gaps_amd.models import celerite_models
 from oracle import dense
 
-import test_oracle as closed_forms  # PSD closed forms restated from psd_models.py
-
-FREQ = np.arange(1, 1000).astype(float)
+from test_oracle import reference_psd  # outputs of the reference's own psd_models.py (golden fixture)
 
 
 # ---- the reference's tests/models_test.py, against THIS package's classes ------
 def test_DRW():
     cel = celerite_models.DampedRandomWalk(log_S0=np.log(10), log_omega0=np.log(5))
-    np.testing.assert_array_almost_equal(closed_forms.psd_bpl(FREQ, 10, 5, 0.5), cel.get_psd(FREQ))
+    w, ref = reference_psd("drw", 10.0, 5.0)
+    np.testing.assert_array_almost_equal(ref, cel.get_psd(w))
 
 
 @pytest.mark.parametrize("Q", [10, 1, 1 / np.sqrt(2), 0.1])
 def test_SHO(Q):
     cel = terms.SHOTerm(log_S0=np.log(10), log_Q=np.log(Q), log_omega0=np.log(5))
-    np.testing.assert_array_almost_equal(closed_forms.psd_sho(FREQ, 10, Q, 5), cel.get_psd(FREQ))
+    w, ref = reference_psd("sho", 10.0, Q, 5.0)
+    np.testing.assert_array_almost_equal(ref, cel.get_psd(w))
 
 
 @pytest.mark.parametrize("rho", [1, 10, 20])
 def test_materns(rho):
     cel = terms.Matern32Term(log_sigma=np.log(10), log_rho=np.log(rho), eps=1e-15)
-    np.testing.assert_array_almost_equal(closed_forms.psd_matern32(FREQ, 10, rho), cel.get_psd(FREQ))
+    w, ref = reference_psd("matern32", 10.0, rho)
+    np.testing.assert_array_almost_equal(ref, cel.get_psd(w))
 
 
 @pytest.mark.parametrize("Q", [10, 1, 1 / np.sqrt(2), 0.1])
 @pytest.mark.parametrize("S", [10, 5, 1])
 def test_Lorentzian(Q, S):
     cel = celerite_models.Lorentzian(log_S0=np.log(S), log_Q=np.log(Q), log_omega0=np.log(5))
-    np.testing.assert_array_almost_equal(closed_forms.psd_lorentzian(FREQ, S, Q, 5), cel.get_psd(FREQ))
+    w, ref = reference_psd("lorentzian", S, Q, 5.0)
+    np.testing.assert_array_almost_equal(ref, cel.get_psd(w))
 
 
 # ---- coefficients: product classes == oracle restatement -----------------------------

@@ -7,6 +7,8 @@
   forms from mind_the_gaps/models/psd_models.py:7-85, restated below),
 * prior and status conventions.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -57,49 +59,45 @@ def test_ou_closed_form_agrees():
 
 
 # ---- PSD known answers (reference tests/models_test.py) --------------------
-def psd_sho(w, S0, Q, w0):          # psd_models.py:8-11
-    return np.sqrt(2 / np.pi) * S0 * w0**4 / ((w**2 - w0**2)**2 + w**2 * w0**2 / Q**2)
-
-
-def psd_lorentzian(w, S0, Q, w0):   # psd_models.py:15-32
-    c = w0 / 2 / Q
-    return np.sqrt(1 / 2 / np.pi) * S0 / c * (1 / (1 + ((w - w0) / c)**2) + 1 / (1 + ((w + w0) / c)**2))
-
-
-def psd_bpl(w, S0, w0, Q=0.5):      # psd_models.py:36-46
-    c = 0.5 * w0 / Q
-    return np.sqrt(2 / np.pi) * S0 / c * (1 / (1 + (w / c)**2))
-
-
-def psd_matern32(w, sigma, rho):    # psd_models.py:64-67
-    return 1 / np.sqrt(2 * np.pi) * sigma**2 * 4 / np.sqrt(3) * rho * (1 / (1 + (w * rho / np.sqrt(3))**2))**2
-
-
-FREQ = np.arange(1, 1000).astype(float)
+def reference_psd(model, *params):
+    """Output of the reference's own closed-form PSD (mind_the_gaps/models/psd_models.py) on
+    omega = 1..999 for one of the cases of its tests/models_test.py -- committed as
+    tests/golden/psd_golden.npz by tests/golden/make_psd_golden.py, which runs the reference's
+    functions themselves."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "psd_golden.npz"))
+    want = np.array(list(params) + [np.nan] * (3 - len(params)))
+    for m, p, psd in zip(g["model"], g["params"], g["psd"]):
+        if m == model and np.allclose(p, want, rtol=1e-15, atol=0, equal_nan=True):
+            return g["omega"], psd
+    raise KeyError((model, params))
 
 
 def test_psd_drw():                 # models_test.py:14-29
     co = dense.build_coeffs([K.K_DRW], [np.log(10.0), np.log(5.0)])
-    np.testing.assert_array_almost_equal(psd_bpl(FREQ, 10.0, 5.0), dense.psd(co, FREQ))
+    w, ref = reference_psd("drw", 10.0, 5.0)
+    np.testing.assert_array_almost_equal(ref, dense.psd(co, w))
 
 
 @pytest.mark.parametrize("Q", [10, 1, 1 / np.sqrt(2), 0.1])
 def test_psd_sho(Q):                # models_test.py:31-46
     co = dense.build_coeffs([K.K_SHO], [np.log(10.0), np.log(Q), np.log(5.0)])
-    np.testing.assert_array_almost_equal(psd_sho(FREQ, 10.0, Q, 5.0), dense.psd(co, FREQ))
+    w, ref = reference_psd("sho", 10.0, Q, 5.0)
+    np.testing.assert_array_almost_equal(ref, dense.psd(co, w))
 
 
 @pytest.mark.parametrize("rho", [1, 10, 20])
 def test_psd_matern32(rho):         # models_test.py:48-63
     co = dense.build_coeffs([K.K_MATERN32], [np.log(10.0), np.log(rho)], extra=[1e-15])
-    np.testing.assert_array_almost_equal(psd_matern32(FREQ, 10.0, rho), dense.psd(co, FREQ))
+    w, ref = reference_psd("matern32", 10.0, rho)
+    np.testing.assert_array_almost_equal(ref, dense.psd(co, w))
 
 
 @pytest.mark.parametrize("Q", [10, 1, 1 / np.sqrt(2), 0.1])
 @pytest.mark.parametrize("S0", [10, 5, 1])
 def test_psd_lorentzian(Q, S0):     # models_test.py:86-102
     co = dense.build_coeffs([K.K_LORENTZIAN], [np.log(S0), np.log(Q), np.log(5.0)])
-    np.testing.assert_array_almost_equal(psd_lorentzian(FREQ, S0, Q, 5.0), dense.psd(co, FREQ))
+    w, ref = reference_psd("lorentzian", S0, Q, 5.0)
+    np.testing.assert_array_almost_equal(ref, dense.psd(co, w))
 
 
 def test_c_builders_match_python_builders():

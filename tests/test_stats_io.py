@@ -13,6 +13,19 @@ def test_information_criteria_match_reference_formulas():
     assert stats.aicc(lnl, n, k) == stats.aic(lnl, k) + 2 * k * (k + 1) / (n - k - 1)
 
 
+def test_information_criteria_match_the_reference_module():
+    """tests/golden/stats_golden.json holds outputs of the reference's own stats.py (the one
+    module of the reference that imports here); see tests/golden/make_stats_golden.py."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stats_golden.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 60
+    for c in cases:
+        assert stats.bic(c["lnL"], c["n"], c["k"]) == c["bic"]
+        assert stats.aic(c["lnL"], c["k"]) == c["aic"]
+        assert stats.aicc(c["lnL"], c["n"], c["k"]) == c["aicc"]
+
+
 def test_lrt_statistic_and_pvalue():
     null, alt = np.array([-100.0, -90.0, -80.0]), np.array([-95.0, -90.0, -70.0])
     assert np.array_equal(stats.lrt_statistic(null, alt), [10.0, 0.0, 20.0])     # tutorial_ppp.ipynb:406-411
