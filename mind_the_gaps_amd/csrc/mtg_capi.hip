@@ -139,47 +139,77 @@ int reserve_workspace(mtg_ctx *ctx, int64_t B, int nslots, int nsig)
     return MTG_OK;
 }
 
-// Launch the solver(s) for B prepared evaluations living in ctx->coef.
-int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_t *d_lc,
-                    int add_prior, double *d_out, int32_t *d_status, hipStream_t s)
+// every structure of the model (nr0 + 2k, nc0 - k) must have a compiled kernel; reserves the
+// coefficient workspace for B evaluations
+int check_model_workspace(mtg_ctx *ctx, int64_t B)
 {
     const MtgModel &m = ctx->model;
     const int nsig = m.nsho + 1;
-    MtgCoefLayout lay{m.nr_max, m.nc_max};
-    // every signature must have a compiled kernel (nr0 + 2k, nc0 - k)
     for (int k = 0; k < nsig; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
-        if (nr + nc == 0) continue;  // jitter-only model: handled by <0,0>? not supported
+        if (nr + nc == 0) continue;
         if (!mtg_find_solver(nr, nc))
             return fail(ctx, MTG_E_UNSUPPORTED,
                         "no compiled kernel for %d real + %d complex terms (J=%d)", nr, nc,
                         nr + 2 * nc);
     }
-    int rc = reserve_workspace(ctx, B, lay.nslots(), nsig);
-    if (rc) return rc;
+    MtgCoefLayout lay{m.nr_max, m.nc_max};
+    return reserve_workspace(ctx, B, lay.nslots(), nsig);
+}
 
-    const bool prof = ctx->prof_n < ctx->prof_cap;
-    hipEvent_t *pe = prof ? &ctx->prof_ev[3 * (size_t)ctx->prof_n] : nullptr;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
-    if (prof) HIP_TRY(ctx, hipEventRecord(pe[0], s));
-    if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
-
+// arguments of the theta -> coefficients expansion into the context's workspace
+MtgPrepArgs make_prep_args(mtg_ctx *ctx, int64_t B, const double *d_theta, int add_prior, double *d_out,
+                           int32_t *d_status)
+{
     MtgPrepArgs pa;
-    pa.model = m;
+    pa.model = ctx->model;
     pa.theta = d_theta;
     pa.B = B;
     pa.add_prior = add_prior;
     pa.coef = ctx->coef.as<double>();
     pa.cstride = ctx->cstride;
-    pa.nsig = nsig;
+    pa.nsig = ctx->model.nsho + 1;
     pa.lists = ctx->lists.as<int>();
     pa.counts = ctx->counts.as<int>();
     pa.out = d_out;
     pa.status = d_status;
     pa.sig = nullptr;
-    mtg_launch_prepare(pa, s);
-    if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
+    return pa;
+}
 
+int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s);
+
+// theta -> coefficients -> solver(s) for B evaluations; timing events around the launches
+int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_t *d_lc,
+                    int add_prior, double *d_out, int32_t *d_status, hipStream_t s)
+{
+    int rc = check_model_workspace(ctx, B);
+    if (rc) return rc;
+    const int nsig = ctx->model.nsho + 1;
+    const bool prof = ctx->prof_n < ctx->prof_cap;
+    hipEvent_t *pe = prof ? &ctx->prof_ev[3 * (size_t)ctx->prof_n] : nullptr;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+    if (prof) HIP_TRY(ctx, hipEventRecord(pe[0], s));
+    if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
+    mtg_launch_prepare(make_prep_args(ctx, B, d_theta, add_prior, d_out, d_status), s);
+    if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
+    rc = solve_prepared(ctx, B, d_lc, d_out, d_status, s);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+    if (prof) {
+        HIP_TRY(ctx, hipEventRecord(pe[2], s));
+        ctx->prof_n += 1;
+    }
+    ctx->timed = true;
+    return MTG_OK;
+}
+
+// Launch the solver(s) for B prepared evaluations living in ctx->coef (lists / counts filled).
+int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s)
+{
+    const MtgModel &m = ctx->model;
+    const int nsig = m.nsho + 1;
+    MtgCoefLayout lay{m.nr_max, m.nc_max};
     MtgSolveArgs sa;
     sa.coef = ctx->coef.as<double>();
     sa.cstride = ctx->cstride;
@@ -248,12 +278,6 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
-    if (prof) {
-        HIP_TRY(ctx, hipEventRecord(pe[2], s));
-        ctx->prof_n += 1;
-    }
-    ctx->timed = true;
     return MTG_OK;
 }
 
@@ -692,28 +716,29 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     hipStream_t s = ctx->stream;
     if (chain) HIP_TRY(ctx, ctx->ens_chain.reserve((size_t)steps * EW * P * 8));
     if (lnp_chain) HIP_TRY(ctx, ctx->ens_lnp_chain.reserve((size_t)steps * EW * 8));
+    rc = check_model_workspace(ctx, EH);
+    if (rc) return rc;
+    // the accept kernel leaves the structure counters cleared for the next expansion; clear them once here
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
+    const MtgPrepArgs pa = make_prep_args(ctx, EH, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(),
+                                          ctx->ens_st.as<int32_t>());
     for (int it = 0; it < steps; ++it) {
         const uint32_t iter = ctx->ens_iteration;
-        mtg_launch_split(E, W, iter, ctx->ens_seed, ctx->ens_perm.as<int32_t>(), s);
         for (int half = 0; half < 2; ++half) {
             mtg_launch_propose(E, W, P, half, iter, ctx->ens_seed, 2.0, ctx->ens_perm.as<int32_t>(),
-                               ctx->ens_coords.as<double>(), ctx->ens_q.as<double>(),
-                               ctx->ens_factor.as<double>(), s);
-            rc = run_model_batch(ctx, EH, ctx->ens_q.as<double>(), ctx->ens_lc_half.as<int32_t>(), 1,
-                                 ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>(), s);
+                               ctx->ens_coords.as<double>(), ctx->ens_factor.as<double>(), pa, s);
+            rc = solve_prepared(ctx, EH, ctx->ens_lc_half.as<int32_t>(), ctx->ens_new.as<double>(),
+                                ctx->ens_st.as<int32_t>(), s);
             if (rc) return rc;
+            const bool last = half == 1;
             mtg_launch_accept(E, W, P, half, iter, ctx->ens_seed, ctx->ens_perm.as<int32_t>(),
                               ctx->ens_q.as<double>(), ctx->ens_factor.as<double>(), ctx->ens_new.as<double>(),
                               ctx->ens_st.as<int32_t>(), ctx->ens_coords.as<double>(), ctx->ens_lnp.as<double>(),
                               ctx->ens_naccept.as<int32_t>(), ctx->ens_best_lnp.as<double>(),
-                              ctx->ens_best_coords.as<double>(), ctx->ens_notpd.as<int32_t>(), s);
+                              ctx->ens_best_coords.as<double>(), ctx->ens_notpd.as<int32_t>(), ctx->counts.as<int>(),
+                              last && chain ? ctx->ens_chain.as<double>() + (size_t)it * EW * P : nullptr,
+                              last && lnp_chain ? ctx->ens_lnp_chain.as<double>() + (size_t)it * EW : nullptr, s);
         }
-        if (chain)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_chain.as<double>() + (size_t)it * EW * P, ctx->ens_coords.p,
-                                        (size_t)EW * P * 8, hipMemcpyDeviceToDevice, s));
-        if (lnp_chain)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lnp_chain.as<double>() + (size_t)it * EW, ctx->ens_lnp.p,
-                                        (size_t)EW * 8, hipMemcpyDeviceToDevice, s));
         ctx->ens_iteration += 1;
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -121,13 +121,12 @@ void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, 
                          const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,
                          double *dxmax, hipStream_t);
 // device-resident ensemble sampler (mtg_sampler.hip)
-void mtg_launch_split(int E, int W, uint32_t iteration, uint64_t seed, int32_t *perm, hipStream_t);
-void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a,
-                        const int32_t *perm, const double *coords, double *q, double *factor, hipStream_t);
+void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a, int32_t *perm,
+                        const double *coords, double *factor, const MtgPrepArgs &pa, hipStream_t);
 void mtg_launch_accept(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, const int32_t *perm,
                        const double *q, const double *factor, const double *new_lnp, const int32_t *status,
                        double *coords, double *lnp, int32_t *naccept, double *best_lnp, double *best_coords,
-                       int32_t *n_notpd, hipStream_t);
+                       int32_t *n_notpd, int *counts, double *chain_row, double *lnp_chain_row, hipStream_t);
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
                              double *best_coords, hipStream_t);
 // TK95 light-curve simulation (mtg_simulate.hip)

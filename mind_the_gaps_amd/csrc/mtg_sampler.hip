@@ -4,15 +4,19 @@
 // 3.1.4 semantics restated in SURVEY.md Appendix B), for E independent ensembles of
 // W walkers at once, with the walkers, their log-probabilities, the random
 // numbers and the accept/reject step all resident on the GPU: one iteration is
-//     mtg_split_kernel      random red/blue split of every ensemble
-//     2 x { mtg_propose_kernel -> prepare + solve (the likelihood) -> mtg_accept_kernel }
-// enqueued on one stream with no host synchronisation in between.
+//     2 x { mtg_propose_kernel -> solve (the likelihood) -> mtg_accept_kernel }
+// enqueued on one stream with no host synchronisation in between.  The proposal kernel also
+// draws the red/blue split (first half-step) and expands the proposals into celerite
+// coefficients (mtg_prepare_one); the accept kernel also appends the state to the chain and
+// clears the structure lists for the next half-step: three launches per half-step where the
+// straightforward split | propose | memset | prepare | solve | accept | copy sequence needs six.
 //
 // Random numbers: Philox4x32-10 (Salmon et al. 2011), counter-based, so every draw is a
 // pure function of (seed, iteration, purpose, ensemble, walker) -- reproducible and
 // independent of launch geometry; tests/test_device_sampler_gpu.py replays the same
 // stream on the host.
 #include "mtg_device.h"
+#include "mtg_prepare.h"
 
 #include <math.h>
 
@@ -50,70 +54,78 @@ enum { PURPOSE_SPLIT = 1, PURPOSE_PROPOSE = 2, PURPOSE_ACCEPT = 3 };
 
 }  // namespace
 
-// Random red/blue split: a uniformly random permutation of 0..W-1 per ensemble, obtained by
-// ranking one 64-bit Philox key per walker (ties -- probability ~W^2 2^-65 -- broken by walker
-// index).  One workgroup per ensemble, keys in LDS, W broadcast reads per walker: microseconds
-// where a serial Fisher-Yates shuffle took 66 us at W = 256.  perm[e][0..W/2) is the first half.
+// Red/blue split + stretch proposal + theta -> coefficients for the `half`-th half of every
+// ensemble; one workgroup per ensemble.
+//   split (half 0 only; half 1 re-reads it): a uniformly random permutation of 0..W-1, obtained
+//     by ranking one 64-bit Philox key per walker (ties -- probability ~W^2 2^-65 -- broken by
+//     walker index); perm[e][0..W/2) is the first half.  Keys in LDS, W broadcast reads per walker.
+//   proposal: z = ((a - 1) u + 1)^2 / a,  q = c_partner - (c_partner - s) z,  factor = (P - 1) ln z.
+//   expansion: mtg_prepare_one on the proposal (prior verdict, coefficient columns, structure lists).
 __global__ void __launch_bounds__(256)
-mtg_split_kernel(int E, int W, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi, int32_t *perm)
+mtg_propose_kernel(int W, int P, int half, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi, double a,
+                   int32_t *__restrict__ perm, const double *__restrict__ coords, double *__restrict__ factor,
+                   MtgPrepArgs pa)
 {
     extern __shared__ uint64_t s_key[];
-    const int e = blockIdx.x;
-    for (int w = threadIdx.x; w < W; w += blockDim.x) {
-        const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, seed_lo, seed_hi);
-        s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
-    }
-    __syncthreads();
-    int32_t *p = perm + (int64_t)e * W;
-    for (int w = threadIdx.x; w < W; w += blockDim.x) {
-        const uint64_t mine = s_key[w];
-        int rank = 0;
-        for (int j = 0; j < W; ++j) {
-            const uint64_t other = s_key[j];
-            rank += (other < mine) || (other == mine && j < w);
-        }
-        p[rank] = w;
-    }
-}
-
-// Stretch proposal for the `half`-th half of every ensemble:
-//   z = ((a - 1) u + 1)^2 / a,  q = c_partner - (c_partner - s) z,  factor = (P - 1) ln z.
-__global__ void __launch_bounds__(256)
-mtg_propose_kernel(int E, int W, int P, int half, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi,
-                   double a, const int32_t *__restrict__ perm, const double *__restrict__ coords,
-                   double *__restrict__ q, double *__restrict__ factor)
-{
     const int H = W / 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)E * H) return;
-    const int e = (int)(i / H), k = (int)(i % H);
-    const int32_t *p = perm + (int64_t)e * W;
-    const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16 * half, (uint32_t)e, (uint32_t)k, seed_lo, seed_hi);
-    const double u = u01(r.c[0], r.c[1]);
-    const double zr = (a - 1.0) * u + 1.0;
-    const double z = zr * zr / a;
-    const int w = p[half * H + k];
-    const int partner = p[(1 - half) * H + (int)(u01(r.c[2], r.c[3]) * (double)H)];
-    const double *s = coords + ((int64_t)e * W + w) * P;
-    const double *c = coords + ((int64_t)e * W + partner) * P;
-    double *qo = q + i * P;
-    for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
-    factor[i] = (double)(P - 1) * log(z);
+    const int e = blockIdx.x;
+    int32_t *p = perm + (int64_t)e * W;
+    if (half == 0) {
+        for (int w = threadIdx.x; w < W; w += blockDim.x) {
+            const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, seed_lo, seed_hi);
+            s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
+        }
+        __syncthreads();
+        for (int w = threadIdx.x; w < W; w += blockDim.x) {
+            const uint64_t mine = s_key[w];
+            int rank = 0;
+            for (int j = 0; j < W; ++j) {
+                const uint64_t other = s_key[j];
+                rank += (other < mine) || (other == mine && j < w);
+            }
+            p[rank] = w;
+        }
+        __syncthreads();  // the permutation is read back below (same workgroup: visible after the barrier)
+    }
+    double *q = const_cast<double *>(pa.theta);  // the proposals ARE the batch the expansion reads
+    for (int k0 = 0; k0 < H; k0 += blockDim.x) {  // uniform trip count: mtg_prepare_one votes per wave
+        const int k = k0 + (int)threadIdx.x;
+        const bool live = k < H;
+        const int64_t i = (int64_t)e * H + (live ? k : 0);
+        if (live) {
+            const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16 * half, (uint32_t)e, (uint32_t)k, seed_lo, seed_hi);
+            const double u = u01(r.c[0], r.c[1]);
+            const double zr = (a - 1.0) * u + 1.0;
+            const double z = zr * zr / a;
+            const int w = p[half * H + k];
+            const int partner = p[(1 - half) * H + (int)(u01(r.c[2], r.c[3]) * (double)H)];
+            const double *s = coords + ((int64_t)e * W + w) * P;
+            const double *c = coords + ((int64_t)e * W + partner) * P;
+            double *qo = q + i * P;
+            for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
+            factor[i] = (double)(P - 1) * log(z);
+        }
+        mtg_prepare_one(pa, i, live);
+    }
 }
 
-// Accept / reject, state update, per-ensemble running best.  One workgroup per ensemble.
+// Accept / reject, state update, per-ensemble running best; then the housekeeping of the
+// half-step: clear the structure lists' counters for the next expansion and, after the second
+// half, append the ensemble's state to the chain.  One workgroup per ensemble.
 __global__ void __launch_bounds__(256)
 mtg_accept_kernel(int E, int W, int P, int half, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi,
                   const int32_t *__restrict__ perm, const double *__restrict__ q,
                   const double *__restrict__ factor, const double *__restrict__ new_lnp,
                   const int32_t *__restrict__ status, double *__restrict__ coords, double *__restrict__ lnp,
                   int32_t *__restrict__ naccept, double *__restrict__ best_lnp,
-                  double *__restrict__ best_coords, int32_t *__restrict__ n_notpd)
+                  double *__restrict__ best_coords, int32_t *__restrict__ n_notpd, int *__restrict__ counts,
+                  double *__restrict__ chain_row, double *__restrict__ lnp_chain_row)
 {
     const int H = W / 2;
     const int e = blockIdx.x;
     __shared__ double s_best[256];
     __shared__ int s_idx[256];
+    if (e == 0 && threadIdx.x < 64) counts[threadIdx.x] = 0;  // the solver of this half-step is done with them
     double my_best = -INFINITY;
     int my_idx = -1;
     for (int k = threadIdx.x; k < H; k += blockDim.x) {
@@ -146,6 +158,13 @@ mtg_accept_kernel(int E, int W, int P, int half, uint32_t iteration, uint32_t se
         best_lnp[e] = s_best[0];
         for (int d = 0; d < P; ++d) best_coords[(int64_t)e * P + d] = q[(int64_t)s_idx[0] * P + d];
     }
+    // emcee stores the ensemble after both halves moved (every update of this ensemble's walkers
+    // was made by this workgroup, before the barriers above)
+    if (chain_row)
+        for (int j = threadIdx.x; j < W * P; j += blockDim.x)
+            chain_row[(int64_t)e * W * P + j] = coords[(int64_t)e * W * P + j];
+    if (lnp_chain_row)
+        for (int w = threadIdx.x; w < W; w += blockDim.x) lnp_chain_row[(int64_t)e * W + w] = lnp[(int64_t)e * W + w];
 }
 
 // Running best of the INITIAL state (before any move).
@@ -165,29 +184,22 @@ mtg_initial_best_kernel(int E, int W, int P, const double *__restrict__ coords, 
     for (int d = 0; d < P; ++d) best_coords[(int64_t)e * P + d] = coords[((int64_t)e * W + bi) * P + d];
 }
 
-void mtg_launch_split(int E, int W, uint32_t iteration, uint64_t seed, int32_t *perm, hipStream_t s)
+void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a, int32_t *perm,
+                        const double *coords, double *factor, const MtgPrepArgs &pa, hipStream_t s)
 {
-    const int threads = W >= 256 ? 256 : (W + 63) / 64 * 64;
-    hipLaunchKernelGGL(mtg_split_kernel, dim3(E), dim3(threads), (size_t)W * sizeof(uint64_t), s, E, W, iteration,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), perm);
-}
-
-void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a,
-                        const int32_t *perm, const double *coords, double *q, double *factor, hipStream_t s)
-{
-    const int64_t n = (int64_t)E * (W / 2);
-    hipLaunchKernelGGL(mtg_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, E, W, P, half,
-                       iteration, (uint32_t)seed, (uint32_t)(seed >> 32), a, perm, coords, q, factor);
+    const int threads = W / 2 >= 256 ? 256 : (W / 2 + 63) / 64 * 64;
+    hipLaunchKernelGGL(mtg_propose_kernel, dim3(E), dim3(threads), (size_t)W * sizeof(uint64_t), s, W, P, half, iteration,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), a, perm, coords, factor, pa);
 }
 
 void mtg_launch_accept(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, const int32_t *perm,
                        const double *q, const double *factor, const double *new_lnp, const int32_t *status,
                        double *coords, double *lnp, int32_t *naccept, double *best_lnp, double *best_coords,
-                       int32_t *n_notpd, hipStream_t s)
+                       int32_t *n_notpd, int *counts, double *chain_row, double *lnp_chain_row, hipStream_t s)
 {
     hipLaunchKernelGGL(mtg_accept_kernel, dim3(E), dim3(256), 0, s, E, W, P, half, iteration, (uint32_t)seed,
                        (uint32_t)(seed >> 32), perm, q, factor, new_lnp, status, coords, lnp, naccept, best_lnp,
-                       best_coords, n_notpd);
+                       best_coords, n_notpd, counts, chain_row, lnp_chain_row);
 }
 
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
