@@ -229,6 +229,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // the mean vanishes identically when it is a frozen constant equal to 0 (the
     // per-light-curve frozen mean lives in y_offset)
     sa.has_mean = !(m.mean_kind == MTG_MEAN_CONSTANT && m.src[m.nk] < 0 && m.defaults[m.nk] == 0.0);
+    for (int i = 0; i < m.nterms; ++i)
+        if (m.kinds[i] == MTG_TERM_JITTER) sa.has_mean = 1;  // the plain sweep variant also skips the jitter add
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
     // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip).
     // Measured crossovers: J <= 6 (elements in registers) pays up to ~1000 evaluations; the J = 10
@@ -593,6 +595,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
             asum += a_comp[b * jc + k];
         }
         h[lay.asum() * cs + b] = asum;
+        h[lay.jit() * cs + b] = jitter ? jitter[b] : 0.0;
         // slots are (slope, intercept); a constant mean is slope 0
         const double m0 = mean_params ? mean_params[b * nmean] : 0.0;
         h[lay.mean(0) * cs + b] = nmean == 2 ? m0 : 0.0;
@@ -629,7 +632,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
     sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
     sa.mean_kind = mean_kind;
-    sa.has_mean = mean_params != nullptr;
+    sa.has_mean = mean_params != nullptr || jitter != nullptr;
     sa.tp_ws = nullptr;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));

@@ -29,7 +29,7 @@ struct MtgModel {
 // Coefficient workspace: structure-of-arrays, one column per evaluation so that
 // lane e reads/writes coef[slot * stride + e] (coalesced).  Slots:
 //   a_real[nr_max] c_real[nr_max] a_comp[nc_max] b_comp[nc_max] c_comp[nc_max]
-//   d_comp[nc_max] asum(= sum a + jitter) mean_slope mean_intercept
+//   d_comp[nc_max] asum(= sum a + jitter) mean_slope mean_intercept jitter
 struct MtgCoefLayout {
     int nr_max, nc_max;
     __host__ __device__ int ar(int j) const { return j; }
@@ -40,7 +40,8 @@ struct MtgCoefLayout {
     __host__ __device__ int dc(int k) const { return 2 * nr_max + 3 * nc_max + k; }
     __host__ __device__ int asum() const { return 2 * nr_max + 4 * nc_max; }
     __host__ __device__ int mean(int i) const { return 2 * nr_max + 4 * nc_max + 1 + i; }
-    __host__ __device__ int nslots() const { return 2 * nr_max + 4 * nc_max + 3; }
+    __host__ __device__ int jit() const { return 2 * nr_max + 4 * nc_max + 3; }
+    __host__ __device__ int nslots() const { return 2 * nr_max + 4 * nc_max + 4; }
 };
 
 struct MtgPrepArgs {
@@ -76,7 +77,7 @@ struct MtgSolveArgs {
     uint32_t dxt_bytes;
     const double *dxmax;  // [1] max_n dx_n (device): decides table vs OCML sincos per wave
     int mean_kind;
-    int has_mean;  // 0: the mean is identically zero for every evaluation of this launch
+    int has_mean;  // 0: the mean is identically zero for every evaluation of this launch and the model has no jitter term
     // time-parallel kernels of rank J > 6 only: [B][256] chunk elements of MTG_TP_ELEM(J) doubles
     // (they do not fit in LDS); NULL otherwise
     double *tp_ws;

@@ -102,7 +102,7 @@ struct MtgLane {
     static constexpr int J = NR + 2 * NC;
     double ar[NR > 0 ? NR : 1], cr[NR > 0 ? NR : 1];
     double ac[NC > 0 ? NC : 1], bc[NC > 0 ? NC : 1], cc[NC > 0 ? NC : 1], dc[NC > 0 ? NC : 1];
-    double asum, slope, icpt;
+    double jit, slope, icpt;
     double S[J * (J + 1) / 2];
     double Wt[J];  // V_n - S U_n  (W_n = Wt / D_n)
     double f[J];
@@ -119,8 +119,9 @@ struct MtgLane {
 // back edge), so the scheduler can hoist the five table look-ups and the next
 // sample's loads above the polynomial/recurrence arithmetic.
 //   FAST: every lane's d_k * max(dx) is inside the exact range of the table sincos.
-//   MEAN: a mean function has to be subtracted (false: it is identically zero, the
-//         frozen per-light-curve constant having been folded into y at upload).
+//   MEAN: a mean function has to be subtracted or a jitter term added (false: the mean is
+//         identically zero, the frozen per-light-curve constant having been folded into y at
+//         upload, and the model has no JitterTerm).
 template <int NR, int NC, bool FAST, bool MEAN>
 __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, uint32_t yoff,
                                           uint32_t toff, const MtgMathTablesT<(NC > 0)> *tab)
@@ -191,18 +192,20 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
             L.f[i] = ph[ti] * fma(L.Wt[i], zs, L.f[i]);
         }
         // -- D_n = A_n - U^T S U ; Wt = V - S U ; z_n = r_n - U^T f -------------
-        double D = vc + L.asum;
+        // U^T V = sum of the a_j (the kernel at lag 0), so A_n - U^T S U = sigma_n^2 + jitter + U^T Wt:
+        // the subtraction V - S U rides on the multiply-add chain and D needs no second pass over q
+        double D = MEAN ? vc + L.jit : vc;
         double zn = MEAN ? yc - fma(L.slope, tc, L.icpt) : yc;
 #pragma unroll
         for (int i = 0; i < J; ++i) {
-            double q = 0.0;
+            double w = V[i];
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int hi = i > j ? i : j, lo = i > j ? j : i;
-                q = fma(L.S[hi * (hi + 1) / 2 + lo], U[j], q);
+                w = fma(-L.S[hi * (hi + 1) / 2 + lo], U[j], w);
             }
-            L.Wt[i] = V[i] - q;
-            D = fma(-U[i], q, D);
+            L.Wt[i] = w;
+            D = fma(U[i], w, D);
             zn = fma(-U[i], L.f[i], zn);
         }
         L.dmin_hi = min(L.dmin_hi, __double2hiint(D));  // sign / zero test on the high dword
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
         L.dc[k] = cf[a.lay.dc(k) * cs];
         dmax = fmax(dmax, fabs(L.dc[k]));
     }
-    L.asum = cf[a.lay.asum() * cs];
+    L.jit = cf[a.lay.jit() * cs];
     L.slope = cf[a.lay.mean(0) * cs];
     L.icpt = cf[a.lay.mean(1) * cs];
 #pragma unroll

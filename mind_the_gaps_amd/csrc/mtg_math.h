@@ -129,11 +129,17 @@ __device__ __forceinline__ void mtg_phase_step(double d, double dx, double &r, i
     const double x = __builtin_fma(d, dx, r);
     const double w = __builtin_fma(x, 0x1.45f306dc9c883p+1 * MTG_TRIG_N, magic);    // x 16 N / 2 pi
     const double md16 = w - magic;                                                  // 16 rint(x N / 2 pi)
-    double rr = __builtin_fma(md16, -(0x1.921fb40000000p-2 / MTG_TRIG_N), x);       // 2 pi / 16 N
-    rr = __builtin_fma(md16, -(0x1.4442d18469899p-26 / MTG_TRIG_N), rr);
-    m16 = (m16 + (int)md16) & ((MTG_TRIG_N - 1) * 16);
+    // One-constant reduction: the fma forms md16 * C exactly, so the only error is that of C itself
+    // (<= 2^-53 relative), i.e. the accumulated phase is d (1 + eps) (t_n - t_0) with ONE eps for the
+    // whole sweep -- a perturbation of the frequency below its own rounding, not a drift.
+    const double rr = __builtin_fma(md16, -(0x1.921fb54442d18p-2 / MTG_TRIG_N), x);  // 2 pi / 16 N
+    // the low mantissa dword of w is rint(x N / 2 pi) (two's complement): shift-add, no cvt; m16 wraps
+    // freely and is masked where it is used
+    // (v_lshl_add_u32 spelled out: left to itself the compiler narrows the masked sum to packed
+    // 16-bit arithmetic, which takes more instructions)
+    asm("v_lshl_add_u32 %0, %1, 4, %0" : "+v"(m16) : "v"(__double2loint(w)));
     r = rr;
-    const double2 cj = *(const double2 *)((const char *)tab->cis + m16);
+    const double2 cj = *(const double2 *)((const char *)tab->cis + (m16 & ((MTG_TRIG_N - 1) * 16)));
     double s, c;
     mtg_sincos_small(rr, &s, &c);
     *sn = __builtin_fma(cj.x, s, cj.y * c);
@@ -146,16 +152,26 @@ __device__ __forceinline__ void mtg_phase_step(double d, double dx, double &r, i
 // a propagator that multiplies bounded state.  Far below the underflow point q
 // saturates (cvt) and ldexp returns 0.
 #define MTG_EXP_CSCALE (0x1.71547652b82fep+3 * MTG_EXP_N)                           /* 8 N / ln2 */
+#define MTG_EXP_C1 (0x1.62e42fefa39efp-4 / MTG_EXP_N)                               /* ln2 / 8 N */
 template <class Tab>
 __device__ __forceinline__ double mtg_exp_cdx(double negc, double cs8, double dx, const Tab *tab)
 {
     const double magic = 0x1.8p+55;                                                 // 1.5 * 2^(52+3)
     const double w = __builtin_fma(dx, cs8, magic);
     const double q8 = w - magic;                                                    // 8 rint(y N / ln2)
-    const double r = __builtin_fma(q8, -(0x1.62e42fefa39efp-4 / MTG_EXP_N), negc * dx);
     const int i8 = (int)q8;                                                         // saturates: huge c dx -> 0
     const double t = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+#if MTG_EXP_BITS >= 11
+    // remainder in table units, exact in the fma: y 8N/ln2 - q8 = f, r = f ln2/8N with |r| <= ln2/2N;
+    // exp(r) - 1 = f (C + f (C^2/2 + f C^3/6)) with the unit folded into the coefficients
+    (void)negc;
+    const double f = __builtin_fma(dx, cs8, -q8);
+    double p = __builtin_fma(f, MTG_EXP_C1 * MTG_EXP_C1 * MTG_EXP_C1 / 6.0, MTG_EXP_C1 * MTG_EXP_C1 / 2.0);
+    p = __builtin_fma(p, f, MTG_EXP_C1) * f;
+#else
+    const double r = __builtin_fma(q8, -MTG_EXP_C1, negc * dx);
     const double p = mtg_expm1_small(r);
+#endif
     return __builtin_ldexp(__builtin_fma(t, p, t), i8 >> (3 + MTG_EXP_BITS));
 }
 

@@ -45,7 +45,7 @@ __device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e,
         double *c = a.coef + e;
         const int64_t cs = a.cstride;
         int ir = 0, ic = 0;
-        double asum = 0.0;
+        double asum = 0.0, jit = 0.0;
         for (int i = 0; i < m.nterms; ++i) {
             const int o = m.poff[i];
             switch (m.kinds[i]) {
@@ -97,9 +97,11 @@ __device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e,
                 asum += av;
                 break;
             }
-            case MTG_TERM_JITTER:
-                asum += exp(2.0 * par(o));
+            case MTG_TERM_JITTER: {
+                const double jv = exp(2.0 * par(o));
+                asum += jv; jit += jv;
                 break;
+            }
             case MTG_TERM_DRW: {  // celerite_models.py:58-66, Q = 1/2
                 const double av = exp(par(o));
                 c[lay.ar(ir) * cs] = av; c[lay.cr(ir) * cs] = 0.5 * exp(par(o + 1)) / 0.5; ++ir;
@@ -137,6 +139,7 @@ __device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e,
             }
         }
         c[lay.asum() * cs] = asum;
+        c[lay.jit() * cs] = jit;
         // mean(t) = slope * t + intercept; a constant mean is slope 0 (exactly the value)
         c[lay.mean(0) * cs] = m.mean_kind == MTG_MEAN_LINEAR ? par(m.nk) : 0.0;
         c[lay.mean(1) * cs] = m.mean_kind == MTG_MEAN_LINEAR ? par(m.nk + 1) : par(m.nk);
