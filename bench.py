@@ -132,11 +132,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal only: more ranks than GPUs (e.g. two ranks on a one-GPU box) share the cards and agree on
+    # the timing over gloo -- RCCL refuses two ranks on one device.  The line then says "oversubscribed".
+    ndev = torch.cuda.device_count()
+    oversubscribed = world > ndev
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if oversubscribed:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from mind_the_gaps_amd import synthetic as synth
     from mind_the_gaps_amd.engine import Engine
@@ -153,7 +161,7 @@ def main():
     y_mean = y.mean(axis=1)
     lc = np.repeat(np.arange(L, dtype=np.int32), W)
 
-    eng = Engine(local_rank)
+    eng = Engine(local_dev)
     eng.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)   # uploaded once; resident for the whole run
     eng.set_model(kinds, full, free, bounds)
     d_theta = torch.from_numpy(theta).to(dev)
@@ -184,7 +192,7 @@ def main():
     prep_ms, solve_ms = eng.profile_read()
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversubscribed else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -247,6 +255,8 @@ def main():
                               "peak_tflops": 78.6},
             },
         }
+        if oversubscribed:
+            line["oversubscribed"] = "%d ranks on %d GPU(s): rehearsal of the multi-rank path, not a scaling number" % (world, ndev)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds)
             try:
