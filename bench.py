@@ -63,26 +63,39 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds):
-    """oracle/celerite_ref.c on all usable host cores, same inputs, bounded sample."""
+def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds, bounds=None, gpu_out=None, gpu_status=None):
+    """oracle/celerite_ref.c on all usable host cores, same inputs, bounded sample.  The values it
+    produces are the first evaluations of the timed GPU batch, so they double as a parity check of
+    that batch (outside both timed regions): the worst relative difference goes into the line."""
     from oracle import celerite as oracle_c
     cores = usable_cores()
     oracle_c.lib()
     L = y.shape[0]
     chunk = max(cores * 32, 64)
-    done, t0 = 0, time.perf_counter()
+    done, spent, worst, compared = 0, 0.0, 0.0, 0
     while True:
         idx = (np.arange(chunk) + done) % theta.shape[0]
         lc = (idx // (theta.shape[0] // L)).astype(np.int32) % L
         full = np.hstack([theta[idx], y_mean[lc][:, None]])
-        oracle_c.logprob_batch(t, y, dy, kinds, full, lc_index=lc, nthreads=cores)
+        t0 = time.perf_counter()
+        ref, rstatus = oracle_c.logprob_batch(t, y, dy, kinds, full, bounds=bounds, lc_index=lc,
+                                              add_prior=bounds is not None, nthreads=cores)
+        spent += time.perf_counter() - t0
+        if gpu_out is not None and done + chunk <= theta.shape[0]:
+            ok = (rstatus == 0) & (gpu_status[idx] == 0)
+            if not np.array_equal(rstatus == 0, gpu_status[idx] == 0):
+                raise SystemExit("bench: GPU and CPU port disagree on which evaluations are valid")
+            worst = max(worst, float(np.max(np.abs(gpu_out[idx][ok] - ref[ok]) / np.abs(ref[ok]))))
+            compared += int(ok.sum())
         done += chunk
-        el = time.perf_counter() - t0
-        if el >= seconds:
+        if spent >= seconds:
             break
-    return {"value": done / el, "unit": "evals/s", "cores": cores, "kind": "port",
+    if compared and worst > 1e-8:
+        raise SystemExit("bench: GPU batch differs from the CPU port by %.3e relative (> 1e-8)" % worst)
+    return {"value": done / spent, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "%d evaluations of the same workload (N=%d, J=6) in %.1f s, OpenMP over %d "
-                      "threads, oracle/celerite_ref.c" % (done, len(t), el, cores)}
+                      "threads, oracle/celerite_ref.c (gcc -O2)" % (done, len(t), spent, cores),
+            "max_rel_diff_vs_gpu": worst if compared else None, "compared": compared}
 
 
 def single_lightcurve_configs():
@@ -258,7 +271,7 @@ def main():
         if oversubscribed:
             line["oversubscribed"] = "%d ranks on %d GPU(s): rehearsal of the multi-rank path, not a scaling number" % (world, ndev)
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds, bounds, out, status)
             try:
                 line["other_configs"] = single_lightcurve_configs()
             except Exception as exc:  # never let the side measurements break the headline line

@@ -18,6 +18,7 @@ import numpy as np
 
 from .gp import DeviceModel, LogProbEvaluator
 from .modeling import ConstantModel
+from .models.psd_models import PSDModel
 from .terms import Term
 
 __all__ = ["Simulator"]
@@ -29,8 +30,9 @@ class Simulator:
     def __init__(self, psd_model, times, exposures, mean, pdf="gaussian", bkg_rate=None, bkg_rate_err=None,
                  sigma_noise=None, aliasing_factor=2, extension_factor=10, epsilon=1.001, max_iter=400,
                  random_state=None, device=0):
-        """``psd_model``: the kernel ``Term`` whose PSD drives the simulation, or its bound
-        ``get_psd`` (what gpmodelling.py:509 passes).  Other arguments as in the reference."""
+        """``psd_model``: the kernel ``Term`` whose PSD drives the simulation, its bound
+        ``get_psd`` (what gpmodelling.py:509 passes), or one of the closed-form spectra of
+        ``models.psd_models`` (what the tutorials pass).  Other arguments as in the reference."""
         if extension_factor < 1:
             raise ValueError("Extension factor must be greater than 1")
         if epsilon < 1:
@@ -90,8 +92,13 @@ class Simulator:
     @psd_model.setter
     def psd_model(self, new_psd_model):
         kernel = getattr(new_psd_model, "__self__", new_psd_model)
+        if isinstance(kernel, PSDModel):
+            # the reference's closed-form spectra (models/psd_models.py): every one that is the
+            # spectrum of a celerite term is simulated through that term's coefficients
+            kernel = kernel.to_term()
         if not isinstance(kernel, Term):
-            raise ValueError("PSD model must be a mind_the_gaps_amd Term or its get_psd method")
+            raise ValueError("PSD model must be a Term, its get_psd method, or a models.psd_models spectrum "
+                             "with a celerite equivalent")
         self._kernel = kernel
 
     def _engine_and_model(self):

@@ -170,3 +170,21 @@ def test_simulated_set_stays_resident_and_generate_from_posteriors(engine):
     g0._mcmc_samples = g._mcmc_samples
     with pytest.raises(ValueError):                       # "Some exposure times are 0!" (simulator.py:201-202)
         g0.generate_from_posteriors(2)
+
+
+def test_closed_form_spectra_drive_the_simulator_like_their_terms():
+    """The tutorials hand Simulator the closed-form spectra of models/psd_models.py
+    (tutorial_ppp.ipynb: Lorentzian + BendingPowerlaw); they simulate through the celerite
+    term they are the spectrum of: same seed, same light curves."""
+    from mind_the_gaps_amd.models import psd_models as psd
+    times, exposure = regular_pattern(200)
+    spectrum = psd.Lorentzian(30.0, 20.0, 0.7) + psd.BendingPowerlaw(100.0, 2 * np.pi / 20)
+    kernel = Lorentzian(np.log(30.0), np.log(20.0), np.log(0.7)) + DampedRandomWalk(np.log(100.0), np.log(2 * np.pi / 20))
+    a = Simulator(spectrum, times, exposure, 10.0, "Gaussian", sigma_noise=1.0, extension_factor=3, random_state=1)
+    b = Simulator(kernel, times, exposure, 10.0, "Gaussian", sigma_noise=1.0, extension_factor=3, random_state=1)
+    ra, rb = a.simulate(noise=False, seed=77)["rates"], b.simulate(noise=False, seed=77)["rates"]
+    assert np.array_equal(ra, rb)
+    w = np.linspace(0.01, 5, 50)
+    assert np.allclose(a.psd_model(w), spectrum(w), rtol=1e-10)
+    with pytest.raises(ValueError):
+        Simulator(psd.Matern52(), times, exposure, 10.0, "Gaussian", sigma_noise=1.0)
