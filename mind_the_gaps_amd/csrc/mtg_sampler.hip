@@ -241,10 +241,7 @@ __global__ void __launch_bounds__(64) mtg_predict_kernel(MtgPredictArgs a)
         cc[k] = cf[a.lay.cc(k) * cs]; dc[k] = cf[a.lay.dc(k) * cs];
     }
     const double asum = cf[a.lay.asum() * cs], slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
-    double ksum = 0.0;  // k(0) = sum of amplitudes
-    for (int j = 0; j < NR; ++j) ksum += ar[j];
-    for (int k = 0; k < NC; ++k) ksum += ac[k];
-    const double jitter = asum - ksum;
+    const double jitter = cf[a.lay.jit() * cs];
     const int64_t lc = a.lc_index ? a.lc_index[e] : 0;
     const int64_t N = a.N;
     const double2 *yv = a.yv + lc * N, *dxt = a.dxt + lc * a.t_stride;

@@ -868,12 +868,7 @@ __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, c
         M.pc[k] = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
         dmax = fmax(dmax, fabs(d));
     }
-    double ksum = 0.0;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) ksum += M.ar[j];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) ksum += M.ac[k];
-    const double jitter = cf[a.lay.asum() * cs] - ksum;
+    const double jitter = cf[a.lay.jit() * cs];
     const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
     const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
     // a device-side lc_index cannot be validated by the host: this kernel reads through raw
