@@ -14,7 +14,7 @@ ensemble.  Nothing here computes a likelihood: ``evaluate`` is the engine call.
 import numpy as np
 
 __all__ = ["block_bounds", "shard_rows", "shard_lightcurves", "all_gather_rows",
-           "sharded_log_prob", "LightcurveShard"]
+           "sharded_log_prob", "LightcurveShard", "WalkerShardedLogProb", "lockstep"]
 
 
 def block_bounds(n_items, world_size):
@@ -125,3 +125,50 @@ class LightcurveShard:
         if self.world == 1:
             return values
         return all_gather_rows(values, np.diff(self.bounds), self.group, device)
+
+
+class WalkerShardedLogProb:
+    """``log_prob_fn`` of a walker-sharded ensemble (one replicated light curve, BASELINE
+    configs[1], [2], [4]): every rank holds the light curve, is handed
+    the SAME half-ensemble ``coords[B, P]`` by its own copy of the sampler, evaluates rows
+    ``shard_rows(B, rank, world)`` on its GPU and all-gathers the log-probabilities (8 bytes per
+    walker over RCCL), so that every rank takes the identical accept/reject decisions.
+
+    ``log_prob_fn(coords[b, P]) -> lnP[b]`` is the local engine call (e.g.
+    ``GPModelling._log_probability``).  Exceptions it raises (a non positive-definite
+    covariance in strict mode) are raised on EVERY rank after the collective, so that no rank
+    is left waiting in the all-gather."""
+
+    def __init__(self, log_prob_fn, group=None, device=None):
+        self.log_prob_fn, self.group, self.device = log_prob_fn, group, device
+
+    def __call__(self, coords):
+        failure = []
+
+        def evaluate(theta, lc_rows):
+            try:
+                lnp = np.asarray(self.log_prob_fn(theta), dtype=np.float64)
+                return lnp, np.zeros(len(lnp), dtype=np.int32)
+            except Exception as exc:  # re-raised below, after the collective
+                failure.append(exc)
+                return np.full(len(theta), np.nan), np.ones(len(theta), dtype=np.int32)
+
+        lnp, status = sharded_log_prob(evaluate, coords, None, self.group, self.device)
+        if failure:
+            raise failure[0]
+        if np.any(status != 0):
+            raise RuntimeError("the log-probability failed on another rank of the walker-sharded ensemble")
+        return lnp
+
+
+def lockstep(sampler, p0, group=None):
+    """Put the ranks' copies of a host-side ``EnsembleSampler`` in lock-step: rank 0's random
+    state and starting ensemble go to every rank (the reference seeds neither; emcee copies
+    numpy's global state, which differs between processes).  Returns the common ``p0``."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return np.asarray(p0, dtype=np.float64)
+    objs = [sampler.random_state, np.asarray(p0, dtype=np.float64)] if dist.get_rank(group) == 0 else [None, None]
+    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    sampler.random_state = objs[0]
+    return objs[1]

@@ -155,7 +155,8 @@ class GPModelling:
 
     def derive_posteriors(self, initial_chain_params=None, fit: bool = True, converge: bool = True,
                           max_steps: int = 10000, convergence_steps: int = 500, walkers: int = 12,
-                          cores: int = 6, progress: bool = True, device_sampler: bool = None):
+                          cores: int = 6, progress: bool = True, device_sampler: bool = None,
+                          shard_walkers: bool = False, group=None):
         """Derive GP posteriors (gpmodelling.py:197-286): optional fit, walker
         spreading, stretch-move MCMC with an autocorrelation-time convergence check
         every ``convergence_steps`` iterations, then burn-in and thinning.
@@ -166,7 +167,17 @@ class GPModelling:
         device can expand.  Default (None): on whenever that holds -- 2-3x the iteration rate of
         the host-side sampler; like emcee's, the run is reproducible from ``np.random.seed``
         (the Philox key is drawn from numpy's global generator).  False: the host-side sampler
-        with emcee's own use of numpy's global generator."""
+        with emcee's own use of numpy's global generator.
+
+        ``shard_walkers`` (new, optional): inside a ``torch.distributed`` job (one process per
+        GPU, every rank holding this light curve and calling this method with the same
+        arguments) split every half-ensemble across the ranks: each GPU evaluates its rows,
+        one all-gather of the log-probabilities per half-step (``group``: the process group,
+        default the world), identical accept/reject everywhere -- every rank ends with the
+        same chain.  Uses the host-side sampler; rank 0's random state and starting ensemble
+        are broadcast first."""
+        if shard_walkers:
+            device_sampler = False
         if device_sampler is None:
             model = self.gp._device_model()
             device_sampler = walkers % 2 == 0 and bool(model.device_terms) and model.mean_kind is not None
@@ -197,7 +208,13 @@ class GPModelling:
                     yield done
             steps_iter = iterations()
         else:
-            sampler = EnsembleSampler(walkers, self._ndim, self._log_probability, vectorize=True)
+            log_prob_fn = self._log_probability
+            if shard_walkers:
+                from .distributed import WalkerShardedLogProb, lockstep
+                log_prob_fn = WalkerShardedLogProb(self._log_probability, group=group)
+            sampler = EnsembleSampler(walkers, self._ndim, log_prob_fn, vectorize=True)
+            if shard_walkers:
+                initial_chain_params = lockstep(sampler, initial_chain_params, group=group)
             steps_iter = sampler.sample(initial_chain_params, iterations=max_steps, progress=progress)
         for sample in steps_iter:
             if sampler.iteration % every_samples:

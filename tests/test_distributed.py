@@ -131,3 +131,141 @@ def test_two_rank_sharded_posteriors(tmp_path):
     assert np.array_equal(r0["best"], r1["best"]) and r0["best"].shape == (5,)
     assert np.array_equal(r0["best"][:3], r0["local"]) and np.array_equal(r0["best"][3:], r1["local"])
     assert np.all(np.isfinite(r0["best"]))
+
+
+# ---- walker-sharded chain of ONE light curve (BASELINE configs[1], [2], [4]) ----
+def _chain_problem():
+    kinds = synth.NULL_MODEL
+    t, y, dy = synth.make_lightcurves(80, 1, seed=31)
+    bounds = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)]])
+    truth = synth.truth(kinds)
+    return kinds, t, y, dy, bounds, truth
+
+
+def _oracle_log_prob(coords):
+    from oracle import celerite as oracle_c
+    kinds, t, y, dy, bounds, _ = _chain_problem()
+    full = np.hstack([coords, np.full((len(coords), 1), y.mean())])
+    return oracle_c.logprob_batch(t, y, dy, kinds, full, bounds=bounds, add_prior=True)[0]
+
+
+def _chain_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mind_the_gaps_amd.sampler import EnsembleSampler
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    truth = _chain_problem()[5]
+    W, P = 12, len(truth)
+    np.random.seed(100 + rank)                         # every rank starts from a different generator
+    p0 = truth + 0.01 * np.random.randn(W, P)          # ... and a different ensemble
+    calls = []
+
+    def local(coords):
+        calls.append(len(coords))
+        return _oracle_log_prob(coords)
+
+    sampler = EnsembleSampler(W, P, mdist.WalkerShardedLogProb(local))
+    p0 = mdist.lockstep(sampler, p0)
+    sampler.run_mcmc(p0, 15)
+    np.savez(os.path.join(out_dir, "chain%d.npz" % rank), chain=sampler.get_chain(), lnp=sampler.get_log_prob(),
+             calls=np.array(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_walker_sharded_chain(tmp_path):
+    """Two gloo ranks, one light curve: each evaluates half of every half-ensemble, both end with
+    the chain a single process produces from rank 0's generator and starting ensemble."""
+    import torch.multiprocessing as mp
+    from oracle import celerite as oracle_c
+    from mind_the_gaps_amd.sampler import EnsembleSampler
+    oracle_c.lib()
+    world, port = 2, _free_port()
+    mp.spawn(_chain_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / ("chain%d.npz" % r)) for r in range(world))
+    assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
+    # every half-step evaluated 6 proposals as 3 + 3 (the initial ensemble as 6 + 6)
+    assert list(r0["calls"]) == [6] + [3] * 30 and list(r1["calls"]) == [6] + [3] * 30
+    truth = _chain_problem()[5]
+    np.random.seed(100)
+    p0 = truth + 0.01 * np.random.randn(12, len(truth))
+    single = EnsembleSampler(12, len(truth), _oracle_log_prob)
+    single.run_mcmc(p0, 15)
+    assert np.array_equal(single.get_chain(), r0["chain"]) and np.array_equal(single.get_log_prob(), r0["lnp"])
+    assert len(np.unique(r0["chain"][:, 0, 0])) > 3          # the chain moved
+
+
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local(coords):
+        if rank == 1:
+            raise ArithmeticError("failed to factorize or solve matrix")
+        return np.zeros(len(coords))
+
+    try:
+        mdist.WalkerShardedLogProb(local)(np.zeros((4, 2)))
+        outcome = "returned"
+    except ArithmeticError:
+        outcome = "own error"
+    except RuntimeError:
+        outcome = "peer error"
+    open(os.path.join(out_dir, "fail%d.txt" % rank), "w").write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_reaches_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_failing_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "fail0.txt").read() == "peer error" and open(tmp_path / "fail1.txt").read() == "own error"
+
+
+def _gpu_chain_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import warnings
+    import torch.distributed as dist
+    from mind_the_gaps_amd.gpmodelling import GPModelling
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    from mind_the_gaps_amd.models import DampedRandomWalk
+    from mind_the_gaps_amd import terms
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    th = synth.truth(synth.NULL_MODEL)
+    t, y, dy = synth.make_lightcurves(300, 1, seed=41)
+    kernel = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)]) + terms.SHOTerm(
+        th[2], th[3], th[4], bounds=[(-10, 50), (-10, 10), (-10, 10)])
+    g = GPModelling(GappyLightcurve(t, y[0], dy[0]), kernel)
+    np.random.seed(7 if world == 1 else 7 + rank)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g.derive_posteriors(fit=False, max_steps=30, convergence_steps=30, walkers=16, progress=False,
+                            device_sampler=False, shard_walkers=world > 1)
+    np.savez(os.path.join(out_dir, "gpu%d_%d.npz" % (world, rank)), chain=g.sampler.get_chain(),
+             lnp=g.sampler.get_log_prob(), best=g.max_loglikelihood)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
+    """GPModelling.derive_posteriors(shard_walkers=True) on two ranks (sharing the box's GPU, gloo
+    for the gather): identical chains on both, equal to the single-process host-sampler chain."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_gpu_chain_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_gpu_chain_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r0, r1, single = (np.load(tmp_path / name) for name in ("gpu2_0.npz", "gpu2_1.npz", "gpu1_0.npz"))
+    assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
+    assert np.allclose(single["chain"], r0["chain"], rtol=1e-9, atol=0) and np.allclose(single["lnp"], r0["lnp"], rtol=1e-9)
+    assert np.isfinite(float(r0["best"]))
