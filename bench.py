@@ -261,10 +261,11 @@ def main():
                 "evals_per_launch": n_ok,
                 "kernel_ms": solve_s * 1e3,
                 "prepare_kernel_ms": float(np.mean(prep_ms)),
-                # the binding resource: FP64 vector issue.  97 FMA + 63 mul/add per sample and lane in
-                # the J = 6 sweep (scripts/loop_stats.py) against the 78.6 TFLOP/s FP64 vector peak
-                "fp64_valu": {"flop_per_sample": 2 * 97 + 63,
-                              "achieved_tflops": n_ok * N * (2 * 97 + 63) / solve_s / 1e12,
+                # the binding resource: FP64 vector issue (and, under it, board power).  93 FMA + 53
+                # mul/add per sample and lane in the J = 6 sweep of kernel v7 (scripts/loop_stats.py: 186
+                # fma, 96 mul, 10 add per two-step trip) against the 78.6 TFLOP/s FP64 vector peak
+                "fp64_valu": {"flop_per_sample": 2 * 93 + 53,
+                              "achieved_tflops": n_ok * N * (2 * 93 + 53) / solve_s / 1e12,
                               "peak_tflops": 78.6},
             },
         }
