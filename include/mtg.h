@@ -81,6 +81,15 @@ MTG_API void mtg_destroy(mtg_ctx *ctx);
 /* Message for the last non-zero return on this context (ctx may be NULL for
  * mtg_create failures). */
 MTG_API const char *mtg_last_error(const mtg_ctx *ctx);
+/*
+ * Testing aid.  The sweep reads samples through buffer descriptors with 32-bit byte
+ * offsets; for resident sets beyond 4 GiB every wave places its descriptor at the
+ * first light curve its 64 evaluations need and reaches the others within a window
+ * of `bytes` (default and maximum 2^32 - 1).  Evaluations further away (never, when
+ * a batch is grouped by light curve) are collected and swept one per wave by a
+ * second launch.  A small window lets a test exercise that logic on a small set.
+ */
+MTG_API int mtg_set_window_bytes(mtg_ctx *ctx, uint64_t bytes);
 
 /*
  * celerite.GP.compute(t, yerr) for L light curves at once; the reference calls
@@ -94,8 +103,9 @@ MTG_API const char *mtg_last_error(const mtg_ctx *ctx);
  * y_offset: [L] or NULL.  The reference freezes the mean of every light curve at
  * ITS OWN average, ConstantModel(lightcurve.mean) with fit_mean=False
  * (gpmodelling.py:83-87): pass those L values here (they are subtracted from y
- * once, at upload) and give the model a frozen mean of 0.  L * N must stay
- * below 2^28 samples (32-bit byte offsets in the kernel).
+ * once, at upload) and give the model a frozen mean of 0.  The set may be as
+ * large as the HBM allows (L * N * 32 bytes resident; the upload is staged in
+ * blocks); one light curve must stay below 2^28 samples.
  */
 MTG_API int mtg_set_lightcurves(mtg_ctx *ctx, int64_t N, int64_t L, const double *t, int t_per_lc,
                                 const double *y, const double *yerr, const double *y_offset);

@@ -54,6 +54,7 @@ struct mtg_ctx {
     // light curves (resident)
     int64_t N = 0, L = 0;
     int t_per_lc = 0;
+    uint64_t window_bytes = 0xffffffffull;  // reach of one buffer descriptor of the sweep (mtg_set_window_bytes)
     DevBuf dxt, yv, dxmax;  // interleaved (dx, t) and (y, sigma^2) pairs
     DevBuf t_tmp, y_tmp, dy_tmp, off_tmp;  // upload staging
 
@@ -64,6 +65,7 @@ struct mtg_ctx {
     // workspaces
     DevBuf coef, lists, counts, tp_ws;
     int64_t cstride = 0;
+    int nsig_ws = 1;  // signature lists the workspace was laid out for
     // staging for the host-pointer entry points
     DevBuf theta, lc, out, status;
 
@@ -133,7 +135,9 @@ int reserve_workspace(mtg_ctx *ctx, int64_t B, int nslots, int nsig)
     int64_t stride = (B + 63) / 64 * 64;
     if (stride < 64) stride = 64;
     HIP_TRY(ctx, ctx->coef.reserve((size_t)stride * nslots * sizeof(double)));
-    HIP_TRY(ctx, ctx->lists.reserve((size_t)stride * (nsig > 1 ? nsig : 1) * sizeof(int)));
+    // [nsig] signature lists, then [nsig] left-over lists of the windowed sweep (sweep_launch)
+    HIP_TRY(ctx, ctx->lists.reserve((size_t)stride * (nsig > 1 ? nsig : 1) * 2 * sizeof(int)));
+    ctx->nsig_ws = nsig > 1 ? nsig : 1;
     HIP_TRY(ctx, ctx->counts.reserve(64 * sizeof(int)));
     ctx->cstride = stride;
     return MTG_OK;
@@ -175,6 +179,34 @@ MtgPrepArgs make_prep_args(mtg_ctx *ctx, int64_t B, const double *d_theta, int a
     pa.status = d_status;
     pa.sig = nullptr;
     return pa;
+}
+
+// One launch of the serial sweep for structure k of the model.  When the resident set is larger than
+// the reach of a buffer descriptor the kernel leaves the evaluations a wave cannot reach from its
+// first light curve on a list; a second launch sweeps them one per wave (its workgroups find the
+// list empty and leave at once when batches are grouped by light curve, the usual case).
+int sweep_launch(mtg_ctx *ctx, mtg_solve_launcher fn, MtgSolveArgs sa, int64_t B, int k, hipStream_t s)
+{
+    sa.solo = 0;
+    sa.left_list = nullptr;
+    sa.left_count = nullptr;
+    if (sa.yv_bytes <= sa.window_bytes) {
+        fn(sa, B, s);
+        return MTG_OK;
+    }
+    int *left_list = ctx->lists.as<int>() + ((int64_t)ctx->nsig_ws + k) * ctx->cstride;
+    int *left_count = ctx->counts.as<int>() + 32 + k;
+    HIP_TRY(ctx, hipMemsetAsync(left_count, 0, sizeof(int), s));
+    sa.left_list = left_list;
+    sa.left_count = left_count;
+    fn(sa, B, s);
+    sa.solo = 1;
+    sa.list = left_list;
+    sa.count_ptr = left_count;
+    sa.left_list = nullptr;
+    sa.left_count = nullptr;
+    fn(sa, B * 64, s);  // one wave per left-over evaluation
+    return MTG_OK;
 }
 
 int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s);
@@ -223,8 +255,9 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     sa.N = ctx->N;
     sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
     sa.dxmax = ctx->dxmax.as<double>();
-    sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
-    sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
+    sa.yv_bytes = (uint64_t)ctx->L * (uint64_t)ctx->N * 16u;
+    sa.dxt_bytes = (uint64_t)(ctx->t_per_lc ? ctx->L : 1) * (uint64_t)ctx->N * 16u;
+    sa.window_bytes = ctx->window_bytes;
     sa.mean_kind = m.mean_kind;
     // the mean vanishes identically when it is a frozen constant equal to 0 (the
     // per-light-curve frozen mean lives in y_offset)
@@ -263,6 +296,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         if (wide) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256);
         if (!fused) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 64);
     }
+    sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
     if (fused) {  // every signature in one launch
         sa.list = ctx->lists.as<int>();
         sa.count_ptr = ctx->counts.as<int>();
@@ -276,7 +310,13 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
             sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
             sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
-            (tp ? tp : fn)(sa, B, s);
+            if (tp) {
+                sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
+                tp(sa, B, s);
+            } else {
+                const int rc = sweep_launch(ctx, fn, sa, B, k, s);
+                if (rc) return rc;
+            }
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -353,6 +393,16 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     delete ctx;
 }
 
+MTG_API int mtg_set_window_bytes(mtg_ctx *ctx, uint64_t bytes)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (bytes < 16 || bytes > 0xffffffffull) return fail(ctx, MTG_E_ARG, "mtg_set_window_bytes: 16 <= bytes < 2^32");
+    if (ctx->N > 0 && (uint64_t)ctx->N * 16u > bytes)
+        return fail(ctx, MTG_E_ARG, "mtg_set_window_bytes: a resident light curve (%lld samples) does not fit", (long long)ctx->N);
+    ctx->window_bytes = bytes;
+    return MTG_OK;
+}
+
 MTG_API const char *mtg_last_error(const mtg_ctx *ctx)
 {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
@@ -365,33 +415,47 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     if (!ctx) return MTG_E_ARG;
     if (N <= 0 || L <= 0 || !t || !y || !yerr)
         return fail(ctx, MTG_E_ARG, "mtg_set_lightcurves: need N > 0, L > 0 and non-NULL t, y, yerr");
-    // the solve kernel addresses samples with 32-bit byte offsets (16 bytes per sample)
-    if (L * N >= ((int64_t)1 << 28))
-        return fail(ctx, MTG_E_ARG, "light-curve set too large: L * N must be below 2^28 samples");
+    // one light curve must fit the reach of a buffer descriptor; the set itself may fill the HBM
+    if ((uint64_t)N * 16u > ctx->window_bytes)
+        return fail(ctx, MTG_E_ARG, "light curve too long: N * 16 bytes must stay below %llu",
+                    (unsigned long long)ctx->window_bytes);
+    if (L > 0x7fffffff) return fail(ctx, MTG_E_ARG, "too many light curves (32-bit indices)");
     int rc = use_device(ctx);
     if (rc) return rc;
     const int64_t t_rows = t_per_lc ? L : 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, ctx->dxt.reserve((size_t)t_rows * N * 16));
     HIP_TRY(ctx, ctx->yv.reserve((size_t)L * N * 16));
-    HIP_TRY(ctx, ctx->t_tmp.reserve((size_t)t_rows * N * 8));
-    HIP_TRY(ctx, ctx->y_tmp.reserve((size_t)L * N * 8));
-    HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)L * N * 8));
+    // staged in blocks of light curves (<= ~256 MiB of staging per array), so that a resident set
+    // of tens of GB does not need its own size again in scratch
+    int64_t block = ((int64_t)256 << 20) / (N * 8);
+    if (block < 1) block = 1;
+    if (block > L) block = L;
+    HIP_TRY(ctx, ctx->t_tmp.reserve((size_t)(t_per_lc ? block : 1) * N * 8));
+    HIP_TRY(ctx, ctx->y_tmp.reserve((size_t)block * N * 8));
+    HIP_TRY(ctx, ctx->dy_tmp.reserve((size_t)block * N * 8));
     HIP_TRY(ctx, ctx->dxmax.reserve(64));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dxmax.p, 0, 16, ctx->stream));  // [0] max dx, [1] "unsorted" flag
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->t_tmp.p, t, (size_t)t_rows * N * 8, kind, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->y_tmp.p, y, (size_t)L * N * 8, kind, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr, (size_t)L * N * 8, kind, ctx->stream));
-    const double *d_off = nullptr;
-    if (y_offset) {
-        HIP_TRY(ctx, ctx->off_tmp.reserve((size_t)L * 8));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->off_tmp.p, y_offset, (size_t)L * 8, kind, ctx->stream));
-        d_off = ctx->off_tmp.as<double>();
+    if (y_offset) HIP_TRY(ctx, ctx->off_tmp.reserve((size_t)block * 8));
+    for (int64_t l0 = 0; l0 < L; l0 += block) {
+        const int64_t lb = l0 + block <= L ? block : L - l0;
+        const int64_t tr = t_per_lc ? lb : (l0 == 0 ? 1 : 0);  // a shared sampling is set up once
+        if (tr)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->t_tmp.p, t + (t_per_lc ? l0 * N : 0), (size_t)tr * N * 8, kind, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->y_tmp.p, y + l0 * N, (size_t)lb * N * 8, kind, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dy_tmp.p, yerr + l0 * N, (size_t)lb * N * 8, kind, ctx->stream));
+        const double *d_off = nullptr;
+        if (y_offset) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->off_tmp.p, y_offset + l0, (size_t)lb * 8, kind, ctx->stream));
+            d_off = ctx->off_tmp.as<double>();
+        }
+        mtg_launch_lc_setup(N, lb, tr, ctx->t_tmp.as<double>(), ctx->y_tmp.as<double>(), ctx->dy_tmp.as<double>(),
+                            d_off, ctx->dxt.as<double2>() + (t_per_lc ? l0 * N : 0), ctx->yv.as<double2>() + l0 * N,
+                            ctx->dxmax.as<double>(), ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        // the staging buffers are reused by the next block; pageable host copies have returned by
+        // now, device-to-device ones are ordered on the stream
     }
-    mtg_launch_lc_setup(N, L, t_rows, ctx->t_tmp.as<double>(), ctx->y_tmp.as<double>(),
-                        ctx->dy_tmp.as<double>(), d_off, ctx->dxt.as<double2>(), ctx->yv.as<double2>(),
-                        ctx->dxmax.as<double>(), ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
     uint64_t flags[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->dxmax.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -629,14 +693,16 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.N = ctx->N;
     sa.t_stride = ctx->t_per_lc ? ctx->N : 0;
     sa.dxmax = ctx->dxmax.as<double>();
-    sa.yv_bytes = (uint32_t)(ctx->L * ctx->N * 16);
-    sa.dxt_bytes = (uint32_t)((ctx->t_per_lc ? ctx->L : 1) * ctx->N * 16);
+    sa.yv_bytes = (uint64_t)ctx->L * (uint64_t)ctx->N * 16u;
+    sa.dxt_bytes = (uint64_t)(ctx->t_per_lc ? ctx->L : 1) * (uint64_t)ctx->N * 16u;
+    sa.window_bytes = ctx->window_bytes;
     sa.mean_kind = mean_kind;
     sa.has_mean = mean_params != nullptr || jitter != nullptr;
     sa.tp_ws = nullptr;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
-    fn(sa, B, s);
+    rc = sweep_launch(ctx, fn, sa, B, 0, s);
+    if (rc) return rc;
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
@@ -793,8 +859,8 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
         if (win_lo[n] < 0 || win_hi[n] < win_lo[n] || win_hi[n] > seg_len)
             return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: window %lld = [%d, %d) outside the segment of %lld samples",
                         (long long)n, win_lo[n], win_hi[n], (long long)seg_len);
-    if (make_resident && (ctx->t_per_lc || S * N >= ((int64_t)1 << 28)))
-        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: make_resident needs a shared sampling and S * N < 2^28");
+    if (make_resident && ctx->t_per_lc)
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: make_resident needs a shared sampling");
     rc = use_device(ctx);
     if (rc) return rc;
     const MtgModel &m = ctx->model;

@@ -73,8 +73,15 @@ struct MtgSolveArgs {
     const double2 *yv;   // [L][N] pairs (y_n, sigma_n^2 = yerr_n^2)
     int64_t N;
     int64_t t_stride;    // 0 (shared sampling) or N
-    uint32_t yv_bytes;   // L * N * 16 < 4 GiB
-    uint32_t dxt_bytes;
+    uint64_t yv_bytes;   // L * N * 16: may exceed 4 GiB (the sweep windows its 32-bit offsets per wave)
+    uint64_t dxt_bytes;
+    uint64_t window_bytes;  // reach of one buffer descriptor, <= 2^32 - 1 (smaller only in tests)
+    // resident sets beyond the window: evaluations a wave cannot reach from its first light curve are
+    // appended to left_list (count in *left_count) and swept by a second launch with solo = 1, one
+    // evaluation per wave; NULL when the whole set lies inside one window
+    int *left_list;
+    int *left_count;
+    int solo;
     const double *dxmax;  // [1] max_n dx_n (device): decides table vs OCML sincos per wave
     int mean_kind;
     int has_mean;  // 0: the mean is identically zero for every evaluation of this launch and the model has no jitter term

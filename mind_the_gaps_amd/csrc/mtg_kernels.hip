@@ -123,8 +123,10 @@ struct MtgLane {
 //         identically zero, the frozen per-light-curve constant having been folded into y at
 //         upload, and the model has no JitterTerm).
 template <int NR, int NC, bool FAST, bool MEAN>
-__device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, uint32_t yoff,
-                                          uint32_t toff, const MtgMathTablesT<(NC > 0)> *tab)
+__device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, const double2 *yv_base,
+                                          uint32_t yv_records, uint32_t yoff, const double2 *dxt_base,
+                                          uint32_t dxt_records, uint32_t toff,
+                                          const MtgMathTablesT<(NC > 0)> *tab)
 {
     constexpr int J = NR + 2 * NC;
     constexpr int NT = NR + NC;  // distinct exp(-c dx) factors
@@ -134,9 +136,9 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
     // hardware range check makes the one-past-the-end prefetch of the last step a
     // harmless zero.  (y, sigma^2) and (dx, t) are interleaved: one 16-byte load each.
     const __amdgpu_buffer_rsrc_t ryv =
-        __builtin_amdgcn_make_buffer_rsrc((void *)a.yv, 0, (int)a.yv_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)yv_base, 0, (int)yv_records, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdt =
-        __builtin_amdgcn_make_buffer_rsrc((void *)a.dxt, 0, (int)a.dxt_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)dxt_base, 0, (int)dxt_records, 0x00020000);
     auto ld = [](__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
         return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
@@ -247,11 +249,14 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
 {
     constexpr int J = NR + 2 * NC;  // celerite rank
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
-    if ((int64_t)blockIdx.x * MTG_BLOCK >= count) return;  // whole workgroup idle (e.g. empty signature list)
+    // solo launch (left-overs of a resident set beyond one window): one evaluation per wave, on lane 0
+    const int per_block = a.solo ? MTG_BLOCK / 64 : MTG_BLOCK;
+    if ((int64_t)blockIdx.x * per_block >= count) return;  // whole workgroup idle (e.g. empty signature list)
     __shared__ MtgMathTablesT<(NC > 0)> tab;
     mtg_fill_tables(&tab, threadIdx.x, MTG_BLOCK);
     __syncthreads();
-    const int64_t gid = (int64_t)blockIdx.x * MTG_BLOCK + threadIdx.x;
+    if (a.solo && (threadIdx.x & 63) != 0) return;
+    const int64_t gid = (int64_t)blockIdx.x * per_block + (a.solo ? threadIdx.x >> 6 : threadIdx.x);
     if (gid >= count) return;
     const int64_t e = a.list ? (int64_t)a.list[gid] : gid;
     if (!a.list && a.status[e] != MTG_ST_OK) return;  // prior said -inf
@@ -291,16 +296,43 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     L.invD = 0.0; L.z = 0.0; L.dot = 0.0; L.dprod = 1.0; L.dexp = 0; L.dmin_hi = 0x7fffffff;
 
     const uint32_t lc = a.lc_index ? (uint32_t)a.lc_index[e] : 0u;
-    const uint32_t yoff = lc * (uint32_t)a.N * 16u;                // L * N * 16 < 4 GiB (checked on the host)
-    const uint32_t toff = lc * (uint32_t)a.t_stride * 16u;
+    const uint64_t lc_bytes = (uint64_t)a.N * 16u;
+    // The sweep reads samples through buffer descriptors with 32-bit byte offsets while the resident
+    // set may be far larger than 4 GiB (288 GB of HBM): every wave places its descriptors at the
+    // first light curve its evaluations need and reaches the others by their distance from it.
+    // Batches are grouped by light curve as a rule (a wave of a (walker x light curve) sweep touches
+    // one or two); an evaluation further than a.window_bytes from its wave's first light curve goes
+    // to the left-over list, which a second launch sweeps one evaluation per wave.
+    uint32_t lo = 0xffffffffu;
+    for (unsigned long long m = __ballot(1); m; m &= m - 1ull)  // scalar loop over the active lanes
+        lo = min(lo, (uint32_t)__builtin_amdgcn_readlane((int)lc, __ffsll((long long)m) - 1));
+    const uint64_t base_bytes = (uint64_t)lo * lc_bytes, rel = (uint64_t)(lc - lo) * lc_bytes;
+    if (((uint64_t)lc + 1u) * lc_bytes > a.yv_bytes) {
+        // a device-side lc_index outside the resident set (the host cannot see it): no likelihood
+        a.out[e] = -INFINITY;
+        a.status[e] = MTG_ST_NONFINITE;
+        return;
+    }
+    if (rel + lc_bytes > a.window_bytes) {
+        if (a.left_list) a.left_list[atomicAdd(a.left_count, 1)] = (int)e;
+        return;
+    }
+    const uint64_t yv_left = a.yv_bytes > base_bytes ? a.yv_bytes - base_bytes : 0;
+    const double2 *yv_base = (const double2 *)((const char *)a.yv + base_bytes);
+    const uint32_t yv_rec = yv_left > 0xffffffffull ? 0xffffffffu : (uint32_t)yv_left;
+    const uint32_t yoff = (uint32_t)rel;
+    // shared sampling: one (dx, t) row for everybody; per-light-curve sampling: the same window
+    const double2 *dxt_base = a.t_stride ? (const double2 *)((const char *)a.dxt + base_bytes) : a.dxt;
+    const uint32_t dxt_rec = a.t_stride ? yv_rec : (uint32_t)lc_bytes;
+    const uint32_t toff = a.t_stride ? yoff : 0u;
 
     // table sincos is exact while d_k * dx < MTG_TRIG_FAST_MAX for every lane of the wave
     const bool fast = !__any(!(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
     if (fast) {
-        if (a.has_mean) mtg_sweep<NR, NC, true, true>(L, a, yoff, toff, &tab);
-        else mtg_sweep<NR, NC, true, false>(L, a, yoff, toff, &tab);
+        if (a.has_mean) mtg_sweep<NR, NC, true, true>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
+        else mtg_sweep<NR, NC, true, false>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
     } else {
-        mtg_sweep<NR, NC, false, true>(L, a, yoff, toff, &tab);
+        mtg_sweep<NR, NC, false, true>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
     }
 
     const double logdet = log(L.dprod) + (double)L.dexp * 0.69314718055994530942;
@@ -308,9 +340,6 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     int st = MTG_ST_OK;
     if (L.dmin_hi <= 0) { st = MTG_ST_NOTPD; ll = -INFINITY; }
     else if (!isfinite(ll)) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
-    // a device-side lc_index outside the resident set (the host cannot see it): the buffer loads
-    // returned zeros instead of faulting; do not report a likelihood for them
-    if (((uint64_t)lc + 1u) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
     a.out[e] = ll;
     a.status[e] = st;
 }

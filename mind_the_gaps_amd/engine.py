@@ -29,7 +29,7 @@ EXPORTS = (
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
-    "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel",
+    "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
 )
 
 
@@ -130,6 +130,8 @@ def load_library():
                                       c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, c_int]
     lib.mtg_set_time_parallel.restype = c_int
     lib.mtg_set_time_parallel.argtypes = [c_vp, c_int]
+    lib.mtg_set_window_bytes.restype = c_int
+    lib.mtg_set_window_bytes.argtypes = [c_vp, ctypes.c_uint64]
     lib.mtg_predict.restype = c_int
     lib.mtg_predict.argtypes = [c_vp, c_i64, _dp, _ip, _dp, _dp, _ip]
     lib.mtg_math_probe.restype = c_int
@@ -375,6 +377,10 @@ class Engine:
     def set_time_parallel(self, mode):
         """0 = throughput kernel only, 1 = time-parallel kernel whenever available, 2 = auto (default)."""
         self._check(self._lib.mtg_set_time_parallel(self._ctx, int(mode)))
+
+    def set_window_bytes(self, nbytes):
+        """Testing aid: reach of one buffer descriptor of the sweep (default 2^32 - 1); see include/mtg.h."""
+        self._check(self._lib.mtg_set_window_bytes(self._ctx, int(nbytes)))
 
     def synchronize(self):
         self._check(self._lib.mtg_synchronize(self._ctx))
