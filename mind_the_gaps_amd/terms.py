@@ -19,7 +19,7 @@ import numpy as np
 from . import engine as _engine
 from .modeling import Model, ModelSet
 
-__all__ = ["Term", "TermSum", "RealTerm", "ComplexTerm", "SHOTerm", "Matern32Term", "JitterTerm"]
+__all__ = ["Term", "TermSum", "TermProduct", "RealTerm", "ComplexTerm", "SHOTerm", "Matern32Term", "JitterTerm"]
 
 
 class Term(Model):
@@ -98,6 +98,11 @@ class Term(Model):
             return self
         return NotImplemented
 
+    def __mul__(self, other):
+        if not isinstance(other, Term):
+            return NotImplemented
+        return TermProduct(self, other)
+
 
 class TermSum(ModelSet, Term):
     """``k1 + k2 + ...``: parameters named ``terms[i]:name`` in `+` order."""
@@ -124,6 +129,49 @@ class TermSum(ModelSet, Term):
 
     def __repr__(self):
         return " + ".join(repr(t) for t in self.terms)
+
+
+class TermProduct(ModelSet, Term):
+    """``k1 * k2`` (celerite's TermProduct): the product of two sums of exponentials is again
+    one -- real x real gives a real term (a1 a2, c1 + c2), real x complex a complex term
+    (a1 a2, a1 b2, c1 + c2, d2), complex x complex two complex terms at the difference and the sum
+    of the frequencies.  Parameters are named ``k1:...`` and ``k2:...``.  No device tag: the
+    coefficients are expanded on the host and evaluated through ``mtg_loglike_coeffs``."""
+
+    def __init__(self, k1, k2):
+        if k1.jitter != 0.0 or k2.jitter != 0.0:
+            raise ValueError("jitter terms cannot be multiplied")
+        ModelSet.__init__(self, [("k1", k1), ("k2", k2)])
+
+    def get_all_coefficients(self, params=None):
+        if params is not None:
+            raise ValueError("TermProduct coefficients are taken from its factors")
+        r1, q1, a1, b1, c1, d1 = self.models["k1"].get_all_coefficients()
+        r2, q2, a2, b2, c2, d2 = self.models["k2"].get_all_coefficients()
+        ar = [x * y for x in r1 for y in r2]
+        cr = [x + y for x in q1 for y in q2]
+        ac, bc, cc, dc = [], [], [], []
+        for rr, qq, aa, bb, c_, dd in ((r1, q1, a2, b2, c2, d2), (r2, q2, a1, b1, c1, d1)):   # real x complex
+            for x, cx in zip(rr, qq):
+                for a, b, c, d in zip(aa, bb, c_, dd):
+                    ac.append(x * a); bc.append(x * b); cc.append(cx + c); dc.append(d)
+        for aj, bj, cj, dj in zip(a1, b1, c1, d1):                                             # complex x complex
+            for ak, bk, ck, dk in zip(a2, b2, c2, d2):
+                ac.append(0.5 * (aj * ak + bj * bk)); bc.append(0.5 * (bj * ak - aj * bk))
+                cc.append(cj + ck); dc.append(dj - dk)
+                ac.append(0.5 * (aj * ak - bj * bk)); bc.append(0.5 * (bj * ak + aj * bk))
+                cc.append(cj + ck); dc.append(dj + dk)
+        return tuple(np.asarray(v, dtype=np.float64) for v in (ar, cr, ac, bc, cc, dc))
+
+    @property
+    def jitter(self):
+        return 0.0
+
+    def log_prior(self):
+        return ModelSet.log_prior(self)
+
+    def __repr__(self):
+        return "({0!r}) * ({1!r})".format(self.models["k1"], self.models["k2"])
 
 
 class RealTerm(Term):

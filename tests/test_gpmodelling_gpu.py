@@ -242,3 +242,23 @@ def test_predict_and_standarized_residuals():
     assert np.max(np.abs(var2 - var2_ref) / var2_ref) < 1e-7
     with pytest.raises(NotImplementedError):
         g.gp.predict(y, t=np.array([1.0, 2.0]), return_var=True, return_cov=False)
+
+
+def test_product_kernel_against_the_dense_definition():
+    """celerite's ``k1 * k2`` (terms.TermProduct) has no device tag: host-side coefficients through
+    mtg_loglike_coeffs; lnL against the dense covariance of k1(tau) k2(tau)."""
+    from oracle import dense
+    t, y, dy = synth.make_lightcurves(300, 1, seed=13)
+    y, dy = y[0], dy[0]
+    th = synth.truth(synth.NULL_MODEL)
+    k1 = DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER])
+    k2 = terms.SHOTerm(np.log(1.0), th[3], th[4], bounds=[AMP, OTHER, OTHER])
+    kernel = k1 * k2 + DampedRandomWalk(np.log(20.0), np.log(0.05), bounds=[AMP, OTHER])
+    g = GPModelling(GappyLightcurve(t, y, dy), kernel)
+    theta = g.initial_params + 0.05 * np.random.default_rng(0).standard_normal((6, len(g.initial_params)))
+    got = g._log_probability(theta)
+    for row, val in zip(theta, got):
+        kernel.set_parameter_vector(row)
+        coeffs = tuple(kernel.coefficients) + (0.0,)
+        want = dense.dense_loglike(t, y, dy, coeffs, 0, (float(np.mean(y)),))
+        assert abs(val - want) <= 1e-8 * abs(want)

@@ -159,3 +159,25 @@ def test_gp_compute_validates():
     gp.compute(np.array([0.0, 1.0, 2.0]), 0.1)
     with pytest.raises(ValueError):
         gp.log_likelihood(np.zeros(4))                          # dimension mismatch
+
+
+def test_term_product_is_the_product_of_the_kernels():
+    """celerite's ``k1 * k2``: the coefficient algebra must reproduce k1(tau) k2(tau) for every
+    pairing (real x real, real x complex, complex x complex, sums)."""
+    from mind_the_gaps_amd import terms
+    tau = np.linspace(0.0, 40.0, 400)
+    real = terms.RealTerm(np.log(3.0), np.log(0.2))
+    comp = terms.ComplexTerm(np.log(2.0), np.log(0.1), np.log(0.5), np.log(1.3))
+    sho = terms.SHOTerm(np.log(1.5), np.log(4.0), np.log(0.9))
+    for k1, k2 in ((real, real), (real, comp), (comp, real), (comp, sho), (real + comp, sho + real)):
+        prod = k1 * k2
+        np.testing.assert_allclose(prod.get_value(tau), k1.get_value(tau) * k2.get_value(tau), rtol=1e-12, atol=1e-14)
+        assert prod.get_parameter_names()[0].startswith("k1:") and prod.get_parameter_names()[-1].startswith("k2:")
+        assert len(prod.get_parameter_vector()) == len(k1.get_parameter_vector()) + len(k2.get_parameter_vector())
+    prod = real * comp
+    prod.set_parameter_vector(prod.get_parameter_vector() + 0.1)          # parameters reach the factors
+    np.testing.assert_allclose(prod.get_value(tau), prod.models["k1"].get_value(tau) * prod.models["k2"].get_value(tau), rtol=1e-12)
+    total = real + comp * sho                                              # a product inside a sum
+    np.testing.assert_allclose(total.get_value(tau), real.get_value(tau) + comp.get_value(tau) * sho.get_value(tau), rtol=1e-12)
+    with pytest.raises(ValueError):
+        real * terms.JitterTerm(0.0)
