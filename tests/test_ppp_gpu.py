@@ -137,3 +137,40 @@ def test_protassov_test_end_to_end():
     assert np.all(res["T_sim"] > -5.0)                             # nested models: alt never much worse
     assert 1 / 25 <= res["p_value"] <= 1.0 and res["p_value"] > 0.04
     assert res["lightcurves"]["rates"].shape == (24, 250)
+
+
+def test_invariances_at_the_bench_size(engine):
+    """The bench workload itself (BASELINE configs[3] per GPU: 2000 light curves x 256 walkers,
+    N = 1e4, J = 6 -- 512 000 evaluations per launch), checked through properties that need no
+    oracle: splitting the batch changes nothing (bit for bit); stretching time by 2 while halving
+    every frequency leaves the covariance -- and lnL -- unchanged; so does moving the time origin."""
+    kinds = synth.ALT_MODEL
+    N, L, W = 10000, 2000, 256
+    t, y, dy = synth.make_lightcurves(N, L, seed=20250704 + 4)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    theta = synth.draw_thetas(kinds, L * W, seed=20250704 + 40)
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    off = y.mean(axis=1)
+    engine.set_time_parallel(2)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=off)
+    engine.set_model(kinds, full, free, bounds)
+    out, st = engine.loglike(theta, lc, add_prior=True)
+    assert np.all(st == 0) and np.all(np.isfinite(out))
+    # (1) eight partial launches
+    parts = [engine.loglike(theta[i::8], lc[i::8], add_prior=True)[0] for i in range(8)]
+    for i in range(8):
+        assert np.array_equal(parts[i], out[i::8])
+    # (2) t -> 2 t with every rate halved: DRW (a, c) = (S0, w0); SHO a = S0 w0 Q, so S0 doubles;
+    #     Lorentzian (a, c, d) = (S0, w0 / 2Q, w0)
+    th2 = theta.copy()
+    th2[:, [1, 4, 7]] -= np.log(2.0)
+    th2[:, 2] += np.log(2.0)
+    engine.set_lightcurves(2.0 * t, y, dy + 1e-12, y_offset=off)
+    out2, st2 = engine.loglike(th2, lc, add_prior=True)
+    assert np.all(st2 == 0)
+    assert np.max(np.abs(out2 - out) / np.abs(out)) < 1e-10
+    # (3) a new time origin (the kernels only ever see time differences)
+    engine.set_lightcurves(t + 4096.0, y, dy + 1e-12, y_offset=off)
+    out3, st3 = engine.loglike(theta, lc, add_prior=True)
+    assert np.all(st3 == 0)
+    assert np.max(np.abs(out3 - out) / np.abs(out)) < 1e-9
