@@ -1,6 +1,8 @@
 """Seeded random sweep of the HIP path against the oracle: random sums of terms (every term
 kind, J <= 10), sizes, batch shapes, light-curve maps, priors on/off, both kernels (throughput
 and time-parallel).  Tolerance 1e-8 relative (BASELINE.json north_star); statuses must agree."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,9 @@ from mind_the_gaps_amd import synthetic as synth
 from oracle import celerite as oracle_c
 
 pytestmark = pytest.mark.gpu
+
+# MTG_FUZZ_OFFSET=k shifts every seed: a soak run over other cases than the 120 the suite pins
+OFFSET = int(os.environ.get("MTG_FUZZ_OFFSET", "0"))
 
 RANK = {synth.K_REAL: 1, synth.K_DRW: 1, synth.K_JITTER: 0}   # everything else is one complex term (2)
 
@@ -26,6 +31,7 @@ def random_model(rng, jmax, ncmax):
 
 @pytest.mark.parametrize("case", range(120))
 def test_random_model_vs_oracle(engine, case):
+    case = case + OFFSET
     rng = np.random.default_rng(9000 + case)
     tp_mode = int(rng.integers(0, 2))
     kinds = random_model(rng, *((6, 3) if tp_mode else (10, 5)))
@@ -52,7 +58,8 @@ def test_random_model_vs_oracle(engine, case):
         if k == synth.K_SHO:
             theta[rng.random(B) < 0.4, off + 1] = np.log(rng.uniform(0.05, 0.45))
         off += synth.NPARAMS[k]
-    theta[rng.random(B) < 0.1, 0] = 60.0
+    pushed = rng.random(B) < 0.1
+    theta[pushed, 0] = 60.0
     lc = rng.integers(0, L, B).astype(np.int32)
     if linear_mean:
         theta = np.hstack([theta, 0.01 + 0.002 * rng.standard_normal((B, 1)), 100.0 + rng.standard_normal((B, 1))])
@@ -75,6 +82,13 @@ def test_random_model_vs_oracle(engine, case):
         ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, full_b, lc_index=lc, **okw)
     label = "kinds=%s N=%d L=%d B=%d per_lc_t=%s prior=%s tp=%d linear_mean=%s" % (
         kinds, N, L, B, per_lc_t, add_prior, tp_mode, linear_mean)
+    if not add_prior:
+        # Without the prior the rows pushed to log-amplitude 60 are EVALUATED: an amplitude of e^60
+        # against unit noise is a covariance of condition ~1e26, where the sign of a pivot -- the
+        # status -- is rounding noise in celerite's recursion and in the kernels alike (soak runs,
+        # MTG_FUZZ_OFFSET, show them disagree on a few such rows of undamped-cosine models).  They
+        # are in the batch to sit next to the healthy rows, not to be compared.
+        out, st, ref, rst = out[~pushed], st[~pushed], ref[~pushed], rst[~pushed]
     assert np.array_equal(st, rst), label
     ok = st == 0
     assert np.all(np.isneginf(out[~ok])), label
