@@ -178,6 +178,10 @@ class EnsembleSampler:
         bar = _progress_bar(grow) if progress else None
         rng = self._random
         for _ in range(grow):
+            # emcee picks the move of every iteration with RandomState.choice(moves, p=weights),
+            # which draws one uniform even when the stretch move is the only one: consume it, so that
+            # the stream stays aligned with emcee's for the same seed
+            rng.random_sample()
             # red/blue split: shuffled alternating labels, each half moved given the other
             inds = np.arange(W) % 2
             rng.shuffle(inds)
