@@ -249,6 +249,17 @@ MTG_API int mtg_predict(mtg_ctx *ctx, int64_t B, const double *theta, const int3
                         double *var, int32_t *status);
 
 /*
+ * celerite.GP.apply_inverse(y) / CholeskySolver.solve: x <- K^-1 x for M right-hand sides,
+ * x[N][M] (row n = sample n of every right-hand side), K the covariance of light curve
+ * `lc_index` at parameter vector `theta`, in O(N J^2 + N J M) from the same factorisation
+ * mtg_predict uses.  It is what celerite's predict at NEW times is made of (mean
+ * K_* K^-1 r, covariance K_** - K_* K^-1 K_*^T); the host side assembles those.
+ * *status: MTG_ST_* of the parameter vector (nothing is written to x unless MTG_ST_OK).
+ */
+MTG_API int mtg_apply_inverse(mtg_ctx *ctx, const double *theta, int32_t lc_index, int64_t M, double *x,
+                              int32_t *status);
+
+/*
  * Accuracy probe of the device elementary functions the recurrence uses
  * (tests only): exp_neg[i] = exp(-x[i]), sin/cos(x[i]), rcp_x[i] = 1 / x[i] for
  * n host values x >= 0.

@@ -1019,6 +1019,68 @@ MTG_API int mtg_predict(mtg_ctx *ctx, int64_t B, const double *theta, const int3
     return MTG_OK;
 }
 
+MTG_API int mtg_apply_inverse(mtg_ctx *ctx, const double *theta, int32_t lc_index, int64_t M, double *x,
+                              int32_t *status)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (M <= 0 || !x || !status || (!theta && ctx->model.P > 0))
+        return fail(ctx, MTG_E_ARG, "mtg_apply_inverse: bad arguments");
+    if (lc_index < 0 || lc_index >= ctx->L)
+        return fail(ctx, MTG_E_ARG, "lc_index = %d outside [0, %lld)", lc_index, (long long)ctx->L);
+    rc = use_device(ctx);
+    if (rc) return rc;
+    const MtgModel &m = ctx->model;
+    const int P = m.P, Jws = m.nr_max + 2 * m.nc_max, J = m.nr0 + 2 * m.nc0;
+    const int64_t N = ctx->N;
+    MtgCoefLayout lay{m.nr_max, m.nc_max};
+    rc = reserve_workspace(ctx, 1, lay.nslots(), 1);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    DevBuf work, d_mu, d_var, d_sig, d_x;
+    HIP_TRY(ctx, ctx->theta.reserve((size_t)(P > 0 ? P : 1) * 8));
+    HIP_TRY(ctx, ctx->out.reserve(8));
+    HIP_TRY(ctx, ctx->status.reserve(4));
+    HIP_TRY(ctx, ctx->lc.reserve(4));
+    hipError_t e = work.reserve((size_t)N * (3 * Jws + 2) * 8);
+    if (e == hipSuccess) e = d_mu.reserve((size_t)N * 8);
+    if (e == hipSuccess) e = d_var.reserve((size_t)N * 8);
+    if (e == hipSuccess) e = d_sig.reserve(4);
+    if (e == hipSuccess) e = d_x.reserve((size_t)N * M * 8);
+    if (e == hipSuccess && P > 0) e = hipMemcpyAsync(ctx->theta.p, theta, (size_t)P * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->lc.p, &lc_index, 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_x.p, x, (size_t)N * M * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        // the factorisation of this parameter vector: the forward sweep of mtg_predict_kernel leaves
+        // U_n, W_n, phi_n, D_n of every sample in `work`
+        MtgPrepArgs pa;
+        pa.model = m; pa.theta = ctx->theta.as<double>(); pa.B = 1; pa.add_prior = 1;
+        pa.coef = ctx->coef.as<double>(); pa.cstride = ctx->cstride; pa.nsig = 1;
+        pa.lists = ctx->lists.as<int>(); pa.counts = ctx->counts.as<int>();
+        pa.out = ctx->out.as<double>(); pa.status = ctx->status.as<int32_t>(); pa.sig = d_sig.as<int32_t>();
+        mtg_launch_prepare(pa, s);
+        MtgPredictArgs qa;
+        qa.coef = ctx->coef.as<double>(); qa.cstride = ctx->cstride; qa.lay = lay;
+        qa.nr0 = m.nr0; qa.nc0 = m.nc0; qa.sig = d_sig.as<int32_t>(); qa.B = 1; qa.lc_index = ctx->lc.as<int32_t>();
+        qa.status_in = ctx->status.as<int32_t>(); qa.dxt = ctx->dxt.as<double2>(); qa.yv = ctx->yv.as<double2>();
+        qa.N = N; qa.t_stride = ctx->t_per_lc ? N : 0; qa.work = work.as<double>();
+        qa.mu = d_mu.as<double>(); qa.var = d_var.as<double>(); qa.status = ctx->status.as<int32_t>();
+        mtg_launch_predict(&qa, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(status, ctx->status.p, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && *status == MTG_ST_OK) {
+        mtg_launch_apply_inverse(work.as<double>(), N, J, M, d_x.as<double>(), s);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(x, d_x.p, (size_t)N * M * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    work.release(); d_mu.release(); d_var.release(); d_sig.release(); d_x.release();
+    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_apply_inverse: %s", hipGetErrorString(e));
+    return MTG_OK;
+}
+
 MTG_API int mtg_math_probe(mtg_ctx *ctx, int64_t n, const double *x, double *exp_neg, double *sin_x,
                            double *cos_x, double *rcp_x)
 {

@@ -148,5 +148,6 @@ void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int
 void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const double *dy, double2 *yv, double *means,
                               hipStream_t);
 void mtg_launch_predict(const void *predict_args, hipStream_t);
+void mtg_launch_apply_inverse(const double *work, int64_t N, int J, int64_t M, double *x, hipStream_t);
 void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,
                            hipStream_t);

@@ -331,6 +331,50 @@ __global__ void __launch_bounds__(64) mtg_predict_kernel(MtgPredictArgs a)
     a.status[e] = MTG_ST_OK;
 }
 
+// K^-1 applied to M right-hand sides with the factors mtg_predict_kernel left in its workspace
+// (celerite.GP.apply_inverse / solver.solve; what GP.predict at NEW times needs: K^-1 r for the
+// mean, K^-1 K_*^T for the variance).  One lane per right-hand side; x is [N][M] (row n holds
+// sample n of every right-hand side, so the lanes' accesses coalesce) and is overwritten;
+// every lane reads the same generator row (broadcast).
+//   forward   f_n = Phi_n (f_{n-1} + W_{n-1} z_{n-1}),  z_n = b_n - U_n^T f_n
+//   backward  g_n = Phi_{n+1} (g_{n+1} + U_{n+1} x_{n+1}),  x_n = z_n / D_n - W_n^T g_n
+__global__ void __launch_bounds__(64)
+mtg_apply_inverse_kernel(const double *__restrict__ work, int64_t N, int J, int64_t M, double *__restrict__ x)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int stride = 3 * J + 2;
+    double f[MTG_PJ], g[MTG_PJ];
+    for (int i = 0; i < J; ++i) { f[i] = 0.0; g[i] = 0.0; }
+    double zp = 0.0;
+    for (int64_t n = 0; n < N; ++n) {
+        const double *w = work + n * stride;
+        double z = x[n * M + m];
+        for (int i = 0; i < J; ++i) {
+            if (n > 0) f[i] = w[2 * J + i] * (f[i] + w[J + i - stride] * zp);
+            z -= w[i] * f[i];
+        }
+        x[n * M + m] = z;
+        zp = z;
+    }
+    double xn = 0.0;
+    for (int64_t n = N - 1; n >= 0; --n) {
+        const double *w = work + n * stride;
+        double v = x[n * M + m] / w[3 * J];
+        for (int i = 0; i < J; ++i) {
+            if (n < N - 1) g[i] = w[stride + 2 * J + i] * (g[i] + w[stride + i] * xn);
+            v -= w[J + i] * g[i];
+        }
+        x[n * M + m] = v;
+        xn = v;
+    }
+}
+
+void mtg_launch_apply_inverse(const double *work, int64_t N, int J, int64_t M, double *x, hipStream_t s)
+{
+    hipLaunchKernelGGL(mtg_apply_inverse_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, work, N, J, M, x);
+}
+
 void mtg_launch_predict(const void *args_void, hipStream_t s)
 {
     const MtgPredictArgs &a = *static_cast<const MtgPredictArgs *>(args_void);

@@ -30,6 +30,7 @@ EXPORTS = (
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
+    "mtg_apply_inverse",
 )
 
 
@@ -130,6 +131,8 @@ def load_library():
                                       c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, c_int]
     lib.mtg_set_time_parallel.restype = c_int
     lib.mtg_set_time_parallel.argtypes = [c_vp, c_int]
+    lib.mtg_apply_inverse.restype = c_int
+    lib.mtg_apply_inverse.argtypes = [c_vp, _dp, ctypes.c_int32, c_i64, _dp, _ip]
     lib.mtg_set_window_bytes.restype = c_int
     lib.mtg_set_window_bytes.argtypes = [c_vp, ctypes.c_uint64]
     lib.mtg_predict.restype = c_int
@@ -366,6 +369,16 @@ class Engine:
         self._check(self._lib.mtg_predict(self._ctx, B, _ptr(theta), _iptr(lc), _ptr(mu), _ptr(var),
                                           _iptr(status)))
         return mu, var, status
+
+    def apply_inverse(self, theta, rhs, lc_index=0):
+        """K^-1 rhs for rhs[N] or rhs[N][M] at parameter vector ``theta`` -> (x, status)."""
+        rhs = _f64(rhs)
+        one = rhs.ndim == 1
+        x = np.ascontiguousarray(rhs.reshape(self.N, -1)).copy()
+        status = np.zeros(1, dtype=np.int32)
+        self._check(self._lib.mtg_apply_inverse(self._ctx, _ptr(_f64(theta)), int(lc_index), x.shape[1], _ptr(x),
+                                                _iptr(status)))
+        return (x[:, 0] if one else x), int(status[0])
 
     def math_probe(self, x):
         """Device exp(-x), sin(x), cos(x), 1/x of the kernel's own math (accuracy tests)."""

@@ -279,25 +279,59 @@ class GP(ModelSet):
             out[keep], status[keep] = o, s
         return out, status
 
-    def predict(self, y, t=None, return_cov=True, return_var=False):
-        """Conditional mean (and variance) at the training times, celerite.GP.predict as
-        the reference calls it (gpmodelling.py:366: ``return_var=True, return_cov=False``).
-        The variance comes from the O(N J^2) factorisation on the device, not from
-        celerite's dense N x N cross-covariance.  Predicting at other times ``t`` or
-        returning the full covariance is not part of the hot path."""
-        if t is not None:
-            raise NotImplementedError("prediction at new times is outside the log-likelihood hot path")
-        if return_cov and not return_var:
-            raise NotImplementedError("the dense predictive covariance is not computed; use return_var=True")
+    def _bound_engine(self, y):
         ev = self._ensure_evaluator(y)
         model = self._device_model()
         if not model.device_terms or model.mean_kind is None:
-            raise NotImplementedError("predict needs device-expandable terms and a constant or linear mean")
-        eng = ev._bind(model)
-        mu, var, status = eng.predict(model.full[model.free_index][None, :])
-        if status[0] == _engine.ST_NOTPD:
+            raise NotImplementedError("needs device-expandable terms and a constant or linear mean")
+        return ev._bind(model), model
+
+    @staticmethod
+    def _raise_for(status):
+        if status == _engine.ST_NOTPD:
             raise LinAlgError("failed to factorize or solve matrix")
-        if status[0] == _engine.ST_PRIOR:
+        if status == _engine.ST_PRIOR:
             raise ValueError("the current parameter vector has zero prior probability")
-        mu = mu[0] + (model.y_offset or 0.0)
-        return (mu, var[0]) if return_var else mu
+
+    def apply_inverse(self, y):
+        """``K^-1 y`` for ``y`` of shape (N,) or (N, nrhs) (celerite.GP.apply_inverse), K the
+        covariance at the current parameters: O(N J^2 + N J nrhs) on the device."""
+        y = np.asarray(y, dtype=np.float64)
+        if y.shape[0] != len(self._t):
+            raise ValueError("dimension mismatch")
+        eng, model = self._bound_engine(self._y_bound if self._y_bound is not None else np.zeros(len(self._t)))
+        x, status = eng.apply_inverse(model.full[model.free_index], y)
+        self._raise_for(status)
+        return x
+
+    def predict(self, y, t=None, return_cov=True, return_var=False):
+        """Conditional mean and (co)variance, celerite.GP.predict.
+
+        At the training times (``t=None``) with ``return_var=True`` -- the reference's call,
+        gpmodelling.py:366 -- mean and variance both come from the O(N J^2) factorisation on the
+        device (celerite forms the dense N x N cross-covariance for the variance).  At other times,
+        or for the full covariance, celerite's own expressions ``mu = mean(t) + K_* K^-1 r``,
+        ``cov = K_** - K_* K^-1 K_*^T`` are assembled on the host from ``apply_inverse`` (one
+        device call with 1 + N_* right-hand sides).  Like celerite's, the variances are those of
+        the noise-free process (no jitter, no measurement errors)."""
+        if t is None and (return_var or not return_cov):
+            eng, model = self._bound_engine(y)
+            mu, var, status = eng.predict(model.full[model.free_index][None, :])
+            self._raise_for(status[0])
+            mu = mu[0] + (model.y_offset or 0.0)
+            return (mu, var[0]) if return_var else mu
+        eng, model = self._bound_engine(y)
+        y = np.asarray(y, dtype=np.float64)
+        xs = self._t if t is None else np.atleast_1d(np.asarray(t, dtype=np.float64))
+        resid = y - self.mean.get_value(self._t)
+        if not (return_cov or return_var):
+            alpha, status = eng.apply_inverse(model.full[model.free_index], resid)
+            self._raise_for(status)
+            return self.mean.get_value(xs) + self.kernel.get_value(xs[:, None] - self._t[None, :]) @ alpha
+        kxs = self.kernel.get_value(xs[:, None] - self._t[None, :])                # [N_*][N]
+        sol, status = eng.apply_inverse(model.full[model.free_index], np.column_stack([resid, kxs.T]))
+        self._raise_for(status)
+        mu = self.mean.get_value(xs) + kxs @ sol[:, 0]
+        if return_var:
+            return mu, self.kernel.get_value(0.0) - np.sum(kxs.T * sol[:, 1:], axis=0)
+        return mu, self.kernel.get_value(xs[:, None] - xs[None, :]) - kxs @ sol[:, 1:]

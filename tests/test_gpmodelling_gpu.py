@@ -240,8 +240,9 @@ def test_predict_and_standarized_residuals():
     mu2_ref, var2_ref = dense.dense_predict(t, y + 0.01 * t, dy, co2, 1, v[-2:])
     assert np.max(np.abs(mu2 - mu2_ref)) < 1e-8 * np.max(np.abs(mu2_ref))
     assert np.max(np.abs(var2 - var2_ref) / var2_ref) < 1e-7
-    with pytest.raises(NotImplementedError):
-        g.gp.predict(y, t=np.array([1.0, 2.0]), return_var=True, return_cov=False)
+    # other times: see test_apply_inverse_and_predict_at_new_times
+    mu_new, var_new = g.gp.predict(y, t=t[:2] + 0.25, return_var=True, return_cov=False)
+    assert mu_new.shape == (2,) and np.all(var_new > 0)
 
 
 def test_product_kernel_against_the_dense_definition():
@@ -262,3 +263,42 @@ def test_product_kernel_against_the_dense_definition():
         coeffs = tuple(kernel.coefficients) + (0.0,)
         want = dense.dense_loglike(t, y, dy, coeffs, 0, (float(np.mean(y)),))
         assert abs(val - want) <= 1e-8 * abs(want)
+
+
+def test_apply_inverse_and_predict_at_new_times():
+    """celerite.GP.apply_inverse and GP.predict(y, t, ...) at times other than the training ones
+    (mean, variance, full covariance) against dense linear algebra on the same covariance."""
+    N = 300
+    t, y, dy = synth.make_lightcurves(N, 1, seed=17)
+    y, dy = y[0], dy[0]
+    th = synth.truth(synth.ALT_MODEL)
+    kernel = (DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER]) + terms.SHOTerm(th[2], th[3], th[4], bounds=[AMP, OTHER, OTHER])
+              + Lorentzian(th[5], th[6], th[7], bounds=[AMP, OTHER, OTHER]) + terms.JitterTerm(np.log(0.7)))
+    for mean_model in (None, "linear"):
+        g = GPModelling(GappyLightcurve(t, y, dy), kernel, mean_model=mean_model)
+        gp = g.gp
+        K = kernel.get_value(t[:, None] - t[None, :]) + np.diag((dy + 1e-12) ** 2 + kernel.jitter)
+        rng = np.random.default_rng(1)
+        b1, b3 = rng.standard_normal(N), rng.standard_normal((N, 3))
+        assert np.allclose(gp.apply_inverse(b1), np.linalg.solve(K, b1), rtol=1e-8, atol=1e-12)
+        assert np.allclose(gp.apply_inverse(b3), np.linalg.solve(K, b3), rtol=1e-8, atol=1e-12)
+        ts = np.sort(np.concatenate([rng.uniform(t[0] - 5, t[-1] + 5, 40), t[[3, 77]]]))   # between, beyond and ON samples
+        resid = y - gp.mean.get_value(t)
+        ks = kernel.get_value(ts[:, None] - t[None, :])
+        want_mu = gp.mean.get_value(ts) + ks @ np.linalg.solve(K, resid)
+        want_cov = kernel.get_value(ts[:, None] - ts[None, :]) - ks @ np.linalg.solve(K, ks.T)
+        mu = gp.predict(y, ts, return_cov=False)
+        mu_v, var = gp.predict(y, ts, return_var=True)
+        mu_c, cov = gp.predict(y, ts)
+        scale = np.max(np.abs(want_mu))
+        for m in (mu, mu_v, mu_c):
+            assert np.max(np.abs(m - want_mu)) < 1e-8 * scale
+        assert np.max(np.abs(cov - want_cov)) < 1e-7 * np.max(np.abs(want_cov))
+        assert np.max(np.abs(var - np.diag(want_cov))) < 1e-7 * np.max(np.abs(want_cov))
+        # training times through the same route (dense N x N, celerite's default return_cov=True)
+        mu_t, cov_t = gp.predict(y)
+        mu_dev, var_dev = gp.predict(y, return_var=True)
+        assert np.max(np.abs(mu_t - mu_dev)) < 1e-8 * scale
+        assert np.max(np.abs(np.diag(cov_t) - var_dev)) < 1e-6 * np.max(np.abs(var_dev))
+    with pytest.raises(ValueError):
+        gp.apply_inverse(np.zeros(N + 1))
