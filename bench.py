@@ -99,9 +99,9 @@ def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds, bounds=None, gpu_out=N
 
 
 def single_lightcurve_configs():
-    """BASELINE configs[1] and [2] (one light curve, N = 1e4): stretch-move iterations/s through
-    GPModelling.derive_posteriors with the device-resident sampler; small batches take the
-    time-parallel kernel.  Reported next to the headline, not part of `value`."""
+    """BASELINE configs[0], [1], [2] and [4] (ONE light curve each): stretch-move iterations/s through
+    GPModelling.derive_posteriors with the device-resident sampler; such small batches take the
+    time-parallel kernels.  Reported next to the headline, not part of `value`."""
     import warnings
     from mind_the_gaps_amd import synthetic as synth, terms
     from mind_the_gaps_amd.gpmodelling import GPModelling
@@ -110,26 +110,41 @@ def single_lightcurve_configs():
     amp, other = (-10, 50), (-10, 10)
     th = synth.truth(synth.ALT_MODEL)
 
+    def drw():
+        return DampedRandomWalk(th[0], th[1], bounds=[amp, other])
+
     def null_kernel():
-        return DampedRandomWalk(th[0], th[1], bounds=[amp, other]) + terms.SHOTerm(th[2], th[3], th[4],
-                                                                                   bounds=[amp, other, other])
+        return drw() + terms.SHOTerm(th[2], th[3], th[4], bounds=[amp, other, other])
+
+    def five_sho():
+        k = None
+        for i in range(5):
+            term = terms.SHOTerm(np.log(20.0 + 10 * i), np.log([3.0, 8.0, 10.0, 1.0, 0.8][i]),
+                                 np.log(2 * np.pi / (5.0 + 6 * i)), bounds=[amp, other, other])
+            k = term if k is None else k + term
+        return k
+
     out = {}
-    t, y, dy = synth.make_lightcurves(10000, 1, seed=20250704 + 2)
-    for name, kernel, walkers in (("configs[1] DRW+SHO N=1e4 128 walkers", null_kernel(), 128),
-                                  ("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers",
-                                   null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other]), 256)):
-        g = GPModelling(GappyLightcurve(t, y[0], dy[0]), kernel)
+    cases = (("configs[0] DRW N=1e3 32 walkers", drw, 1000, 32, 1000, 8),
+             ("configs[1] DRW+SHO N=1e4 128 walkers", null_kernel, 10000, 128, 200, 11),
+             ("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers",
+              lambda: null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other]), 10000, 256, 200, 14),
+             ("configs[4] 5 x SHO (J=10) N=2e5 512 walkers", five_sho, 200000, 512, 8, 21))
+    for name, make_kernel, n, walkers, steps, P in cases:
+        t, y, dy = synth.make_lightcurves(n, 1, seed=20250704 + 2)
+        g = GPModelling(GappyLightcurve(t, y[0], dy[0]), make_kernel())
         np.random.seed(1)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            g.derive_posteriors(fit=False, max_steps=10, convergence_steps=10, walkers=walkers, progress=False,
-                                device_sampler=True)
-            steps = 200
+            g.derive_posteriors(fit=False, max_steps=min(10, steps), convergence_steps=10, walkers=walkers,
+                                progress=False, device_sampler=True)
             t0 = time.perf_counter()
             g.derive_posteriors(fit=False, max_steps=steps, convergence_steps=steps, walkers=walkers,
                                 progress=False, device_sampler=True)
             el = time.perf_counter() - t0
-        out[name] = {"iterations_per_s": steps / el, "evals_per_s": steps * walkers / el}
+        evals = steps * walkers / el
+        out[name] = {"iterations_per_s": steps / el, "evals_per_s": evals,
+                     "algorithmic_hbm_frac": evals * (24 * n + 8 * (P - 6) + 12) / (HBM_PEAK_GBS * 1e9)}
     return out
 
 
