@@ -81,6 +81,11 @@ struct mtg_ctx {
     DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
         ens_naccept, ens_best_lnp, ens_best_coords, ens_notpd, ens_chain, ens_lnp_chain;
 
+    // side streams: the structures (signatures) of a small batch run next to each other
+    hipStream_t side[MTG_MAX_J / 2] = {};
+    hipEvent_t side_done[MTG_MAX_J / 2] = {};
+    hipEvent_t fork = nullptr;
+
     // per-call kernel timing (mtg_profile_*): event triples start / solve / end
     std::vector<hipEvent_t> prof_ev;
     int prof_cap = 0, prof_n = 0;
@@ -302,6 +307,19 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         sa.count_ptr = ctx->counts.as<int>();
         fused(sa, B, s);
     } else {
+        // A time-parallel launch is latency bound: a structure holding three evaluations takes as long
+        // as one holding 250 (J = 10: ~10 ms each), and one after the other on the same stream they
+        // add up.  The structures work on disjoint evaluations, so each gets its own stream: forked
+        // after the expansion, joined before whatever follows on `s`.
+        const bool fan_out = small_ok && nsig > 1 && nsig - 1 <= MTG_MAX_J / 2;
+        if (fan_out) {
+            if (!ctx->fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming));
+            for (int k = 0; k + 1 < nsig; ++k) {
+                if (!ctx->side[k]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+                if (!ctx->side_done[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_done[k], hipEventDisableTiming));
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->fork, s));
+        }
         for (int k = 0; k < nsig; ++k) {
             const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
             mtg_solve_launcher fn = mtg_find_solver(nr, nc);
@@ -310,12 +328,18 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
             sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
             sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
+            hipStream_t sk = fan_out && k > 0 ? ctx->side[k - 1] : s;
+            if (sk != s) HIP_TRY(ctx, hipStreamWaitEvent(sk, ctx->fork, 0));
             if (tp) {
                 sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
-                tp(sa, B, s);
+                tp(sa, B, sk);
             } else {
-                const int rc = sweep_launch(ctx, fn, sa, B, k, s);
+                const int rc = sweep_launch(ctx, fn, sa, B, k, sk);
                 if (rc) return rc;
+            }
+            if (sk != s) {
+                HIP_TRY(ctx, hipEventRecord(ctx->side_done[k - 1], sk));
+                HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->side_done[k - 1], 0));
             }
         }
     }
@@ -387,6 +411,9 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
                       &ctx->ens_lnp_chain};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipStream_t st : ctx->side) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->fork) (void)hipEventDestroy(ctx->fork);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

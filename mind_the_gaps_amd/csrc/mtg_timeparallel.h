@@ -266,9 +266,12 @@ __device__ __forceinline__ void tp_identity(TpElem<J> &e)
 //   A <- (I - K h) F A,   eta <- eta + g z / D,   Jm <- Jm + g g^T / D
 // (the general combination's (I + C J)^-1 with the step's rank-one J is that filter update).
 // Dv = C - P_inf is carried by the caller across the steps of a chunk.
-template <int NR, int NC, int J>
+// ACC_STRIDE > 0: eta and Jm are accumulated in `acc` (LDS, entry k of this lane at acc[k * ACC_STRIDE],
+// eta first, then the triangle of Jm) instead of e.eta / e.Jm: at J = 10 the element alone is 230
+// doubles and the step's temporaries push the lane past its 512 registers into scratch.
+template <int NR, int NC, int J, int ACC_STRIDE = 0>
 __device__ __forceinline__ void tp_compose_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double y, double R,
-                                                TpElem<J> &e, Sym<J> &Dv)
+                                                TpElem<J> &e, Sym<J> &Dv, double *acc = nullptr)
 {
     tp_left_F<NR, NC, J>(T, e.A);
     double g[J];
@@ -288,13 +291,27 @@ __device__ __forceinline__ void tp_compose_step(const TpModel<NR, NC> &M, const 
 #pragma unroll
         for (int j = 0; j < J; ++j) e.A[i][j] = fma(-kd[i], g[j], e.A[i][j]);
     const double zi = z * inv;
+    if (ACC_STRIDE == 0) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) e.eta[j] = fma(g[j], zi, e.eta[j]);
+        for (int j = 0; j < J; ++j) e.eta[j] = fma(g[j], zi, e.eta[j]);
 #pragma unroll
-    for (int i = 0; i < J; ++i) {
-        const double gi = g[i] * inv;
+        for (int i = 0; i < J; ++i) {
+            const double gi = g[i] * inv;
 #pragma unroll
-        for (int j = 0; j <= i; ++j) e.Jm(i, j) = fma(gi, g[j], e.Jm(i, j));
+            for (int j = 0; j <= i; ++j) e.Jm(i, j) = fma(gi, g[j], e.Jm(i, j));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j * ACC_STRIDE] = fma(g[j], zi, acc[j * ACC_STRIDE]);
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            const double gi = g[i] * inv;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double *p = acc + (J + i * (i + 1) / 2 + j) * ACC_STRIDE;
+                *p = fma(gi, g[j], *p);
+            }
+        }
     }
 }
 
@@ -726,7 +743,7 @@ __device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
 template <int NR, int NC, bool FAST, int LANES>
 __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
                                             double icpt, int64_t ev, int64_t lc, const MtgMathTables *tab, double *elems,
-                                            double *red)
+                                            double *red, double *acc_lds = nullptr)
 {
     double *sh = elems;
     constexpr int MTG_TP_LANES = LANES;
@@ -747,14 +764,29 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     if (lo == 0) lo = 1;
 
     // ---- pass 1: element of the chunk ---------------------------------------------------
+    // the J = 10 kernels with 256 chunks keep their elements in global memory, so LDS is free to take
+    // the information part (eta, Jm: 65 doubles per lane, entry-major -> no bank conflicts) off the
+    // registers while the chunk is composed
+    constexpr bool ACC_LDS = !IN_LDS && LANES == 256;
+    constexpr int NACC = J + J * (J + 1) / 2;
     TpElem<J> e;
     tp_identity<J>(e);
     tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
+    if (ACC_LDS) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc_lds[k * LANES + lane] = 0.0;
+    }
     for (int64_t n = lo; n < hi; ++n) {
         TpTrans<NR, NC> T;
         tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
         const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
-        tp_compose_step<NR, NC, J>(M, T, r, yv[n].y + jitter, e, e.C);
+        tp_compose_step<NR, NC, J, (ACC_LDS ? LANES : 0)>(M, T, r, yv[n].y + jitter, e, e.C, acc_lds + lane);
+    }
+    if (ACC_LDS) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) e.eta[j] = acc_lds[j * LANES + lane];
+#pragma unroll
+        for (int k = 0; k < J * (J + 1) / 2; ++k) e.Jm.v[k] = acc_lds[(J + k) * LANES + lane];
     }
     tp_add_pinf<NR, NC, J>(M, e.C);
 
@@ -851,7 +883,7 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
 // trigonometric path, run the three passes.
 template <int NR, int NC, int LANES>
 __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab, double *elems,
-                                            double *red)
+                                            double *red, double *acc_lds = nullptr)
 {
     // ---- model of this evaluation (same on every lane) ------------------------------------
     TpModel<NR, NC> M;
@@ -878,9 +910,9 @@ __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, c
         return;
     }
     if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
-        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red);
+        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red, acc_lds);
     else
-        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red);
+        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red, acc_lds);
 }
 
 template <int NR, int NC, int LANES>
@@ -888,7 +920,10 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;
     constexpr bool IN_LDS = MTG_TP_IN_LDS(J, LANES);  // 256 J = 10 elements live in a.tp_ws
-    __shared__ double sh[IN_LDS ? LANES * MTG_TP_ELEM(J) : 1];
+    // elements in LDS when they fit; otherwise (J = 10, 256 chunks) the elements go through a.tp_ws and
+    // LDS holds the information part (eta, Jm) of the chunk being composed
+    constexpr int NACC = J + J * (J + 1) / 2;
+    __shared__ double sh[IN_LDS ? LANES * MTG_TP_ELEM(J) : (LANES == 256 ? LANES * NACC : 1)];
     __shared__ double red[3 * (LANES / 64)];
     __shared__ MtgMathTables tab;
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
@@ -897,8 +932,10 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     if (!a.list && a.status[ev] != MTG_ST_OK) return;
     mtg_fill_tables(&tab, threadIdx.x, LANES);
     __syncthreads();
-    double *elems = IN_LDS ? sh : a.tp_ws + (int64_t)blockIdx.x * (LANES * MTG_TP_ELEM(J));
-    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, elems, red);
+    // workspace slice by EVALUATION, not by workgroup: the structures of a batch run concurrently on
+    // their own streams (solve_prepared) and share a.tp_ws
+    double *elems = IN_LDS ? sh : a.tp_ws + ev * (LANES * MTG_TP_ELEM(J));
+    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, elems, red, IN_LDS ? nullptr : sh);
 }
 
 template <int NR, int NC, int LANES = 64>
