@@ -1,6 +1,7 @@
 // mtg_capi.hip -- host side of the C-ABI declared in include/mtg.h.
 // One context = one MI355X + resident light curves + model + workspaces.
 #include "mtg_device.h"
+#include "mtg_tp_scan.h"
 
 #include <hipfft/hipfft.h>
 
@@ -270,29 +271,29 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     for (int i = 0; i < m.nterms; ++i)
         if (m.kinds[i] == MTG_TERM_JITTER) sa.has_mean = 1;  // the plain sweep variant also skips the jitter add
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
-    // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip).
+    // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip); the rank-10
+    // structures get as many chunks per evaluation as fill the GPU (mtg_tp_big.h).
     // Measured crossovers: J <= 6 (elements in registers) pays up to ~1000 evaluations; the J = 10
-    // kernels (elements spill) cost ~0.14 us x N + 0.6 ms per 256 evaluations with 64 chunks and
-    // ~0.05 us x N + 6 ms with 256 chunks, against ~1.05 us x N for the serial sweep.
+    // path costs ~3 x the serial sweep's work per sample, spread over every SIMD instead of B / 64 of
+    // them, against ~1.05 us x N for the serial sweep whatever B <= 65 536 is.
     const int Jmodel = m.nr0 + 2 * m.nc0;
     bool pays;
-    if (Jmodel <= 6) {
-        pays = ctx->N >= 256 && B <= 1024;
-    } else {  // microseconds per 256 evaluations against the serial sweep's ~1.05 us x N
-        const double n = (double)ctx->N, rounds = (double)((B + 255) / 256);
-        const double tp = n >= MTG_TP_BIG_WIDE_MIN_N ? 0.05 * n + 6000.0 : 0.14 * n + 600.0;
-        pays = rounds * tp < 1.05 * n;
-    }
+    if (Jmodel <= 6) pays = ctx->N >= 256 && B <= 1024;
+    else pays = ctx->N >= 1024 && B <= 8192;
     const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
+    sa.tp_chunks = 0;
     bool small_ok = small;
-    if (small && Jmodel > 6 && ctx->N >= MTG_TP_BIG_WIDE_MIN_N) {  // 256 chunks: elements in global memory
-        const size_t need = (size_t)B * MTG_TP_BIG_LANES * MTG_TP_ELEM(Jmodel) * sizeof(double);
+    if (small && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
             if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
-        if (small_ok && need <= ((size_t)8 << 30)) {  // else (forced mode, huge batch): the 64-chunk shape
+        const int C = mtg_tp_big_chunks(ctx->N, B);
+        const size_t need = (size_t)mtg_tp_big_plan(Jmodel, B, C).total * sizeof(double);
+        if (B > 65535 || need > ((size_t)16 << 30)) small_ok = false;  // grid / workspace limits: the serial sweep
+        if (small_ok) {
             HIP_TRY(ctx, ctx->tp_ws.reserve(need));
             sa.tp_ws = ctx->tp_ws.as<double>();
+            sa.tp_chunks = C;
         }
     }
     const bool wide = B <= 256 && ctx->N >= 4096;  // four waves per evaluation
@@ -726,6 +727,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.mean_kind = mean_kind;
     sa.has_mean = mean_params != nullptr || jitter != nullptr;
     sa.tp_ws = nullptr;
+    sa.tp_chunks = 0;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
     rc = sweep_launch(ctx, fn, sa, B, 0, s);

@@ -85,17 +85,14 @@ struct MtgSolveArgs {
     const double *dxmax;  // [1] max_n dx_n (device): decides table vs OCML sincos per wave
     int mean_kind;
     int has_mean;  // 0: the mean is identically zero for every evaluation of this launch and the model has no jitter term
-    // time-parallel kernels of rank J > 6 only: [B][256] chunk elements of MTG_TP_ELEM(J) doubles
-    // (they do not fit in LDS); NULL otherwise
+    // time-parallel path of the rank-10 structures only (mtg_tp_big.h): workspace laid out by
+    // mtg_tp_big_plan(J, B, tp_chunks) and the number of chunks per evaluation; NULL / 0 otherwise
     double *tp_ws;
+    int tp_chunks;
 };
 
 // doubles per filtering element (A | b | eta | C | Jm) of the time-parallel kernel
 #define MTG_TP_ELEM(J) ((J) * (J) + 2 * (J) + (J) * ((J) + 1))
-// chunks per evaluation of the J > 6 time-parallel kernels from MTG_TP_BIG_WIDE_MIN_N samples on
-// (64 chunks, elements in LDS, below)
-#define MTG_TP_BIG_LANES 256
-#define MTG_TP_BIG_WIDE_MIN_N 8192
 
 struct MtgPredictArgs {
     const double *coef;     // SoA coefficient workspace (mtg_prepare_kernel)

@@ -1,0 +1,435 @@
+// mtg_tp_big.h -- time-parallel log-likelihood for the rank-10 structures (five SHOTerms, BASELINE
+// configs[4]: N = 2e5 samples, 512 walkers), where neither the filtering element (230 doubles) nor
+// the combination of two of them fits the registers of one lane.
+//
+// Round 1 ran the whole algorithm of mtg_timeparallel.h in one kernel with one lane per chunk: 256
+// chunks per evaluation, the scan's combinations in scratch memory (9.8 KB per lane), ~10 ms per
+// launch whatever the batch.  Here the three passes are three kernels, each with the geometry that
+// suits it, and the number of chunks follows the batch so that 32 evaluations fill the GPU as well as
+// 256 do (mtg_tp_big_chunks):
+//   compose  mtg_tpb_compose_kernel<NR, NC>: lane = chunk (64 per workgroup); element of the chunk by
+//            the filter-from-zero recursion (tp_compose_step), eta / Jm accumulated in LDS; the
+//            element goes to global memory in the full layout of mtg_tp_scan.h;
+//   scan     mtg_tp_scan.h: up-sweep of combinations, down-sweep of applications, each J x J
+//            operation spread over 16 lanes with the operands in LDS -- no lane holds a matrix;
+//   filter   mtg_tpb_filter_kernel<NR, NC>: lane = chunk; the ordinary Kalman filter over the chunk
+//            from its start state; (sum z^2/D, ln prod D, min D) per chunk;
+//   finish   mtg_tpb_finish_kernel: one wave per evaluation adds the chunks up in a fixed order.
+// The light curve is cut into C chunks of `per` samples after sample 0, whose update of the
+// stationary prior is the scan's initial state (mtg_tpb_down_kernel).
+#pragma once
+#include "mtg_timeparallel.h"
+#include "mtg_tp_scan.h"
+
+namespace {
+
+// element -> global memory, full layout; eta and Jm go straight from their LDS accumulators (entry k of
+// this lane at acc[k * 64]: eta, then the triangle of Jm) -- loaded into registers first they would sit
+// next to A, b and C: the whole element, 460 registers
+template <int J> __device__ __forceinline__ void tpb_store_full(const TpElem<J> &e, const double *acc, double *slot)
+{
+    constexpr int M = J * J;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            slot[i * J + j] = e.A[i][j];
+            slot[M + 2 * J + i * J + j] = e.C(i, j);
+        }
+#pragma unroll
+    for (int i = 0; i < J; ++i) { slot[M + i] = e.b[i]; slot[M + J + i] = acc[i * 64]; }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const double v = acc[(J + i * (i + 1) / 2 + j) * 64];
+            slot[2 * M + 2 * J + i * J + j] = v;
+            slot[2 * M + 2 * J + j * J + i] = v;
+        }
+}
+
+// tp_predict_dev with the real x real part scaled row by row (phi_i phi_j formed inside the entry's
+// own product chain instead of as 55 simultaneous temporaries) and a scheduling barrier per block row
+template <int NR, int NC, int J>
+__device__ __forceinline__ void tpb_predict_dev(const TpTrans<NR, NC> &T, Sym<J> &Dv)
+{
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Dv(i, j) = (Dv(i, j) * T.phi[i]) * T.phi[j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int o = NR + 2 * k;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const double x0 = Dv(o, j) * T.phi[j], x1 = Dv(o + 1, j) * T.phi[j];
+            Dv(o, j) = T.ec[k] * x0 - T.es[k] * x1;
+            Dv(o + 1, j) = T.es[k] * x0 + T.ec[k] * x1;
+        }
+#pragma unroll
+        for (int l = 0; l < k; ++l) {
+            const int ol = NR + 2 * l;
+            const double b00 = Dv(o, ol), b01 = Dv(o, ol + 1), b10 = Dv(o + 1, ol), b11 = Dv(o + 1, ol + 1);
+            const double y00 = T.ec[k] * b00 - T.es[k] * b10, y01 = T.ec[k] * b01 - T.es[k] * b11;
+            const double y10 = T.es[k] * b00 + T.ec[k] * b10, y11 = T.es[k] * b01 + T.ec[k] * b11;
+            Dv(o, ol) = y00 * T.ec[l] - y01 * T.es[l];
+            Dv(o, ol + 1) = y00 * T.es[l] + y01 * T.ec[l];
+            Dv(o + 1, ol) = y10 * T.ec[l] - y11 * T.es[l];
+            Dv(o + 1, ol + 1) = y10 * T.es[l] + y11 * T.ec[l];
+        }
+        {
+            const double d00 = Dv(o, o), d10 = Dv(o + 1, o), d11 = Dv(o + 1, o + 1);
+            const double y00 = T.ec[k] * d00 - T.es[k] * d10, y01 = T.ec[k] * d10 - T.es[k] * d11;
+            const double y10 = T.es[k] * d00 + T.ec[k] * d10, y11 = T.es[k] * d10 + T.ec[k] * d11;
+            Dv(o, o) = y00 * T.ec[k] - y01 * T.es[k];
+            Dv(o + 1, o) = y10 * T.ec[k] - y11 * T.es[k];
+            Dv(o + 1, o + 1) = y10 * T.es[k] + y11 * T.ec[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One step of the chunk composition (tp_compose_step of mtg_timeparallel.h) arranged so that the register
+// allocator sees one stage at a time: transition | filter step on (b, Dv) | A column by column | Jm.
+// The scheduling barriers keep the stages from being interleaved: an element is 230 doubles, the file
+// holds 256 (512 registers), and every temporary that lives across a stage it does not belong to ends up
+// in scratch memory.  eta / Jm are accumulated in LDS (acc, entry k of this lane at acc[k * 64]).
+// b_lds != NULL: the mean part b of the element lives in LDS between steps (entry i of this lane at
+// b_lds[i * 64]) -- the all-real structure, whose workgroups have the trigonometric table's space to
+// spare and whose register allocation is the tightest.
+template <int NR, int NC, int J, class Prefetch>
+__device__ __forceinline__ void tpb_compose_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double y, double R,
+                                                 TpElem<J> &e, Sym<J> &Dv, double *acc, double *b_lds, Prefetch prefetch)
+{
+    // the filter step on (b, Dv) (tp_filter_step) with the gain kept as ch = D * kd: one vector less to hold
+    tpb_predict_dev<NR, NC, J>(T, Dv);
+    if (b_lds) {
+#pragma unroll
+        for (int i = 0; i < J; ++i) e.b[i] = b_lds[i * 64];
+    }
+    tp_apply_F<NR, NC>(T, e.b);
+    double ch[J];  // (P_inf + Dv) h
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double sum = i < NR ? M.ar[i] : ((i - NR) & 1 ? -M.bc[(i - NR) / 2] : M.ac[(i - NR) / 2]);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) sum += Dv(i, j);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) sum += Dv(i, NR + 2 * k);
+        ch[i] = sum;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const double D = tp_h_dot<NR, NC>(ch) + R;
+    const double z = y - tp_h_dot<NR, NC>(e.b);
+    const double inv = mtg_rcp(D);
+    const double zi = z * inv;
+#pragma unroll
+    for (int i = 0; i < J; ++i) e.b[i] = fma(ch[i], zi, e.b[i]);
+    if (b_lds) {
+#pragma unroll
+        for (int i = 0; i < J; ++i) b_lds[i * 64] = e.b[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const double ki = ch[i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Dv(i, j) = fma(-ki, ch[j], Dv(i, j));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    double g[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        double col[J];
+#pragma unroll
+        for (int i = 0; i < J; ++i) col[i] = e.A[i][j];
+        tp_apply_F<NR, NC>(T, col);
+        const double gj = tp_h_dot<NR, NC>(col);
+        const double gs = gj * inv;
+#pragma unroll
+        for (int i = 0; i < J; ++i) e.A[i][j] = fma(-ch[i], gs, col[i]);
+        g[j] = gj;
+        acc[j * 64] = fma(gj, zi, acc[j * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    prefetch();  // the next sample's loads go out here: their registers live through the Jm stage only
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const double gi = g[i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double *p = acc + (J + i * (i + 1) / 2 + j) * 64;
+            *p = fma(gi, g[j], *p);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// tp_transition term by term (same reason: the ten table look-ups and polynomials of a step would
+// otherwise be interleaved, each with its own temporaries).
+// fast = false (some d_k * max dx beyond the exact range of the table reduction): the phase increment
+// is first reduced modulo 2 pi with a two-part constant -- n = rint(x / 2 pi) is exact in a double, the
+// fused multiply-adds form x - n C1 - n C2 with one rounding each, and the rounding error of the
+// product d * dx itself is carried along -- and the remainder, |r| <= pi, goes through the same table
+// path.  (OCML's sincos / exp here cost a second copy of the loop and ~150 bytes of scratch per lane.)
+// exp(-c dx) as mtg_exp_cdx (mtg_math.h) with the per-term constants -c and -c 8N/ln2 replaced by one
+// product per step, dxs = dx 8N/ln2: the model of an evaluation is uniform over the workgroup and sits in
+// SGPRs, but anything COMPUTED from it is a vector value (there is no scalar FP64 unit) -- two hoisted
+// doubles per term are 40 registers at ten real terms, which this kernel does not have.
+template <class Tab>
+__device__ __forceinline__ double tpb_exp(double c, double dx, double dxs, const Tab *tab)
+{
+    const double magic = 0x1.8p+55;                                                 // 1.5 * 2^(52+3)
+    const double w = __builtin_fma(-c, dxs, magic);
+    const double q8 = w - magic;                                                    // 8 rint(-c dx N / ln2)
+    const int i8 = (int)q8;
+    const double t = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+    const double r = __builtin_fma(-c, dx, q8 * -MTG_EXP_C1);
+    const double p = mtg_expm1_small(r);
+    return __builtin_ldexp(__builtin_fma(t, p, t), i8 >> (3 + MTG_EXP_BITS));
+}
+
+template <int NR, int NC, class Tab>
+__device__ __forceinline__ void tpb_transition(const TpModel<NR, NC> &M, double dx, TpTrans<NR, NC> &T, const Tab *tab,
+                                               bool fast)
+{
+    const double dxs = dx * MTG_EXP_CSCALE;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        T.phi[j] = tpb_exp(M.cr[j], dx, dxs, tab);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        double s, c;
+        const double e = tpb_exp(M.cc[k], dx, dxs, tab);
+        double r0 = 0.0;
+        int m0 = 0;
+        double dk = M.dc[k], xk = dx;
+        if (!fast) {  // uniform over the workgroup (one evaluation)
+            const double x = dk * dx, xl = fma(dk, dx, -x);
+            const double n = rint(x * 0x1.45f306dc9c883p-3);       // x / 2 pi
+            double r = fma(-n, 0x1.921fb54442d18p+2, x);            // 2 pi, head
+            xk = fma(-n, 0x1.1a62633145c07p-52, r) + xl;            // 2 pi, tail
+            dk = 1.0;
+        }
+        mtg_phase_step(dk, xk, r0, m0, &s, &c, tab);
+        T.ec[k] = e * c;
+        T.es[k] = e * s;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// model of evaluation `ev` (uniform over the workgroup: scalar loads); false = light-curve index
+// outside the resident set
+template <int NR, int NC>
+__device__ __forceinline__ bool tpb_load_model(const MtgSolveArgs &a, int64_t ev, TpModel<NR, NC> &M, double &jitter,
+                                               double &slope, double &icpt, int64_t &lc, bool &fast)
+{
+    const double *cf = a.coef + ev;
+    const int64_t cs = a.cstride;
+    double dmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { M.ar[j] = cf[a.lay.ar(j) * cs]; M.cr[j] = cf[a.lay.cr(j) * cs]; }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const double aa = cf[a.lay.ac(k) * cs], bb = cf[a.lay.bc(k) * cs], c = cf[a.lay.cc(k) * cs], d = cf[a.lay.dc(k) * cs];
+        M.ac[k] = aa; M.bc[k] = bb; M.cc[k] = c; M.dc[k] = d;
+        M.pc[k] = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
+        dmax = fmax(dmax, fabs(d));
+    }
+    jitter = cf[a.lay.jit() * cs];
+    slope = cf[a.lay.mean(0) * cs];
+    icpt = cf[a.lay.mean(1) * cs];
+    lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+    fast = dmax * *a.dxmax <= MTG_TRIG_FAST_MAX;
+    return !(lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes);
+}
+
+// workgroup -> evaluation through the structure's list; -1 = nothing to do
+__device__ __forceinline__ int64_t tpb_evaluation(const MtgSolveArgs &a, int64_t i)
+{
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if (i >= count) return -1;
+    const int64_t ev = a.list ? (int64_t)a.list[i] : i;
+    if (!a.list && a.status[ev] != MTG_ST_OK) return -1;
+    return ev;
+}
+
+// samples [lo, hi) of chunk c: C chunks of `per` samples after sample 0.  32-bit indices: a light curve
+// is at most 2^28 samples (its 16-byte records stay below the 4 GiB window, mtg_set_lightcurves), and
+// the loops address samples as (uniform 64-bit base) + (32-bit byte offset per lane).
+__device__ __forceinline__ void tpb_chunk_range(int64_t N, int C, uint32_t c, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t n = (uint32_t)N, per = (n - 1u + (uint32_t)C - 1u) / (uint32_t)C;
+    const uint64_t l = 1u + (uint64_t)c * per, h = l + per;
+    lo = l > n ? n : (uint32_t)l;
+    hi = h > n ? n : (uint32_t)h;
+}
+
+__device__ __forceinline__ double2 tpb_sample(const double2 *base, uint32_t byte_off)
+{
+    return *(const double2 *)((const char *)base + byte_off);
+}
+
+template <int NR, int NC>
+__device__ __forceinline__ void tpb_compose_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
+                                                 double icpt, int64_t lc, const MtgMathTablesT<(NC > 0)> *tab, bool fast, double *acc,
+                                                 const double *pc_sh, double *elems, int64_t ev, int C)
+{
+    constexpr int J = NR + 2 * NC;
+    constexpr int NACC = J + J * (J + 1) / 2;
+    const int lane = threadIdx.x;
+    const double2 *yv = a.yv + lc * a.N, *dxt = a.dxt + lc * a.t_stride;
+    uint32_t lo, hi;
+    tpb_chunk_range(a.N, C, blockIdx.x * 64u + threadIdx.x, lo, hi);
+    TpElem<J> e;
+    tp_identity<J>(e);
+    tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k * 64 + lane] = 0.0;
+    double *const b_lds = NC == 0 ? acc + NACC * 64 + lane : nullptr;
+    if (b_lds) {
+#pragma unroll
+        for (int i = 0; i < J; ++i) b_lds[i * 64] = 0.0;
+    }
+    const uint32_t last = ((uint32_t)a.N - 1u) * 16u, end = hi * 16u;
+    uint32_t off = lo * 16u;
+    double2 dn = tpb_sample(dxt, off < last ? off : last), yn = tpb_sample(yv, off < last ? off : last);
+    for (; off < end; off += 16u) {
+        // residual as (y - intercept) - slope t: one scalar operand per instruction (y - fma(slope, t,
+        // intercept) needs two, and the copy of the second becomes a loop-invariant VGPR pair)
+        const double dx = dn.x, r = fma(-slope, dn.y, yn.x - icpt), R = yn.y + jitter;
+        TpTrans<NR, NC> T;
+        tpb_transition<NR, NC>(M, dx, T, tab, fast);
+        __builtin_amdgcn_sched_barrier(0);
+        tpb_compose_step<NR, NC, J>(M, T, r, R, e, e.C, acc + lane, b_lds, [&]() {
+            const uint32_t nn = off + 16u < last ? off + 16u : last;
+            dn = tpb_sample(dxt, nn); yn = tpb_sample(yv, nn);
+        });
+    }
+    // the free entry of P_inf comes back from LDS: kept in registers across the loop it is ten VGPRs
+    // (computed from the model, it cannot live in SGPRs)
+    TpModel<NR, NC> M2 = M;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) M2.pc[k] = pc_sh[k];
+    tp_add_pinf<NR, NC, J>(M2, e.C);
+    if (b_lds) {
+#pragma unroll
+        for (int i = 0; i < J; ++i) e.b[i] = b_lds[i * 64];
+    }
+    tpb_store_full<J>(e, acc + lane, elems + (ev * C + (int64_t)(blockIdx.x * 64u + threadIdx.x)) * MTG_TPB_ELEM(J));
+}
+
+// grid (C / 64, evaluations of this structure), 64 lanes: lane = chunk
+template <int NR, int NC>
+__global__ void __launch_bounds__(64, 1) mtg_tpb_compose_kernel(MtgSolveArgs a, double *elems, int C)
+{
+    constexpr int J = NR + 2 * NC;
+    constexpr int NACC = J + J * (J + 1) / 2;
+    __shared__ double acc[64 * (NACC + (NC == 0 ? J : 0))];  // eta, Jm (+ b: tpb_compose_step)
+    __shared__ double pc_sh[NC > 0 ? NC : 1];
+    __shared__ MtgMathTablesT<(NC > 0)> tab;
+    const int64_t ev = tpb_evaluation(a, blockIdx.y);
+    if (ev < 0) return;
+    TpModel<NR, NC> M;
+    double jitter, slope, icpt;
+    int64_t lc;
+    bool fast;
+    if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;  // the finish kernel reports it
+    mtg_fill_tables(&tab, threadIdx.x, 64);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) pc_sh[k] = M.pc[k];
+    }
+    __syncthreads();
+    tpb_compose_body<NR, NC>(a, M, jitter, slope, icpt, lc, &tab, fast, acc, pc_sh, elems, ev, C);
+}
+
+template <int NR, int NC>
+__device__ __forceinline__ void tpb_filter_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
+                                                double icpt, int64_t lc, const MtgMathTablesT<(NC > 0)> *tab, bool fast, const double *st,
+                                                double *part, uint32_t lo, uint32_t hi)
+{
+    constexpr int J = NR + 2 * NC;
+    const double2 *yv = a.yv + lc * a.N, *dxt = a.dxt + lc * a.t_stride;
+    double m[J];
+    Sym<J> C;
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        m[i] = st[i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) C(i, j) = st[J + i * J + j];
+    }
+    tp_sub_pinf<NR, NC, J>(M, C);  // deviation form
+    double dot = 0.0, dprod = 1.0, dmin = INFINITY;
+    int dexp = 0;
+    const uint32_t last = ((uint32_t)a.N - 1u) * 16u, end = hi * 16u;
+    uint32_t off = lo * 16u;
+    double2 dn = tpb_sample(dxt, off < last ? off : last), yn = tpb_sample(yv, off < last ? off : last);
+    for (; off < end; off += 16u) {
+        const double2 dc = dn, yc = yn;
+        const uint32_t nn = off + 16u < last ? off + 16u : last;  // next sample, loaded under this one's arithmetic
+        dn = tpb_sample(dxt, nn); yn = tpb_sample(yv, nn);
+        TpTrans<NR, NC> T;
+        tpb_transition<NR, NC>(M, dc.x, T, tab, fast);
+        const double r = fma(-slope, dc.y, yc.x - icpt);
+        double D, inv, z, kd[J];
+        tp_filter_step<NR, NC, J>(M, T, r, yc.y + jitter, m, C, D, inv, z, kd);
+        dot = fma(z * z, inv, dot);
+        dmin = fmin(dmin, D);
+        const double pr = dprod * D;
+        dprod = __builtin_amdgcn_frexp_mant(pr);
+        dexp += __builtin_amdgcn_frexp_exp(pr);
+    }
+    part[0] = dot;
+    part[1] = log(dprod) + (double)dexp * 0.69314718055994530942;
+    part[2] = dmin;
+}
+
+template <int NR, int NC>
+__global__ void __launch_bounds__(64, 1) mtg_tpb_filter_kernel(MtgSolveArgs a, const double *states, double *parts, int C)
+{
+    constexpr int J = NR + 2 * NC;
+    __shared__ MtgMathTablesT<(NC > 0)> tab;
+    const int64_t ev = tpb_evaluation(a, blockIdx.y);
+    if (ev < 0) return;
+    mtg_fill_tables(&tab, threadIdx.x, 64);
+    __syncthreads();
+    TpModel<NR, NC> M;
+    double jitter, slope, icpt;
+    int64_t lc;
+    bool fast;
+    if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    uint32_t lo, hi;
+    tpb_chunk_range(a.N, C, c, lo, hi);
+    const double *st = states + (ev * C + c) * MTG_TPB_STATE(J);
+    double *part = parts + (ev * C + c) * 4;
+    tpb_filter_body<NR, NC>(a, M, jitter, slope, icpt, lc, &tab, fast, st, part, lo, hi);
+}
+
+}  // namespace
+
+// one wave per evaluation: the chunks' partial sums in a fixed order, plus the head (sample 0)
+void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
+                           hipStream_t stream);
+
+template <int NR, int NC>
+static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
+{
+    constexpr int J = NR + 2 * NC;
+    if (nevals <= 0 || !a.tp_ws) return;
+    const int C = a.tp_chunks;
+    const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C);
+    double *ws = a.tp_ws;
+    const dim3 grid((unsigned)(C / 64), (unsigned)nevals);
+    hipLaunchKernelGGL((mtg_tpb_compose_kernel<NR, NC>), grid, dim3(64), 0, s, a, ws + plan.elem_off[0], C);
+    mtg_launch_tpb_scan(J, a, plan, nevals, NR, NC, s);
+    hipLaunchKernelGGL((mtg_tpb_filter_kernel<NR, NC>), grid, dim3(64), 0, s, a, ws + plan.state_off[0],
+                       ws + plan.part_off, C);
+    mtg_launch_tpb_finish(a, ws + plan.part_off, ws + plan.head_off, C, nevals, s);
+}

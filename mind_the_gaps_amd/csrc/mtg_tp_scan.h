@@ -1,0 +1,330 @@
+// mtg_tp_scan.h -- the scan over the chunk elements of the big-J time-parallel path
+// (mtg_tp_big.h), with every J x J operation of a combination spread over a group of 16 lanes.
+//
+// A filtering element of rank J = 10 is 230 doubles; combining two of them in one lane needs
+// eight 10 x 10 products and an inverse -- ~800 doubles of temporaries, i.e. scratch memory (round 1:
+// 9.8 KB per lane, 10 ms per launch).  Here no lane ever holds a matrix: lane r of a group owns ROW r
+// of whatever is being computed (10 doubles), the operands sit in the group's LDS region and are
+// read as broadcasts (every lane of the group reads the same row of the right-hand operand), so a
+// product costs each lane J (J + J/2) issue slots and ~60 VGPRs; four groups share a wave.
+//
+// Structure of the scan (per evaluation, C chunk elements e_0 .. e_{C-1} in global memory):
+//   up-sweep    mtg_tpb_reduce_kernel: groups of 16 consecutive elements are composed into one
+//               (15 sequential combinations per lane group), level after level while more than 16
+//               elements remain;
+//   down-sweep  mtg_tpb_down_kernel: from the state after sample 0 the start state of every top-level
+//               element by sequential application, then level by level down to the chunks: the
+//               start state of element 16 k + i follows from that of group k by applying i elements.
+// Work: ~C combinations + ~C applications per evaluation (a Hillis-Steele scan needs C log2 C
+// combinations); depth: 15 combinations + 16 + 15 applications per level.
+//
+// Global layouts (full matrices, so that loading is a plain copy):
+//   element: A[J][J] | b[J] | eta[J] | C[J][J] | Jm[J][J]     MTG_TPB_ELEM(J) doubles
+//   state:   m[J] | P[J][J]                                   MTG_TPB_STATE(J) doubles
+#pragma once
+#include "mtg_device.h"
+
+#define MTG_TPB_ELEM(J) (3 * (J) * (J) + 2 * (J))
+#define MTG_TPB_STATE(J) ((J) * (J) + (J))
+#define MTG_TPB_GROUP 16   /* lanes per lane group = elements per scan group */
+#define MTG_TPB_MAX_LEVELS 4
+
+// Workspace of the big-J path, in doubles from a.tp_ws: element and state arrays per scan level,
+// per-chunk partial sums of the final filter pass, per-evaluation head (sample 0).
+struct MtgTpBigPlan {
+    int C;                         // chunks per evaluation (a power of two >= 64)
+    int nlev;                      // scan levels; level 0 = the chunks
+    int n[MTG_TPB_MAX_LEVELS];     // elements per evaluation at each level
+    int64_t elem_off[MTG_TPB_MAX_LEVELS], state_off[MTG_TPB_MAX_LEVELS];
+    int64_t part_off, head_off, total;
+};
+
+static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C)
+{
+    MtgTpBigPlan p;
+    p.C = C;
+    p.nlev = 0;
+    int64_t off = 0;
+    for (int n = C;; n /= MTG_TPB_GROUP) {
+        p.n[p.nlev] = n;
+        p.elem_off[p.nlev] = off; off += B * n * MTG_TPB_ELEM(J);
+        p.state_off[p.nlev] = off; off += B * n * MTG_TPB_STATE(J);
+        ++p.nlev;
+        if (n <= MTG_TPB_GROUP || p.nlev == MTG_TPB_MAX_LEVELS) break;
+    }
+    p.part_off = off; off += B * C * 4;
+    p.head_off = off; off += B * 4;
+    p.total = off;
+    return p;
+}
+
+// chunks per evaluation: enough (chunk, evaluation) lanes to fill the 256 CUs at one wave per SIMD
+// (65 536 lanes), at least 64, at most 4096, and no chunk shorter than ~24 samples
+static inline int mtg_tp_big_chunks(int64_t N, int64_t B)
+{
+    int C = 64;
+    while (C < 4096 && (int64_t)C * B < 65536 && (int64_t)C * 2 * 24 <= N) C *= 2;
+    return C;
+}
+
+void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc,
+                         hipStream_t stream);
+
+#ifdef __HIPCC__
+namespace tpg {
+
+// wave-level ordering of LDS traffic between the lanes of a group (they run in lock-step: one
+// wave; LDS operations of a wave complete in order)
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int J> struct Lds {  // one lane group's region
+    static constexpr int M = J * J;
+    double A1[M], C1[M], J1[M], b1[J], eta1[J];   // running element (reduce) / state in (C1, b1) (down)
+    double A2[M], C2[M], J2[M], b2[J], eta2[J];   // the next element
+    double T1[M], T2[M], T3[M];
+    double v1[J], v2[J], v3[J];
+    double piv[2 * J];
+};
+
+template <int J> __device__ __forceinline__ void row(const double *X, int r, double (&x)[J])
+{
+#pragma unroll
+    for (int k = 0; k < J; ++k) x[k] = X[r * J + k];
+}
+template <int J> __device__ __forceinline__ void col(const double *X, int r, double (&x)[J])
+{
+#pragma unroll
+    for (int k = 0; k < J; ++k) x[k] = X[k * J + r];
+}
+template <int J> __device__ __forceinline__ void put(double *X, int r, const double (&x)[J])
+{
+#pragma unroll
+    for (int k = 0; k < J; ++k) X[r * J + k] = x[k];
+}
+// o += x Y (x a row vector, Y in LDS, its rows read by every lane of the group)
+template <int J> __device__ __forceinline__ void mm(const double (&x)[J], const double *Y, double (&o)[J])
+{
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) o[j] = fma(x[k], Y[k * J + j], o[j]);
+        __builtin_amdgcn_sched_barrier(0);  // one row of Y in flight at a time: the registers hold rows, not matrices
+    }
+}
+// o += x Y^T
+template <int J> __device__ __forceinline__ void mmT(const double (&x)[J], const double *Y, double (&o)[J])
+{
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        double s = o[j];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(x[k], Y[j * J + k], s);
+        o[j] = s;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int J> __device__ __forceinline__ double dot(const double (&x)[J], const double *v)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; ++k) s = fma(x[k], v[k], s);
+    return s;
+}
+
+// Lanes J .. 15 of a group have no row of their own: they are given r = J - 1 and duplicate that row's
+// work, identical stores included (predicating the stores instead makes the compiler sink the arithmetic
+// into the predicated block while the LDS reads stay where they are -- every operand then lives in
+// scratch memory in between).
+//
+// Row r of (I + X Y)^-1 by Gauss-Jordan without pivoting (I + C J is similar to a symmetric positive
+// definite matrix); the pivot row travels through L.piv.  Returns the row of the inverse in gi and the
+// product of the pivots (= det) in det.
+template <int J>
+__device__ __forceinline__ void inv_ipxy(Lds<J> &L, const double *X, const double *Y, int r, double (&gi)[J],
+                                         double &det)
+{
+    double g[J], x[J];
+    row<J>(X, r, x);
+#pragma unroll
+    for (int j = 0; j < J; ++j) { g[j] = j == r ? 1.0 : 0.0; gi[j] = g[j]; }
+    mm<J>(x, Y, g);
+    det = 1.0;
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+        if (r == p) {
+            const double ip = 1.0 / g[p];
+#pragma unroll
+            for (int j = 0; j < J; ++j) { g[j] *= ip; gi[j] *= ip; }
+#pragma unroll
+            for (int j = 0; j < J; ++j) { L.piv[j] = g[j]; L.piv[J + j] = gi[j]; }
+            L.v3[0] = ip;
+        }
+        wsync();
+        const double f = r == p ? 0.0 : g[p];
+        det *= L.v3[0];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { g[j] = fma(-f, L.piv[j], g[j]); gi[j] = fma(-f, L.piv[J + j], gi[j]); }
+        wsync();
+    }
+    det = 1.0 / det;
+}
+
+// running element (A1, b1, eta1, C1, J1) <- (running) o (A2, b2, eta2, C2, J2), the running one earlier in
+// time:  G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2;
+//        eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1,
+// with G^-T J2 = J2 G^-1 (push-through identity).
+template <int J> __device__ __forceinline__ void combine(Lds<J> &L, int r)
+{
+    double gi[J], det;
+    inv_ipxy<J>(L, L.C1, L.J2, r, gi, det);
+    // w = b1 + C1 eta2 -> v1 ; t = eta2 - J2 b1 -> v2 ; Gi -> T1
+    {
+        double x[J];
+        row<J>(L.C1, r, x);
+        const double w = L.b1[r] + dot<J>(x, L.eta2);
+        row<J>(L.J2, r, x);
+        const double t = L.eta2[r] - dot<J>(x, L.b1);
+        L.v1[r] = w; L.v2[r] = t;
+        put<J>(L.T1, r, gi);
+    }
+    wsync();
+    // XA = Gi A1 -> T2 ; XC = Gi C1 -> T3 ; xb = Gi w -> v3
+    {
+        double xa[J], xc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { xa[j] = 0.0; xc[j] = 0.0; }
+        mm<J>(gi, L.A1, xa);
+        mm<J>(gi, L.C1, xc);
+        const double xb = dot<J>(gi, L.v1);
+        put<J>(L.T2, r, xa);
+        put<J>(L.T3, r, xc);
+        L.v3[r] = xb;
+    }
+    // yeta = G^-T t (column r of Gi; stays in this lane until A1's columns are read);
+    // YJ = G^-T J2 = J2 Gi ; Z = YJ A1
+    double yeta, z[J];
+    {
+        double x[J], yj[J];
+        col<J>(L.T1, r, x);
+        yeta = dot<J>(x, L.v2);
+        row<J>(L.J2, r, x);
+#pragma unroll
+        for (int j = 0; j < J; ++j) { yj[j] = 0.0; z[j] = 0.0; }
+        mm<J>(x, L.T1, yj);
+        mm<J>(yj, L.A1, z);
+    }
+    wsync();                       // everybody has read Gi (T1) and v2
+    put<J>(L.T1, r, z);       // Z -> T1
+    L.v2[r] = yeta;
+    wsync();
+    // new information part: eta = eta1 + A1^T yeta ; J = J1 + A1^T Z   (column r of A1)
+    double eta_new, j_new[J];
+    {
+        double a1c[J];
+        col<J>(L.A1, r, a1c);
+        eta_new = L.eta1[r] + dot<J>(a1c, L.v2);
+        row<J>(L.J1, r, j_new);
+        mm<J>(a1c, L.T1, j_new);
+    }
+    // new state part: A = A2 XA ; Y = A2 XC ; C = C2 + Y A2^T ; b = b2 + A2 xb
+    double a_new[J], c_new[J], b_new;
+    {
+        double a2[J], y[J];
+        row<J>(L.A2, r, a2);
+#pragma unroll
+        for (int j = 0; j < J; ++j) { a_new[j] = 0.0; y[j] = 0.0; }
+        mm<J>(a2, L.T2, a_new);
+        mm<J>(a2, L.T3, y);
+        row<J>(L.C2, r, c_new);
+        mmT<J>(y, L.A2, c_new);
+        b_new = L.b2[r] + dot<J>(a2, L.v3);
+    }
+    wsync();                       // all reads of the old running element are done
+    put<J>(L.A1, r, a_new);
+    put<J>(L.C1, r, c_new);
+    put<J>(L.J1, r, j_new);
+    L.b1[r] = b_new; L.eta1[r] = eta_new;
+    wsync();
+}
+
+// state (m in b1, P in C1) <- element (A2, b2, eta2, C2, J2) applied to it:
+//   G = I + P J2;  m' = A2 G^-1 (m + P eta2) + b2;  P' = A2 G^-1 P A2^T + C2
+template <int J> __device__ __forceinline__ void apply(Lds<J> &L, int r)
+{
+    double gi[J], det;
+    inv_ipxy<J>(L, L.C1, L.J2, r, gi, det);
+    {
+        double x[J];
+        row<J>(L.C1, r, x);
+        const double w = L.b1[r] + dot<J>(x, L.eta2);
+        L.v1[r] = w;
+    }
+    wsync();
+    {
+        double xc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) xc[j] = 0.0;
+        mm<J>(gi, L.C1, xc);
+        const double xb = dot<J>(gi, L.v1);
+        put<J>(L.T3, r, xc);
+        L.v3[r] = xb;
+    }
+    wsync();
+    double c_new[J], b_new;
+    {
+        double a2[J], y[J];
+        row<J>(L.A2, r, a2);
+#pragma unroll
+        for (int j = 0; j < J; ++j) y[j] = 0.0;
+        mm<J>(a2, L.T3, y);
+        row<J>(L.C2, r, c_new);
+        mmT<J>(y, L.A2, c_new);
+        b_new = L.b2[r] + dot<J>(a2, L.v3);
+    }
+    wsync();
+    put<J>(L.C1, r, c_new);
+    L.b1[r] = b_new;
+    wsync();
+}
+
+// copy n doubles global <-> LDS by the 16 lanes of a group
+__device__ __forceinline__ void gcopy(double *dst, const double *src, int n, int l16)
+{
+    for (int i = l16; i < n; i += MTG_TPB_GROUP) dst[i] = src[i];
+}
+
+template <int J> __device__ __forceinline__ void load_second(Lds<J> &L, const double *e, int l16)
+{
+    constexpr int M = J * J;
+    gcopy(L.A2, e, M, l16);
+    gcopy(L.b2, e + M, J, l16);
+    gcopy(L.eta2, e + M + J, J, l16);
+    gcopy(L.C2, e + M + 2 * J, M, l16);
+    gcopy(L.J2, e + 2 * M + 2 * J, M, l16);
+}
+template <int J> __device__ __forceinline__ void load_first(Lds<J> &L, const double *e, int l16)
+{
+    constexpr int M = J * J;
+    gcopy(L.A1, e, M, l16);
+    gcopy(L.b1, e + M, J, l16);
+    gcopy(L.eta1, e + M + J, J, l16);
+    gcopy(L.C1, e + M + 2 * J, M, l16);
+    gcopy(L.J1, e + 2 * M + 2 * J, M, l16);
+}
+template <int J> __device__ __forceinline__ void store_first(const Lds<J> &L, double *e, int l16)
+{
+    constexpr int M = J * J;
+    gcopy(e, L.A1, M, l16);
+    gcopy(e + M, L.b1, J, l16);
+    gcopy(e + M + J, L.eta1, J, l16);
+    gcopy(e + M + 2 * J, L.C1, M, l16);
+    gcopy(e + 2 * M + 2 * J, L.J1, M, l16);
+}
+
+}  // namespace tpg
+#endif  // __HIPCC__

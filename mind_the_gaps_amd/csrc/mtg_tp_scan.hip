@@ -1,0 +1,187 @@
+// mtg_tp_scan.hip -- scan kernels of the big-J time-parallel path (mtg_tp_scan.h, mtg_tp_big.h):
+// up-sweep (mtg_tpb_reduce_kernel), down-sweep (mtg_tpb_down_kernel), final sum
+// (mtg_tpb_finish_kernel).  They depend on the rank J only, not on the (real, complex) structure.
+#include "mtg_tp_scan.h"
+
+#include <math.h>
+
+#define MTG_LN_2PI 1.8378770664093454835606594728112
+
+namespace {
+
+constexpr int GROUPS = 4;  // lane groups per workgroup (one wave)
+
+// group -> (evaluation, group index inside the evaluation); false = nothing to do
+__device__ __forceinline__ bool tpb_group(const MtgSolveArgs &a, int groups_per_eval, int64_t &ev, int &k)
+{
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + (threadIdx.x >> 4);
+    const int64_t i = gid / groups_per_eval;
+    k = (int)(gid % groups_per_eval);
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if (i >= count) return false;
+    ev = a.list ? (int64_t)a.list[i] : i;
+    if (!a.list && a.status[ev] != MTG_ST_OK) return false;
+    return true;
+}
+
+// out[ev][k] = in[ev][16 k] o in[ev][16 k + 1] o ... o in[ev][16 k + 15]
+template <int J>
+__global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_GROUP */, 1) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
+                                                                                           double *out, int n_in)
+{
+    __shared__ tpg::Lds<J> lds[GROUPS];
+    const int gpe = n_in / MTG_TPB_GROUP;
+    int64_t ev;
+    int k;
+    if (!tpb_group(a, gpe, ev, k)) return;
+    if (k == gpe - 1) return;  // only prefixes are ever applied: the last group's total is not needed
+    tpg::Lds<J> &L = lds[threadIdx.x >> 4];
+    const int l16 = threadIdx.x & 15;
+    const int r = l16 < J ? l16 : J - 1;
+    const double *e = in + (ev * n_in + (int64_t)k * MTG_TPB_GROUP) * MTG_TPB_ELEM(J);
+    tpg::load_first<J>(L, e, l16);
+#pragma unroll 1
+    for (int i = 1; i < MTG_TPB_GROUP; ++i) {
+        tpg::load_second<J>(L, e + (int64_t)i * MTG_TPB_ELEM(J), l16);
+        tpg::wsync();
+        tpg::combine<J>(L, r);
+    }
+    tpg::store_first<J>(L, out + (ev * gpe + k) * MTG_TPB_ELEM(J), l16);
+}
+
+// states[ev][k gsize + i] = start state of element k gsize + i, i = 0 .. gsize - 1, from the start state
+// of the group: up[ev][k] (the level above), or -- at the top, up == NULL, one group per evaluation --
+// the filtered state after sample 0 (update of the stationary prior; also leaves that sample's terms of
+// the likelihood in head[ev]).
+template <int J>
+__global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, const double *elems, const double *up,
+                                                          double *states, double *head, int n, int gsize, int nr, int nc)
+{
+    constexpr int M = J * J;
+    __shared__ tpg::Lds<J> lds[GROUPS];
+    const int gpe = n / gsize;
+    int64_t ev;
+    int k;
+    if (!tpb_group(a, gpe, ev, k)) return;
+    tpg::Lds<J> &L = lds[threadIdx.x >> 4];
+    const int l16 = threadIdx.x & 15;
+    const int r = l16 < J ? l16 : J - 1;
+    if (up) {
+        const double *s = up + (ev * gpe + k) * MTG_TPB_STATE(J);
+        tpg::gcopy(L.b1, s, J, l16);
+        tpg::gcopy(L.C1, s + J, M, l16);
+    } else {
+        const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+        if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) return;
+        if (l16 == 0) {  // stationary covariance P_inf and P_inf h, rank by rank
+            const double *cf = a.coef + ev;
+            const int64_t cs = a.cstride;
+            for (int i = 0; i < M; ++i) L.C1[i] = 0.0;
+            double D0 = 0.0;
+            for (int j = 0; j < nr; ++j) {
+                const double aj = cf[a.lay.ar(j) * cs];
+                L.C1[j * J + j] = aj; L.v1[j] = aj; D0 += aj;
+            }
+            for (int q = 0; q < nc; ++q) {
+                const double aa = cf[a.lay.ac(q) * cs], bb = cf[a.lay.bc(q) * cs], c = cf[a.lay.cc(q) * cs], d = cf[a.lay.dc(q) * cs];
+                const double p = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
+                const int o = nr + 2 * q;
+                L.C1[o * J + o] = aa; L.C1[o * J + o + 1] = -bb; L.C1[(o + 1) * J + o] = -bb; L.C1[(o + 1) * J + o + 1] = p;
+                L.v1[o] = aa; L.v1[o + 1] = -bb; D0 += aa;
+            }
+            const double2 y0 = a.yv[lc * a.N], t0 = a.dxt[lc * a.t_stride];
+            D0 += y0.y + cf[a.lay.jit() * cs];
+            const double z0 = y0.x - fma(cf[a.lay.mean(0) * cs], t0.y, cf[a.lay.mean(1) * cs]);
+            L.v2[0] = z0 / D0; L.v2[1] = 1.0 / D0;
+            double *h = head + ev * 4;
+            h[0] = z0 * z0 / D0; h[1] = log(D0); h[2] = D0;
+        }
+        tpg::wsync();
+        {
+            const double chr = L.v1[r];
+            double prow[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) prow[j] = L.C1[r * J + j] - chr * L.v1[j] * L.v2[1];
+            tpg::wsync();   // lanes J .. 15 duplicate row J - 1: everybody reads before anybody writes
+            L.b1[r] = chr * L.v2[0];
+            tpg::put<J>(L.C1, r, prow);
+        }
+    }
+    tpg::wsync();
+    const int64_t first = ev * n + (int64_t)k * gsize;
+#pragma unroll 1
+    for (int i = 0; i < gsize; ++i) {
+        double *s = states + (first + i) * MTG_TPB_STATE(J);
+        tpg::gcopy(s, L.b1, J, l16);
+        tpg::gcopy(s + J, L.C1, M, l16);
+        if (i + 1 < gsize) {
+            tpg::load_second<J>(L, elems + (first + i) * MTG_TPB_ELEM(J), l16);
+            tpg::wsync();
+            tpg::apply<J>(L, r);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) mtg_tpb_finish_kernel(MtgSolveArgs a, const double *parts, const double *head, int C)
+{
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if ((int64_t)blockIdx.x >= count) return;
+    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
+    if (!a.list && a.status[ev] != MTG_ST_OK) return;
+    const int lane = threadIdx.x;
+    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+    if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) {
+        if (lane == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
+        return;
+    }
+    double dot = 0.0, ld = 0.0, dmin = INFINITY;
+    for (int c = lane; c < C; c += 64) {
+        const double *p = parts + (ev * C + c) * 4;
+        dot += p[0]; ld += p[1]; dmin = fmin(dmin, p[2]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        dot += __shfl_down(dot, off);
+        ld += __shfl_down(ld, off);
+        dmin = fmin(dmin, __shfl_down(dmin, off));
+    }
+    if (lane == 0) {
+        const double *h = head + ev * 4;
+        dot += h[0]; ld += h[1]; dmin = fmin(dmin, h[2]);
+        double ll = -0.5 * (dot + ld + (double)a.N * MTG_LN_2PI);
+        int st = MTG_ST_OK;
+        if (!(dmin > 0.0)) { st = MTG_ST_NOTPD; ll = -INFINITY; }
+        else if (!isfinite(ll)) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
+        a.out[ev] = ll;
+        a.status[ev] = st;
+    }
+}
+
+template <int J>
+void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int nr, int nc, hipStream_t s)
+{
+    double *ws = a.tp_ws;
+    auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
+    for (int l = 0; l + 1 < p.nlev; ++l)
+        hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
+                           ws + p.elem_off[l], ws + p.elem_off[l + 1], p.n[l]);
+    const int top = p.nlev - 1;
+    hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top], (const double *)nullptr,
+                       ws + p.state_off[top], ws + p.head_off, p.n[top], p.n[top], nr, nc);
+    for (int l = top - 1; l >= 0; --l)
+        hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a, ws + p.elem_off[l],
+                           ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off, p.n[l], MTG_TPB_GROUP, nr, nc);
+}
+
+}  // namespace
+
+void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc,
+                         hipStream_t stream)
+{
+    if (J == 10) launch_scan<10>(a, plan, nevals, nr, nc, stream);
+}
+
+void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL(mtg_tpb_finish_kernel, dim3((unsigned)nevals), dim3(64), 0, stream, a, parts, head, C);
+}
