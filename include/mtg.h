@@ -171,9 +171,18 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
  * evaluation (throughput kernel), 1 = one wave per evaluation, parallel in time, whenever the
  * structure has that kernel (J <= 6, and the J = 10 structures of five SHO terms), 2 = automatic
  * (default): time-parallel for light curves of at least 256 samples and batches of at most 1024
- * evaluations (J <= 6: 4-10x faster there) or 128 evaluations (J = 10: ~3x faster).
+ * evaluations (J <= 6: 4-10x faster there); J = 10: at least 1024 samples and at most 8192 evaluations
+ * (the light curve is cut into as many chunks as fill the GPU: 40-100x faster than the serial sweep for
+ * the 32-256 evaluations of an ensemble half-step).
  */
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
+/*
+ * J = 10 time-parallel path: enabled != 0 (default) takes the likelihood from the chunk-composition pass
+ * and the scan alone and sends only evaluations whose terms cancel badly (or meet a non-positive pivot)
+ * through the filter pass; 0 runs the filter pass for every evaluation.  Same results to ~1e-13; a
+ * switch for tests and measurements.
+ */
+MTG_API int mtg_set_tp_direct(mtg_ctx *ctx, int enabled);
 /* Block until everything enqueued on the context's stream has finished. */
 MTG_API int mtg_synchronize(mtg_ctx *ctx);
 /* Device time (ms, HIP events on the launch stream) of the last

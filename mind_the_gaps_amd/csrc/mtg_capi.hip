@@ -72,6 +72,7 @@ struct mtg_ctx {
 
     // small batches: one wave per evaluation, parallel in time (0 never, 1 whenever compiled, 2 auto)
     int tp_mode = 2;
+    int tp_direct = 1;  // rank-10 time-parallel path: likelihood without the filter pass (mtg_set_tp_direct)
 
     // device-resident ensembles (mtg_ensemble_*)
     int64_t ens_E = 0;
@@ -283,6 +284,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
+    sa.tp_direct = ctx->tp_direct;
     bool small_ok = small;
     if (small && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
@@ -728,6 +730,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.has_mean = mean_params != nullptr || jitter != nullptr;
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
+    sa.tp_direct = 0;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
     rc = sweep_launch(ctx, fn, sa, B, 0, s);
@@ -1139,6 +1142,13 @@ MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return MTG_E_ARG;
     ctx->tp_mode = mode;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_tp_direct(mtg_ctx *ctx, int enabled)
+{
+    if (!ctx) return MTG_E_ARG;
+    ctx->tp_direct = enabled >= 2 ? enabled : (enabled ? 1 : 0);  // 2 (diagnostic): never fall back to the filter pass
     return MTG_OK;
 }
 

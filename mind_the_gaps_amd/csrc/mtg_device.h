@@ -89,6 +89,7 @@ struct MtgSolveArgs {
     // mtg_tp_big_plan(J, B, tp_chunks) and the number of chunks per evaluation; NULL / 0 otherwise
     double *tp_ws;
     int tp_chunks;
+    int tp_direct;  // likelihood without the filter pass (mtg_tp_big.h)
 };
 
 // doubles per filtering element (A | b | eta | C | Jm) of the time-parallel kernel

@@ -99,9 +99,11 @@ __device__ __forceinline__ void tpb_predict_dev(const TpTrans<NR, NC> &T, Sym<J>
 // b_lds != NULL: the mean part b of the element lives in LDS between steps (entry i of this lane at
 // b_lds[i * 64]) -- the all-real structure, whose workgroups have the trigonometric table's space to
 // spare and whose register allocation is the tightest.
+// kap: (sum z^2/D, prod D, min D) of this recursion -- the chunk's likelihood given x_in = 0.
 template <int NR, int NC, int J, class Prefetch>
 __device__ __forceinline__ void tpb_compose_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double y, double R,
-                                                 TpElem<J> &e, Sym<J> &Dv, double *acc, double *b_lds, Prefetch prefetch)
+                                                 TpElem<J> &e, Sym<J> &Dv, double *acc, double *b_lds, double (&kap)[3],
+                                                 Prefetch prefetch)
 {
     // the filter step on (b, Dv) (tp_filter_step) with the gain kept as ch = D * kd: one vector less to hold
     tpb_predict_dev<NR, NC, J>(T, Dv);
@@ -125,6 +127,9 @@ __device__ __forceinline__ void tpb_compose_step(const TpModel<NR, NC> &M, const
     const double z = y - tp_h_dot<NR, NC>(e.b);
     const double inv = mtg_rcp(D);
     const double zi = z * inv;
+    kap[0] = fma(z, zi, kap[0]);
+    kap[1] *= D;
+    kap[2] = fmin(kap[2], D);
 #pragma unroll
     for (int i = 0; i < J; ++i) e.b[i] = fma(ch[i], zi, e.b[i]);
     if (b_lds) {
@@ -151,22 +156,39 @@ __device__ __forceinline__ void tpb_compose_step(const TpModel<NR, NC> &M, const
 #pragma unroll
         for (int i = 0; i < J; ++i) e.A[i][j] = fma(-ch[i], gs, col[i]);
         g[j] = gj;
-        acc[j * 64] = fma(gj, zi, acc[j * 64]);
         __builtin_amdgcn_sched_barrier(0);
     }
     prefetch();  // the next sample's loads go out here: their registers live through the Jm stage only
     __builtin_amdgcn_sched_barrier(0);
+    // eta += g z / D ; Jm += g g^T / D in LDS, in three batches of reads, multiply-adds and writes: the
+    // round trip to LDS is paid three times per step instead of once per row
+    {
+        double v[J];
 #pragma unroll
-    for (int i = 0; i < J; ++i) {
-        const double gi = g[i] * inv;
+        for (int j = 0; j < J; ++j) v[j] = acc[j * 64];
 #pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double *p = acc + (J + i * (i + 1) / 2 + j) * 64;
-            *p = fma(gi, g[j], *p);
+        for (int j = 0; j < J; ++j) acc[j * 64] = fma(g[j], zi, v[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int SPLIT = (2 * J + 2) / 3;  // rows [0, SPLIT) and [SPLIT, J) hold about half the triangle each
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        constexpr int R0[2] = {0, SPLIT}, R1[2] = {SPLIT, J};
+        double v[J * (J + 1) / 2];
+#pragma unroll
+        for (int i = R0[h]; i < R1[h]; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) v[i * (i + 1) / 2 + j] = acc[(J + i * (i + 1) / 2 + j) * 64];
+#pragma unroll
+        for (int i = R0[h]; i < R1[h]; ++i) {
+            const double gi = g[i] * inv;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) acc[(J + i * (i + 1) / 2 + j) * 64] = fma(gi, g[j], v[i * (i + 1) / 2 + j]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
 
 // tp_transition term by term (same reason: the ten table look-ups and polynomials of a step would
 // otherwise be interleaved, each with its own temporaries).
@@ -175,52 +197,74 @@ __device__ __forceinline__ void tpb_compose_step(const TpModel<NR, NC> &M, const
 // fused multiply-adds form x - n C1 - n C2 with one rounding each, and the rounding error of the
 // product d * dx itself is carried along -- and the remainder, |r| <= pi, goes through the same table
 // path.  (OCML's sincos / exp here cost a second copy of the loop and ~150 bytes of scratch per lane.)
-// exp(-c dx) as mtg_exp_cdx (mtg_math.h) with the per-term constants -c and -c 8N/ln2 replaced by one
-// product per step, dxs = dx 8N/ln2: the model of an evaluation is uniform over the workgroup and sits in
-// SGPRs, but anything COMPUTED from it is a vector value (there is no scalar FP64 unit) -- two hoisted
-// doubles per term are 40 registers at ten real terms, which this kernel does not have.
-template <class Tab>
-__device__ __forceinline__ double tpb_exp(double c, double dx, double dxs, const Tab *tab)
-{
-    const double magic = 0x1.8p+55;                                                 // 1.5 * 2^(52+3)
-    const double w = __builtin_fma(-c, dxs, magic);
-    const double q8 = w - magic;                                                    // 8 rint(-c dx N / ln2)
-    const int i8 = (int)q8;
-    const double t = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
-    const double r = __builtin_fma(-c, dx, q8 * -MTG_EXP_C1);
-    const double p = mtg_expm1_small(r);
-    return __builtin_ldexp(__builtin_fma(t, p, t), i8 >> (3 + MTG_EXP_BITS));
-}
-
+// Transition of one step, in two phases so that the LDS latency of the table look-ups is paid once per
+// step, not once per term (one wave per SIMD: nothing else hides it): phase 1 reduces every argument and
+// issues every look-up, phase 2 runs the polynomials.
+//   exp(-c dx) as mtg_exp_cdx (mtg_math.h) with the per-term constants -c and -c 8N/ln2 replaced by one
+//   product per step, dxs = dx 8N/ln2: the model of an evaluation is uniform over the workgroup and sits
+//   in SGPRs, but anything COMPUTED from it is a vector value (there is no scalar FP64 unit) -- two
+//   hoisted doubles per term are 40 registers at ten real terms, which the compose kernel does not have.
+//   fast = false (some d_k * max dx beyond the exact range of the table reduction): the phase increment
+//   is first reduced modulo 2 pi with a two-part constant -- n = rint(x / 2 pi) is exact in a double, the
+//   fused multiply-adds form x - n C1 - n C2 with one rounding each, and the rounding error of the
+//   product d * dx itself is carried along -- and the remainder, |r| <= pi, goes through the same table
+//   path.  (OCML's sincos / exp here cost a second copy of the loop and ~150 bytes of scratch per lane.)
 template <int NR, int NC, class Tab>
 __device__ __forceinline__ void tpb_transition(const TpModel<NR, NC> &M, double dx, TpTrans<NR, NC> &T, const Tab *tab,
                                                bool fast)
 {
+    constexpr int NT = NR + NC;
     const double dxs = dx * MTG_EXP_CSCALE;
+    const double magic = 0x1.8p+55;                                                 // 1.5 * 2^(52+3)
+    double er[NT > 0 ? NT : 1], et[NT > 0 ? NT : 1];   // remainder and table value of every exp
+    int ek[NT > 0 ? NT : 1];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        T.phi[j] = tpb_exp(M.cr[j], dx, dxs, tab);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NT; ++i) {
+        const double c = i < NR ? M.cr[i < NR ? i : 0] : M.cc[i < NR ? 0 : i - NR];
+        const double w = __builtin_fma(-c, dxs, magic);
+        const double q8 = w - magic;                                                // 8 rint(-c dx N / ln2)
+        const int i8 = (int)q8;
+        et[i] = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+        er[i] = __builtin_fma(-c, dx, q8 * -MTG_EXP_C1);
+        ek[i] = i8 >> (3 + MTG_EXP_BITS);
     }
+    double pr[NC > 0 ? NC : 1];
+    double2 pj[NC > 0 ? NC : 1];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        double s, c;
-        const double e = tpb_exp(M.cc[k], dx, dxs, tab);
-        double r0 = 0.0;
-        int m0 = 0;
         double dk = M.dc[k], xk = dx;
         if (!fast) {  // uniform over the workgroup (one evaluation)
             const double x = dk * dx, xl = fma(dk, dx, -x);
             const double n = rint(x * 0x1.45f306dc9c883p-3);       // x / 2 pi
-            double r = fma(-n, 0x1.921fb54442d18p+2, x);            // 2 pi, head
+            const double r = fma(-n, 0x1.921fb54442d18p+2, x);      // 2 pi, head
             xk = fma(-n, 0x1.1a62633145c07p-52, r) + xl;            // 2 pi, tail
             dk = 1.0;
         }
-        mtg_phase_step(dk, xk, r0, m0, &s, &c, tab);
-        T.ec[k] = e * c;
-        T.es[k] = e * s;
-        __builtin_amdgcn_sched_barrier(0);
+        // mtg_phase_step from phase 0 (mtg_math.h): reduction, table entry
+        const double tm = 0x1.8p+56;                                                // 1.5 * 2^(52+4)
+        const double x = dk * xk;
+        const double w = __builtin_fma(x, 0x1.45f306dc9c883p+1 * MTG_TRIG_N, tm);   // x 16 N / 2 pi
+        const double md16 = w - tm;
+        pr[k] = __builtin_fma(md16, -(0x1.921fb54442d18p-2 / MTG_TRIG_N), x);       // 2 pi / 16 N
+        pj[k] = *(const double2 *)((const char *)tab->cis + ((__double2loint(w) << 4) & ((MTG_TRIG_N - 1) * 16)));
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const double p = mtg_expm1_small(er[i]);
+        const double e = __builtin_ldexp(__builtin_fma(et[i], p, et[i]), ek[i]);
+        if (i < NR) {
+            T.phi[i < NR ? i : 0] = e;
+        } else {
+            const int k = i < NR ? 0 : i - NR;
+            double sn, cs;
+            mtg_sincos_small(pr[k], &sn, &cs);
+            const double s = __builtin_fma(pj[k].x, sn, pj[k].y * cs), c = __builtin_fma(-pj[k].y, sn, pj[k].x * cs);
+            T.ec[k] = e * c;
+            T.es[k] = e * s;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // model of evaluation `ev` (uniform over the workgroup: scalar loads); false = light-curve index
@@ -278,7 +322,7 @@ __device__ __forceinline__ double2 tpb_sample(const double2 *base, uint32_t byte
 template <int NR, int NC>
 __device__ __forceinline__ void tpb_compose_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
                                                  double icpt, int64_t lc, const MtgMathTablesT<(NC > 0)> *tab, bool fast, double *acc,
-                                                 const double *pc_sh, double *elems, int64_t ev, int C)
+                                                 const double *pc_sh, double *elems, double *parts, int64_t ev, int C)
 {
     constexpr int J = NR + 2 * NC;
     constexpr int NACC = J + J * (J + 1) / 2;
@@ -299,6 +343,8 @@ __device__ __forceinline__ void tpb_compose_body(const MtgSolveArgs &a, const Tp
     const uint32_t last = ((uint32_t)a.N - 1u) * 16u, end = hi * 16u;
     uint32_t off = lo * 16u;
     double2 dn = tpb_sample(dxt, off < last ? off : last), yn = tpb_sample(yv, off < last ? off : last);
+    double kap[3] = {0.0, 1.0, INFINITY};
+    int kexp = 0;
     for (; off < end; off += 16u) {
         // residual as (y - intercept) - slope t: one scalar operand per instruction (y - fma(slope, t,
         // intercept) needs two, and the copy of the second becomes a loop-invariant VGPR pair)
@@ -306,10 +352,18 @@ __device__ __forceinline__ void tpb_compose_body(const MtgSolveArgs &a, const Tp
         TpTrans<NR, NC> T;
         tpb_transition<NR, NC>(M, dx, T, tab, fast);
         __builtin_amdgcn_sched_barrier(0);
-        tpb_compose_step<NR, NC, J>(M, T, r, R, e, e.C, acc + lane, b_lds, [&]() {
+        tpb_compose_step<NR, NC, J>(M, T, r, R, e, e.C, acc + lane, b_lds, kap, [&]() {
             const uint32_t nn = off + 16u < last ? off + 16u : last;
             dn = tpb_sample(dxt, nn); yn = tpb_sample(yv, nn);
         });
+        kexp += __builtin_amdgcn_frexp_exp(kap[1]);
+        kap[1] = __builtin_amdgcn_frexp_mant(kap[1]);
+    }
+    {
+        double *part = parts + (ev * C + (int64_t)(blockIdx.x * 64u + threadIdx.x)) * 4;
+        part[0] = kap[0];
+        part[1] = log(kap[1]) + (double)kexp * 0.69314718055994530942;
+        part[2] = kap[2];
     }
     // the free entry of P_inf comes back from LDS: kept in registers across the loop it is ten VGPRs
     // (computed from the model, it cannot live in SGPRs)
@@ -326,7 +380,7 @@ __device__ __forceinline__ void tpb_compose_body(const MtgSolveArgs &a, const Tp
 
 // grid (C / 64, evaluations of this structure), 64 lanes: lane = chunk
 template <int NR, int NC>
-__global__ void __launch_bounds__(64, 1) mtg_tpb_compose_kernel(MtgSolveArgs a, double *elems, int C)
+__global__ void __launch_bounds__(64, 1) mtg_tpb_compose_kernel(MtgSolveArgs a, double *elems, double *parts, int C)
 {
     constexpr int J = NR + 2 * NC;
     constexpr int NACC = J + J * (J + 1) / 2;
@@ -346,7 +400,7 @@ __global__ void __launch_bounds__(64, 1) mtg_tpb_compose_kernel(MtgSolveArgs a, 
         for (int k = 0; k < NC; ++k) pc_sh[k] = M.pc[k];
     }
     __syncthreads();
-    tpb_compose_body<NR, NC>(a, M, jitter, slope, icpt, lc, &tab, fast, acc, pc_sh, elems, ev, C);
+    tpb_compose_body<NR, NC>(a, M, jitter, slope, icpt, lc, &tab, fast, acc, pc_sh, elems, parts, ev, C);
 }
 
 template <int NR, int NC>
@@ -417,7 +471,12 @@ __global__ void __launch_bounds__(64, 1) mtg_tpb_filter_kernel(MtgSolveArgs a, c
 // one wave per evaluation: the chunks' partial sums in a fixed order, plus the head (sample 0)
 void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
                            hipStream_t stream);
+void mtg_launch_tpb_finish_direct(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
+                                  int *redo_list, int *redo_count, hipStream_t stream);
 
+// a.tp_direct: the likelihood from the composition pass and the scan alone (see
+// mtg_tpb_finish_direct_kernel); the filter pass then runs for the evaluations on the redo list only --
+// as a rule none, and its workgroups leave at once.  Otherwise the filter pass runs for everybody.
 template <int NR, int NC>
 static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
 {
@@ -427,9 +486,17 @@ static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t
     const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C);
     double *ws = a.tp_ws;
     const dim3 grid((unsigned)(C / 64), (unsigned)nevals);
-    hipLaunchKernelGGL((mtg_tpb_compose_kernel<NR, NC>), grid, dim3(64), 0, s, a, ws + plan.elem_off[0], C);
-    mtg_launch_tpb_scan(J, a, plan, nevals, NR, NC, s);
-    hipLaunchKernelGGL((mtg_tpb_filter_kernel<NR, NC>), grid, dim3(64), 0, s, a, ws + plan.state_off[0],
+    hipLaunchKernelGGL((mtg_tpb_compose_kernel<NR, NC>), grid, dim3(64), 0, s, a, ws + plan.elem_off[0], ws + plan.part_off, C);
+    mtg_launch_tpb_scan(J, a, plan, nevals, NR, NC, a.tp_direct, s);
+    MtgSolveArgs f = a;
+    if (a.tp_direct) {
+        int *redo_list = (int *)(ws + plan.redo_off) + (int64_t)NR * (a.B + 16), *redo_count = redo_list + a.B;
+        (void)hipMemsetAsync(redo_count, 0, sizeof(int), s);
+        mtg_launch_tpb_finish_direct(a, ws + plan.part_off, ws + plan.head_off, C, nevals, redo_list, redo_count, s);
+        f.list = redo_list;
+        f.count_ptr = redo_count;
+    }
+    hipLaunchKernelGGL((mtg_tpb_filter_kernel<NR, NC>), grid, dim3(64), 0, s, f, ws + plan.state_off[0],
                        ws + plan.part_off, C);
-    mtg_launch_tpb_finish(a, ws + plan.part_off, ws + plan.head_off, C, nevals, s);
+    mtg_launch_tpb_finish(f, ws + plan.part_off, ws + plan.head_off, C, nevals, s);
 }

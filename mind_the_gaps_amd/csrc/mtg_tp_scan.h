@@ -36,7 +36,7 @@ struct MtgTpBigPlan {
     int nlev;                      // scan levels; level 0 = the chunks
     int n[MTG_TPB_MAX_LEVELS];     // elements per evaluation at each level
     int64_t elem_off[MTG_TPB_MAX_LEVELS], state_off[MTG_TPB_MAX_LEVELS];
-    int64_t part_off, head_off, total;
+    int64_t part_off, head_off, redo_off, total;
 };
 
 static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C)
@@ -54,6 +54,9 @@ static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C)
     }
     p.part_off = off; off += B * C * 4;
     p.head_off = off; off += B * 4;
+    // evaluations sent back through the filter pass (mtg_tp_big.h): one int list + counter per structure,
+    // indexed by its number of real terms (0 .. 10)
+    p.redo_off = off; off += 11 * ((B + 16) / 2 + 1);
     p.total = off;
     return p;
 }
@@ -67,7 +70,8 @@ static inline int mtg_tp_big_chunks(int64_t N, int64_t B)
     return C;
 }
 
-void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc,
+// corr != 0: the level-0 down-sweep also leaves every chunk's likelihood correction in parts[..][3]
+void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc, int corr,
                          hipStream_t stream);
 
 #ifdef __HIPCC__
@@ -113,7 +117,6 @@ template <int J> __device__ __forceinline__ void mm(const double (&x)[J], const 
     for (int k = 0; k < J; ++k) {
 #pragma unroll
         for (int j = 0; j < J; ++j) o[j] = fma(x[k], Y[k * J + j], o[j]);
-        __builtin_amdgcn_sched_barrier(0);  // one row of Y in flight at a time: the registers hold rows, not matrices
     }
 }
 // o += x Y^T
@@ -125,7 +128,6 @@ template <int J> __device__ __forceinline__ void mmT(const double (&x)[J], const
 #pragma unroll
         for (int k = 0; k < J; ++k) s = fma(x[k], Y[j * J + k], s);
         o[j] = s;
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int J> __device__ __forceinline__ double dot(const double (&x)[J], const double *v)
@@ -143,17 +145,17 @@ template <int J> __device__ __forceinline__ double dot(const double (&x)[J], con
 //
 // Row r of (I + X Y)^-1 by Gauss-Jordan without pivoting (I + C J is similar to a symmetric positive
 // definite matrix); the pivot row travels through L.piv.  Returns the row of the inverse in gi and the
-// product of the pivots (= det) in det.
+// reciprocal of the product of the pivots (1 / det) as dm * 2^de.
 template <int J>
 __device__ __forceinline__ void inv_ipxy(Lds<J> &L, const double *X, const double *Y, int r, double (&gi)[J],
-                                         double &det)
+                                         double &dm, int &de)
 {
     double g[J], x[J];
     row<J>(X, r, x);
 #pragma unroll
     for (int j = 0; j < J; ++j) { g[j] = j == r ? 1.0 : 0.0; gi[j] = g[j]; }
     mm<J>(x, Y, g);
-    det = 1.0;
+    dm = 1.0; de = 0;
 #pragma unroll
     for (int p = 0; p < J; ++p) {
         if (r == p) {
@@ -166,12 +168,16 @@ __device__ __forceinline__ void inv_ipxy(Lds<J> &L, const double *X, const doubl
         }
         wsync();
         const double f = r == p ? 0.0 : g[p];
-        det *= L.v3[0];
+        {
+            // (single pivots of I + X Y may be negative -- it is not symmetric -- only their product is a sign test)
+            const double pr = dm * L.v3[0];
+            dm = __builtin_amdgcn_frexp_mant(pr);
+            de += __builtin_amdgcn_frexp_exp(pr);
+        }
 #pragma unroll
         for (int j = 0; j < J; ++j) { g[j] = fma(-f, L.piv[j], g[j]); gi[j] = fma(-f, L.piv[J + j], gi[j]); }
         wsync();
     }
-    det = 1.0 / det;
 }
 
 // running element (A1, b1, eta1, C1, J1) <- (running) o (A2, b2, eta2, C2, J2), the running one earlier in
@@ -180,8 +186,9 @@ __device__ __forceinline__ void inv_ipxy(Lds<J> &L, const double *X, const doubl
 // with G^-T J2 = J2 G^-1 (push-through identity).
 template <int J> __device__ __forceinline__ void combine(Lds<J> &L, int r)
 {
-    double gi[J], det;
-    inv_ipxy<J>(L, L.C1, L.J2, r, gi, det);
+    double gi[J], dm;
+    int de;
+    inv_ipxy<J>(L, L.C1, L.J2, r, gi, dm, de);
     // w = b1 + C1 eta2 -> v1 ; t = eta2 - J2 b1 -> v2 ; Gi -> T1
     {
         double x[J];
@@ -254,17 +261,31 @@ template <int J> __device__ __forceinline__ void combine(Lds<J> &L, int r)
 
 // state (m in b1, P in C1) <- element (A2, b2, eta2, C2, J2) applied to it:
 //   G = I + P J2;  m' = A2 G^-1 (m + P eta2) + b2;  P' = A2 G^-1 P A2^T + C2
-template <int J> __device__ __forceinline__ void apply(Lds<J> &L, int r)
+// CORR: also returns the element's chunk likelihood given the state it is applied to, relative to
+// the chunk likelihood given x_in = 0 (kappa, which the composition pass accumulates):
+//   ln p(y_chunk | m, P) - kappa = -1/2 ln det G + eta^T m - 1/2 m^T J m + 1/2 t^T (G^-1 P) t,  t = eta - J m
+// (p(y_chunk | x_in) = exp(kappa + eta^T x_in - 1/2 x_in^T J x_in), integrated against N(m, P)).
+// NaN when det G is not positive.  UPDATE = false: only that number, the state is left alone.
+template <int J, bool CORR = false, bool UPDATE = true> __device__ __forceinline__ double apply(Lds<J> &L, int r)
 {
-    double gi[J], det;
-    inv_ipxy<J>(L, L.C1, L.J2, r, gi, det);
+    double gi[J], dm;
+    int de;
+    inv_ipxy<J>(L, L.C1, L.J2, r, gi, dm, de);
+    double t = 0.0, mr = 0.0, er = 0.0;
     {
         double x[J];
         row<J>(L.C1, r, x);
         const double w = L.b1[r] + dot<J>(x, L.eta2);
         L.v1[r] = w;
+        if (CORR) {
+            row<J>(L.J2, r, x);
+            mr = L.b1[r]; er = L.eta2[r];
+            t = er - dot<J>(x, L.b1);
+            L.v2[r] = t;
+        }
     }
     wsync();
+    double corr = 0.0;
     {
         double xc[J];
 #pragma unroll
@@ -273,7 +294,19 @@ template <int J> __device__ __forceinline__ void apply(Lds<J> &L, int r)
         const double xb = dot<J>(gi, L.v1);
         put<J>(L.T3, r, xc);
         L.v3[r] = xb;
+        if (CORR) {
+            const double xt = dot<J>(xc, L.v2);
+            // this row's share of eta^T m - 1/2 m^T J m + 1/2 t^T X t   (J m = eta - t)
+            L.piv[r] = fma(er, mr, 0.5 * fma(t, xt, -mr * (er - t)));
+            wsync();
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) sum += L.piv[k];
+            // 1 / det G = dm 2^de > 0, or some pivot was not positive
+            corr = dm > 0.0 ? sum + 0.5 * (log(dm) + (double)de * 0.69314718055994530942) : __builtin_nan("");
+        }
     }
+    if (!UPDATE) { wsync(); return corr; }
     wsync();
     double c_new[J], b_new;
     {
@@ -290,6 +323,7 @@ template <int J> __device__ __forceinline__ void apply(Lds<J> &L, int r)
     put<J>(L.C1, r, c_new);
     L.b1[r] = b_new;
     wsync();
+    return corr;
 }
 
 // copy n doubles global <-> LDS by the 16 lanes of a group

@@ -53,9 +53,12 @@ __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_GROUP */, 1) mtg_tpb_
 // of the group: up[ev][k] (the level above), or -- at the top, up == NULL, one group per evaluation --
 // the filtered state after sample 0 (update of the stationary prior; also leaves that sample's terms of
 // the likelihood in head[ev]).
-template <int J>
+// CORR (level 0 only): every element of the group is applied -- the last one for its number only -- and the
+// chunk likelihood correction of tpg::apply goes to parts[chunk][3].
+template <int J, bool CORR>
 __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, const double *elems, const double *up,
-                                                          double *states, double *head, int n, int gsize, int nr, int nc)
+                                                          double *states, double *head, double *parts, int n, int gsize,
+                                                          int nr, int nc)
 {
     constexpr int M = J * J;
     __shared__ tpg::Lds<J> lds[GROUPS];
@@ -114,7 +117,12 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, con
         double *s = states + (first + i) * MTG_TPB_STATE(J);
         tpg::gcopy(s, L.b1, J, l16);
         tpg::gcopy(s + J, L.C1, M, l16);
-        if (i + 1 < gsize) {
+        if (CORR) {
+            tpg::load_second<J>(L, elems + (first + i) * MTG_TPB_ELEM(J), l16);
+            tpg::wsync();
+            const double corr = i + 1 < gsize ? tpg::apply<J, true, true>(L, r) : tpg::apply<J, true, false>(L, r);
+            if (l16 == 0) parts[(first + i) * 4 + 3] = corr;
+        } else if (i + 1 < gsize) {
             tpg::load_second<J>(L, elems + (first + i) * MTG_TPB_ELEM(J), l16);
             tpg::wsync();
             tpg::apply<J>(L, r);
@@ -156,8 +164,52 @@ __global__ void __launch_bounds__(64) mtg_tpb_finish_kernel(MtgSolveArgs a, cons
     }
 }
 
+// Direct mode: lnL = sum over the chunks of [kappa_c (composition pass: the chunk's likelihood given
+// x_in = 0) + correction_c (down-sweep)] -- no filter pass.  kappa is computed under a wrong hypothesis, so
+// its residuals can be far larger than the true ones and the correction then cancels most of it; an
+// evaluation whose terms exceed 1e3 x the result (or with anything not positive / not finite on the way)
+// is appended to the redo list and goes through the filter pass, whose pivots are celerite's own.
+__global__ void __launch_bounds__(64) mtg_tpb_finish_direct_kernel(MtgSolveArgs a, const double *parts, const double *head, int C,
+                                                                   int *redo_list, int *redo_count)
+{
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    if ((int64_t)blockIdx.x >= count) return;
+    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
+    if (!a.list && a.status[ev] != MTG_ST_OK) return;
+    const int lane = threadIdx.x;
+    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+    if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) {
+        if (lane == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
+        return;
+    }
+    double dot = 0.0, ld = 0.0, dmin = INFINITY, corr = 0.0, mag = 0.0;
+    for (int c = lane; c < C; c += 64) {
+        const double *p = parts + (ev * C + c) * 4;
+        dot += p[0]; ld += p[1]; dmin = fmin(dmin, p[2]); corr += p[3]; mag += fabs(p[3]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        dot += __shfl_down(dot, off);
+        ld += __shfl_down(ld, off);
+        dmin = fmin(dmin, __shfl_down(dmin, off));
+        corr += __shfl_down(corr, off);
+        mag += __shfl_down(mag, off);
+    }
+    if (lane == 0) {
+        const double *h = head + ev * 4;
+        mag += 0.5 * dot;
+        dot += h[0]; ld += h[1]; dmin = fmin(dmin, h[2]);
+        const double ll = corr - 0.5 * (dot + ld + (double)a.N * MTG_LN_2PI);
+        if (a.tp_direct >= 2 || (dmin > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll))) {  // 2: diagnostic, never redo
+            a.out[ev] = a.tp_direct == 3 ? dot : a.tp_direct == 4 ? ld : a.tp_direct == 5 ? corr : a.tp_direct == 6 ? mag : ll;
+            a.status[ev] = MTG_ST_OK;
+        } else {
+            redo_list[atomicAdd(redo_count, 1)] = (int)ev;
+        }
+    }
+}
+
 template <int J>
-void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int nr, int nc, hipStream_t s)
+void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int nr, int nc, int corr, hipStream_t s)
 {
     double *ws = a.tp_ws;
     auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
@@ -165,19 +217,35 @@ void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, i
         hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
                            ws + p.elem_off[l], ws + p.elem_off[l + 1], p.n[l]);
     const int top = p.nlev - 1;
-    hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top], (const double *)nullptr,
-                       ws + p.state_off[top], ws + p.head_off, p.n[top], p.n[top], nr, nc);
-    for (int l = top - 1; l >= 0; --l)
-        hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a, ws + p.elem_off[l],
-                           ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off, p.n[l], MTG_TPB_GROUP, nr, nc);
+    // (the chunk count is at least 64, so the top level is never level 0)
+    hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top],
+                       (const double *)nullptr, ws + p.state_off[top], ws + p.head_off, (double *)nullptr, p.n[top], p.n[top],
+                       nr, nc);
+    for (int l = top - 1; l >= 0; --l) {
+        if (l == 0 && corr)
+            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, true>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
+                               ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
+                               ws + p.part_off, p.n[l], MTG_TPB_GROUP, nr, nc);
+        else
+            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
+                               ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
+                               (double *)nullptr, p.n[l], MTG_TPB_GROUP, nr, nc);
+    }
 }
 
 }  // namespace
 
-void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc,
+void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc, int corr,
                          hipStream_t stream)
 {
-    if (J == 10) launch_scan<10>(a, plan, nevals, nr, nc, stream);
+    if (J == 10) launch_scan<10>(a, plan, nevals, nr, nc, corr, stream);
+}
+
+void mtg_launch_tpb_finish_direct(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
+                                  int *redo_list, int *redo_count, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mtg_tpb_finish_direct_kernel, dim3((unsigned)nevals), dim3(64), 0, stream, a, parts, head, C, redo_list,
+                       redo_count);
 }
 
 void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,

@@ -30,7 +30,7 @@ EXPORTS = (
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
-    "mtg_apply_inverse",
+    "mtg_apply_inverse", "mtg_set_tp_direct",
 )
 
 
@@ -131,6 +131,8 @@ def load_library():
                                       c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, c_int]
     lib.mtg_set_time_parallel.restype = c_int
     lib.mtg_set_time_parallel.argtypes = [c_vp, c_int]
+    lib.mtg_set_tp_direct.restype = c_int
+    lib.mtg_set_tp_direct.argtypes = [c_vp, c_int]
     lib.mtg_apply_inverse.restype = c_int
     lib.mtg_apply_inverse.argtypes = [c_vp, _dp, ctypes.c_int32, c_i64, _dp, _ip]
     lib.mtg_set_window_bytes.restype = c_int
@@ -390,6 +392,10 @@ class Engine:
     def set_time_parallel(self, mode):
         """0 = throughput kernel only, 1 = time-parallel kernel whenever available, 2 = auto (default)."""
         self._check(self._lib.mtg_set_time_parallel(self._ctx, int(mode)))
+
+    def set_tp_direct(self, enabled):
+        """J = 10 time-parallel path: likelihood without the filter pass (default on); see include/mtg.h."""
+        self._check(self._lib.mtg_set_tp_direct(self._ctx, int(enabled)))
 
     def set_window_bytes(self, nbytes):
         """Testing aid: reach of one buffer descriptor of the sweep (default 2^32 - 1); see include/mtg.h."""

@@ -23,10 +23,22 @@ for B in Bs:
     theta = th + 0.05 * np.abs(th) * rng.standard_normal((B, len(th)))
     theta[0] = th
     eng.set_time_parallel(1)
+    eng.set_tp_direct(0)
+    out_f, st_f = eng.loglike(theta); ms_f = eng.last_kernel_ms
+    out_f, st_f = eng.loglike(theta); ms_f = min(ms_f, eng.last_kernel_ms)
+    eng.set_tp_direct(6)
+    mag = eng.loglike(theta)[0]
+    eng.set_tp_direct(2)
+    out_d, st_d = eng.loglike(theta)
+    print("   direct, no fallback: max rel diff to the filter pass %.2e; largest terms / result %.2e" % (
+        np.nanmax(np.abs(out_d - out_f) / np.abs(out_f)), np.max(mag / np.abs(out_f))))
+    eng.set_tp_direct(1)
     ms = []
     for _ in range(4):
         out, st = eng.loglike(theta); ms.append(eng.last_kernel_ms)
     ms = min(ms)
+    print("   direct vs filter pass: max rel diff %.2e, statuses equal %s; filter-pass mode %.3f ms" % (
+        np.max(np.abs(out - out_f) / np.abs(out_f)), np.array_equal(st, st_f), ms_f))
     if ref is None:
         eng.set_time_parallel(0)
         ref = eng.loglike(theta[:1])[0][0]
