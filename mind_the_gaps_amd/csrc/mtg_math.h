@@ -82,6 +82,10 @@ __device__ __forceinline__ void mtg_sincos_small(double r, double *s, double *c)
 #if MTG_TRIG_BITS >= 11
     *s = __builtin_fma(r * z, -0x1.5555555555555p-3, r);                            // r - r^3/6
     *c = __builtin_fma(__builtin_fma(z, 0x1.5555555555555p-5, -0.5), z, 1.0);       // 1 - z/2 + z^2/24
+#elif MTG_TRIG_BITS >= 10
+    // |r| <= pi / 1024: the sine needs its r^5 term (r^5/120 = 2e-15 without), the cosine is as above (r^6/720 = 1e-18)
+    *s = __builtin_fma(r * z, __builtin_fma(z, 0x1.1111111111111p-7, -0x1.5555555555555p-3), r);
+    *c = __builtin_fma(__builtin_fma(z, 0x1.5555555555555p-5, -0.5), z, 1.0);
 #elif MTG_TRIG_BITS >= 8
     const double ps = __builtin_fma(z, 0x1.1111111111111p-7, -0x1.5555555555555p-3);
     *s = __builtin_fma(r * z, ps, r);

@@ -27,9 +27,12 @@
 // the chunk elements of a workgroup sit in LDS when they fit (160 KiB per CU), else in a.tp_ws
 #define MTG_TP_IN_LDS(J, LANES) ((LANES) * MTG_TP_ELEM(J) * 8 <= 150 * 1024)
 
-// 256-entry tables here (2 KiB + 4 KiB): LDS is needed for the chunk elements
+// 256-entry tables here (2 KiB + 4 KiB): LDS is needed for the chunk elements (the rank-10 path,
+// mtg_tp_big.h, keeps its elements in registers / global memory and asks for the 2048-entry tables)
+#ifndef MTG_EXP_BITS
 #define MTG_EXP_BITS 8
 #define MTG_TRIG_BITS 8
+#endif
 #include "mtg_math.h"
 
 #include <math.h>

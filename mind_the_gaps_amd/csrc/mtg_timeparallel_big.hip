@@ -2,6 +2,9 @@
 //   hipcc -DMTG_TP_BIG_NR=<nr> -DMTG_TP_BIG_NC=<nc> -c mtg_timeparallel_big.hip
 // (compose and filter kernels of mtg_tp_big.h; the scan kernels, which depend on the rank only, are
 // compiled once in mtg_tp_scan.hip).
+// 2048 + 1024-entry tables (16 + 16 KiB): next to the 37 KiB of rings two composition workgroups still fit a CU
+#define MTG_EXP_BITS 11
+#define MTG_TRIG_BITS 10
 #include "mtg_tp_big.h"
 
 #define MTG_CAT2(a, b, c, d) a##b##c##d

@@ -3,18 +3,21 @@
 // the combination of two of them fits the registers of one lane.
 //
 // Round 1 ran the whole algorithm of mtg_timeparallel.h in one kernel with one lane per chunk: 256
-// chunks per evaluation, the scan's combinations in scratch memory (9.8 KB per lane), ~10 ms per
-// launch whatever the batch.  Here the three passes are three kernels, each with the geometry that
-// suits it, and the number of chunks follows the batch so that 32 evaluations fill the GPU as well as
-// 256 do (mtg_tp_big_chunks):
-//   compose  mtg_tpb_compose_kernel<NR, NC>: lane = chunk (64 per workgroup); element of the chunk by
-//            the filter-from-zero recursion (tp_compose_step), eta / Jm accumulated in LDS; the
-//            element goes to global memory in the full layout of mtg_tp_scan.h;
+// chunks per evaluation, the scan's combinations in scratch memory (9.8 KB per lane), ~10-14 ms per
+// launch whatever the batch.  Here the passes are separate kernels, each with the geometry that suits
+// it, none with scratch memory, and the number of chunks follows the batch so that 32 evaluations fill
+// the GPU as well as 256 do (mtg_tp_big_chunks):
+//   compose  mtg_tpb_compose2_kernel<NR, NC>: the element of every chunk by the filter-from-zero
+//            recursion, TWO waves per 64 chunks (one keeps A, the other Dv, b, eta, Jm; see below); also
+//            the chunk's likelihood given x_in = 0 (kappa);
 //   scan     mtg_tp_scan.h: up-sweep of combinations, down-sweep of applications, each J x J
-//            operation spread over 16 lanes with the operands in LDS -- no lane holds a matrix;
+//            operation spread over 16 lanes with the operands in LDS -- no lane holds a matrix; the last
+//            level of the down-sweep also yields every chunk's likelihood correction;
+//   finish   mtg_tpb_finish_direct_kernel: lnL = sum of (kappa + correction) -- no further pass over the
+//            data.  Evaluations whose terms cancel badly, or that met a pivot that is not positive, go
+//            through
 //   filter   mtg_tpb_filter_kernel<NR, NC>: lane = chunk; the ordinary Kalman filter over the chunk
-//            from its start state; (sum z^2/D, ln prod D, min D) per chunk;
-//   finish   mtg_tpb_finish_kernel: one wave per evaluation adds the chunks up in a fixed order.
+//            from its start state: celerite's own pivots and residuals (mtg_tpb_finish_kernel sums them).
 // The light curve is cut into C chunks of `per` samples after sample 0, whose update of the
 // stationary prior is the scan's initial state (mtg_tpb_down_kernel).
 #pragma once
@@ -22,31 +25,6 @@
 #include "mtg_tp_scan.h"
 
 namespace {
-
-// element -> global memory, full layout; eta and Jm go straight from their LDS accumulators (entry k of
-// this lane at acc[k * 64]: eta, then the triangle of Jm) -- loaded into registers first they would sit
-// next to A, b and C: the whole element, 460 registers
-template <int J> __device__ __forceinline__ void tpb_store_full(const TpElem<J> &e, const double *acc, double *slot)
-{
-    constexpr int M = J * J;
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            slot[i * J + j] = e.A[i][j];
-            slot[M + 2 * J + i * J + j] = e.C(i, j);
-        }
-#pragma unroll
-    for (int i = 0; i < J; ++i) { slot[M + i] = e.b[i]; slot[M + J + i] = acc[i * 64]; }
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            const double v = acc[(J + i * (i + 1) / 2 + j) * 64];
-            slot[2 * M + 2 * J + i * J + j] = v;
-            slot[2 * M + 2 * J + j * J + i] = v;
-        }
-}
 
 // tp_predict_dev with the real x real part scaled row by row (phi_i phi_j formed inside the entry's
 // own product chain instead of as 55 simultaneous temporaries) and a scheduling barrier per block row
@@ -91,112 +69,6 @@ __device__ __forceinline__ void tpb_predict_dev(const TpTrans<NR, NC> &T, Sym<J>
     }
 }
 
-// One step of the chunk composition (tp_compose_step of mtg_timeparallel.h) arranged so that the register
-// allocator sees one stage at a time: transition | filter step on (b, Dv) | A column by column | Jm.
-// The scheduling barriers keep the stages from being interleaved: an element is 230 doubles, the file
-// holds 256 (512 registers), and every temporary that lives across a stage it does not belong to ends up
-// in scratch memory.  eta / Jm are accumulated in LDS (acc, entry k of this lane at acc[k * 64]).
-// b_lds != NULL: the mean part b of the element lives in LDS between steps (entry i of this lane at
-// b_lds[i * 64]) -- the all-real structure, whose workgroups have the trigonometric table's space to
-// spare and whose register allocation is the tightest.
-// kap: (sum z^2/D, prod D, min D) of this recursion -- the chunk's likelihood given x_in = 0.
-template <int NR, int NC, int J, class Prefetch>
-__device__ __forceinline__ void tpb_compose_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double y, double R,
-                                                 TpElem<J> &e, Sym<J> &Dv, double *acc, double *b_lds, double (&kap)[3],
-                                                 Prefetch prefetch)
-{
-    // the filter step on (b, Dv) (tp_filter_step) with the gain kept as ch = D * kd: one vector less to hold
-    tpb_predict_dev<NR, NC, J>(T, Dv);
-    if (b_lds) {
-#pragma unroll
-        for (int i = 0; i < J; ++i) e.b[i] = b_lds[i * 64];
-    }
-    tp_apply_F<NR, NC>(T, e.b);
-    double ch[J];  // (P_inf + Dv) h
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double sum = i < NR ? M.ar[i] : ((i - NR) & 1 ? -M.bc[(i - NR) / 2] : M.ac[(i - NR) / 2]);
-#pragma unroll
-        for (int j = 0; j < NR; ++j) sum += Dv(i, j);
-#pragma unroll
-        for (int k = 0; k < NC; ++k) sum += Dv(i, NR + 2 * k);
-        ch[i] = sum;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    const double D = tp_h_dot<NR, NC>(ch) + R;
-    const double z = y - tp_h_dot<NR, NC>(e.b);
-    const double inv = mtg_rcp(D);
-    const double zi = z * inv;
-    kap[0] = fma(z, zi, kap[0]);
-    kap[1] *= D;
-    kap[2] = fmin(kap[2], D);
-#pragma unroll
-    for (int i = 0; i < J; ++i) e.b[i] = fma(ch[i], zi, e.b[i]);
-    if (b_lds) {
-#pragma unroll
-        for (int i = 0; i < J; ++i) b_lds[i * 64] = e.b[i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        const double ki = ch[i] * inv;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) Dv(i, j) = fma(-ki, ch[j], Dv(i, j));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    double g[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        double col[J];
-#pragma unroll
-        for (int i = 0; i < J; ++i) col[i] = e.A[i][j];
-        tp_apply_F<NR, NC>(T, col);
-        const double gj = tp_h_dot<NR, NC>(col);
-        const double gs = gj * inv;
-#pragma unroll
-        for (int i = 0; i < J; ++i) e.A[i][j] = fma(-ch[i], gs, col[i]);
-        g[j] = gj;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    prefetch();  // the next sample's loads go out here: their registers live through the Jm stage only
-    __builtin_amdgcn_sched_barrier(0);
-    // eta += g z / D ; Jm += g g^T / D in LDS, in three batches of reads, multiply-adds and writes: the
-    // round trip to LDS is paid three times per step instead of once per row
-    {
-        double v[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) v[j] = acc[j * 64];
-#pragma unroll
-        for (int j = 0; j < J; ++j) acc[j * 64] = fma(g[j], zi, v[j]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int SPLIT = (2 * J + 2) / 3;  // rows [0, SPLIT) and [SPLIT, J) hold about half the triangle each
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        constexpr int R0[2] = {0, SPLIT}, R1[2] = {SPLIT, J};
-        double v[J * (J + 1) / 2];
-#pragma unroll
-        for (int i = R0[h]; i < R1[h]; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) v[i * (i + 1) / 2 + j] = acc[(J + i * (i + 1) / 2 + j) * 64];
-#pragma unroll
-        for (int i = R0[h]; i < R1[h]; ++i) {
-            const double gi = g[i] * inv;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) acc[(J + i * (i + 1) / 2 + j) * 64] = fma(gi, g[j], v[i * (i + 1) / 2 + j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-
-// tp_transition term by term (same reason: the ten table look-ups and polynomials of a step would
-// otherwise be interleaved, each with its own temporaries).
-// fast = false (some d_k * max dx beyond the exact range of the table reduction): the phase increment
-// is first reduced modulo 2 pi with a two-part constant -- n = rint(x / 2 pi) is exact in a double, the
-// fused multiply-adds form x - n C1 - n C2 with one rounding each, and the rounding error of the
-// product d * dx itself is carried along -- and the remainder, |r| <= pi, goes through the same table
-// path.  (OCML's sincos / exp here cost a second copy of the loop and ~150 bytes of scratch per lane.)
 // Transition of one step, in two phases so that the LDS latency of the table look-ups is paid once per
 // step, not once per term (one wave per SIMD: nothing else hides it): phase 1 reduces every argument and
 // issues every look-up, phase 2 runs the polynomials.
@@ -317,90 +189,6 @@ __device__ __forceinline__ void tpb_chunk_range(int64_t N, int C, uint32_t c, ui
 __device__ __forceinline__ double2 tpb_sample(const double2 *base, uint32_t byte_off)
 {
     return *(const double2 *)((const char *)base + byte_off);
-}
-
-template <int NR, int NC>
-__device__ __forceinline__ void tpb_compose_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
-                                                 double icpt, int64_t lc, const MtgMathTablesT<(NC > 0)> *tab, bool fast, double *acc,
-                                                 const double *pc_sh, double *elems, double *parts, int64_t ev, int C)
-{
-    constexpr int J = NR + 2 * NC;
-    constexpr int NACC = J + J * (J + 1) / 2;
-    const int lane = threadIdx.x;
-    const double2 *yv = a.yv + lc * a.N, *dxt = a.dxt + lc * a.t_stride;
-    uint32_t lo, hi;
-    tpb_chunk_range(a.N, C, blockIdx.x * 64u + threadIdx.x, lo, hi);
-    TpElem<J> e;
-    tp_identity<J>(e);
-    tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k * 64 + lane] = 0.0;
-    double *const b_lds = NC == 0 ? acc + NACC * 64 + lane : nullptr;
-    if (b_lds) {
-#pragma unroll
-        for (int i = 0; i < J; ++i) b_lds[i * 64] = 0.0;
-    }
-    const uint32_t last = ((uint32_t)a.N - 1u) * 16u, end = hi * 16u;
-    uint32_t off = lo * 16u;
-    double2 dn = tpb_sample(dxt, off < last ? off : last), yn = tpb_sample(yv, off < last ? off : last);
-    double kap[3] = {0.0, 1.0, INFINITY};
-    int kexp = 0;
-    for (; off < end; off += 16u) {
-        // residual as (y - intercept) - slope t: one scalar operand per instruction (y - fma(slope, t,
-        // intercept) needs two, and the copy of the second becomes a loop-invariant VGPR pair)
-        const double dx = dn.x, r = fma(-slope, dn.y, yn.x - icpt), R = yn.y + jitter;
-        TpTrans<NR, NC> T;
-        tpb_transition<NR, NC>(M, dx, T, tab, fast);
-        __builtin_amdgcn_sched_barrier(0);
-        tpb_compose_step<NR, NC, J>(M, T, r, R, e, e.C, acc + lane, b_lds, kap, [&]() {
-            const uint32_t nn = off + 16u < last ? off + 16u : last;
-            dn = tpb_sample(dxt, nn); yn = tpb_sample(yv, nn);
-        });
-        kexp += __builtin_amdgcn_frexp_exp(kap[1]);
-        kap[1] = __builtin_amdgcn_frexp_mant(kap[1]);
-    }
-    {
-        double *part = parts + (ev * C + (int64_t)(blockIdx.x * 64u + threadIdx.x)) * 4;
-        part[0] = kap[0];
-        part[1] = log(kap[1]) + (double)kexp * 0.69314718055994530942;
-        part[2] = kap[2];
-    }
-    // the free entry of P_inf comes back from LDS: kept in registers across the loop it is ten VGPRs
-    // (computed from the model, it cannot live in SGPRs)
-    TpModel<NR, NC> M2 = M;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) M2.pc[k] = pc_sh[k];
-    tp_add_pinf<NR, NC, J>(M2, e.C);
-    if (b_lds) {
-#pragma unroll
-        for (int i = 0; i < J; ++i) e.b[i] = b_lds[i * 64];
-    }
-    tpb_store_full<J>(e, acc + lane, elems + (ev * C + (int64_t)(blockIdx.x * 64u + threadIdx.x)) * MTG_TPB_ELEM(J));
-}
-
-// grid (C / 64, evaluations of this structure), 64 lanes: lane = chunk
-template <int NR, int NC>
-__global__ void __launch_bounds__(64, 1) mtg_tpb_compose_kernel(MtgSolveArgs a, double *elems, double *parts, int C)
-{
-    constexpr int J = NR + 2 * NC;
-    constexpr int NACC = J + J * (J + 1) / 2;
-    __shared__ double acc[64 * (NACC + (NC == 0 ? J : 0))];  // eta, Jm (+ b: tpb_compose_step)
-    __shared__ double pc_sh[NC > 0 ? NC : 1];
-    __shared__ MtgMathTablesT<(NC > 0)> tab;
-    const int64_t ev = tpb_evaluation(a, blockIdx.y);
-    if (ev < 0) return;
-    TpModel<NR, NC> M;
-    double jitter, slope, icpt;
-    int64_t lc;
-    bool fast;
-    if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;  // the finish kernel reports it
-    mtg_fill_tables(&tab, threadIdx.x, 64);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < NC; ++k) pc_sh[k] = M.pc[k];
-    }
-    __syncthreads();
-    tpb_compose_body<NR, NC>(a, M, jitter, slope, icpt, lc, &tab, fast, acc, pc_sh, elems, parts, ev, C);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,21 +452,23 @@ __device__ __forceinline__ void tpb_filter_body(const MtgSolveArgs &a, const TpM
     part[2] = dmin;
 }
 
+// grid (ceil(C / 256), evaluations), 256 lanes: lane = chunk; four waves share one set of tables
 template <int NR, int NC>
-__global__ void __launch_bounds__(64, 1) mtg_tpb_filter_kernel(MtgSolveArgs a, const double *states, double *parts, int C)
+__global__ void __launch_bounds__(256, 1) mtg_tpb_filter_kernel(MtgSolveArgs a, const double *states, double *parts, int C)
 {
     constexpr int J = NR + 2 * NC;
     __shared__ MtgMathTablesT<(NC > 0)> tab;
     const int64_t ev = tpb_evaluation(a, blockIdx.y);
     if (ev < 0) return;
-    mtg_fill_tables(&tab, threadIdx.x, 64);
+    mtg_fill_tables(&tab, threadIdx.x, 256);
     __syncthreads();
     TpModel<NR, NC> M;
     double jitter, slope, icpt;
     int64_t lc;
     bool fast;
     if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;
-    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= (uint32_t)C) return;
     uint32_t lo, hi;
     tpb_chunk_range(a.N, C, c, lo, hi);
     const double *st = states + (ev * C + c) * MTG_TPB_STATE(J);
@@ -706,10 +496,7 @@ static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t
     const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C);
     double *ws = a.tp_ws;
     const dim3 grid((unsigned)(C / 64), (unsigned)nevals);
-    if (a.tp_direct >= 7)  // diagnostic: the single-wave composition kernel
-        hipLaunchKernelGGL((mtg_tpb_compose_kernel<NR, NC>), grid, dim3(64), 0, s, a, ws + plan.elem_off[0], ws + plan.part_off, C);
-    else
-        hipLaunchKernelGGL((mtg_tpb_compose2_kernel<NR, NC>), grid, dim3(128), 0, s, a, ws + plan.elem_off[0], ws + plan.part_off, C);
+    hipLaunchKernelGGL((mtg_tpb_compose2_kernel<NR, NC>), grid, dim3(128), 0, s, a, ws + plan.elem_off[0], ws + plan.part_off, C);
     mtg_launch_tpb_scan(J, a, plan, nevals, NR, NC, a.tp_direct, s);
     MtgSolveArgs f = a;
     if (a.tp_direct) {
@@ -719,7 +506,7 @@ static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t
         f.list = redo_list;
         f.count_ptr = redo_count;
     }
-    hipLaunchKernelGGL((mtg_tpb_filter_kernel<NR, NC>), grid, dim3(64), 0, s, f, ws + plan.state_off[0],
-                       ws + plan.part_off, C);
+    hipLaunchKernelGGL((mtg_tpb_filter_kernel<NR, NC>), dim3((unsigned)((C + 255) / 256), (unsigned)nevals), dim3(256), 0, s, f,
+                       ws + plan.state_off[0], ws + plan.part_off, C);
     mtg_launch_tpb_finish(f, ws + plan.part_off, ws + plan.head_off, C, nevals, s);
 }

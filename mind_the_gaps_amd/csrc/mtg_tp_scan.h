@@ -88,8 +88,8 @@ __device__ __forceinline__ void wsync()
 
 template <int J> struct Lds {  // one lane group's region
     static constexpr int M = J * J;
-    double A1[M], C1[M], J1[M], b1[J], eta1[J];   // running element (reduce) / state in (C1, b1) (down)
-    double A2[M], C2[M], J2[M], b2[J], eta2[J];   // the next element
+    double A1[M], eta1[J], b1[J], C1[M], J1[M];   // running element (reduce) / state (b1 | C1, contiguous) (down)
+    double A2[M], b2[J], eta2[J], C2[M], J2[M];   // the next element, in the order of the global layout
     double T1[M], T2[M], T3[M];
     double v1[J], v2[J], v3[J];
     double piv[2 * J];
@@ -332,14 +332,27 @@ __device__ __forceinline__ void gcopy(double *dst, const double *src, int n, int
     for (int i = l16; i < n; i += MTG_TPB_GROUP) dst[i] = src[i];
 }
 
-template <int J> __device__ __forceinline__ void load_second(Lds<J> &L, const double *e, int l16)
+// The next element travels global memory -> registers (issued before the current combination, whose
+// arithmetic hides the latency) -> LDS (after it): MTG_TPB_ELEM(J) / 16 doubles per lane.
+template <int J> struct Pre { double v[(MTG_TPB_ELEM(J) + MTG_TPB_GROUP - 1) / MTG_TPB_GROUP]; };
+template <int J> __device__ __forceinline__ void fetch(Pre<J> &p, const double *e, int l16)
 {
-    constexpr int M = J * J;
-    gcopy(L.A2, e, M, l16);
-    gcopy(L.b2, e + M, J, l16);
-    gcopy(L.eta2, e + M + J, J, l16);
-    gcopy(L.C2, e + M + 2 * J, M, l16);
-    gcopy(L.J2, e + 2 * M + 2 * J, M, l16);
+    constexpr int N = MTG_TPB_ELEM(J), Q = (N + MTG_TPB_GROUP - 1) / MTG_TPB_GROUP;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = l16 + MTG_TPB_GROUP * q;
+        p.v[q] = e[i < N ? i : N - 1];
+    }
+}
+template <int J> __device__ __forceinline__ void put_second(Lds<J> &L, const Pre<J> &p, int l16)
+{
+    constexpr int N = MTG_TPB_ELEM(J), Q = (N + MTG_TPB_GROUP - 1) / MTG_TPB_GROUP;
+    double *dst = L.A2;  // A2 | b2 | eta2 | C2 | J2 are contiguous and in the global order
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = l16 + MTG_TPB_GROUP * q;
+        if (i < N) dst[i] = p.v[q];
+    }
 }
 template <int J> __device__ __forceinline__ void load_first(Lds<J> &L, const double *e, int l16)
 {

@@ -40,9 +40,12 @@ __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_GROUP */, 1) mtg_tpb_
     const int r = l16 < J ? l16 : J - 1;
     const double *e = in + (ev * n_in + (int64_t)k * MTG_TPB_GROUP) * MTG_TPB_ELEM(J);
     tpg::load_first<J>(L, e, l16);
+    tpg::Pre<J> pre;
+    tpg::fetch<J>(pre, e + MTG_TPB_ELEM(J), l16);
 #pragma unroll 1
     for (int i = 1; i < MTG_TPB_GROUP; ++i) {
-        tpg::load_second<J>(L, e + (int64_t)i * MTG_TPB_ELEM(J), l16);
+        tpg::put_second<J>(L, pre, l16);
+        if (i + 1 < MTG_TPB_GROUP) tpg::fetch<J>(pre, e + (int64_t)(i + 1) * MTG_TPB_ELEM(J), l16);
         tpg::wsync();
         tpg::combine<J>(L, r);
     }
@@ -70,9 +73,7 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, con
     const int l16 = threadIdx.x & 15;
     const int r = l16 < J ? l16 : J - 1;
     if (up) {
-        const double *s = up + (ev * gpe + k) * MTG_TPB_STATE(J);
-        tpg::gcopy(L.b1, s, J, l16);
-        tpg::gcopy(L.C1, s + J, M, l16);
+        tpg::gcopy(L.b1, up + (ev * gpe + k) * MTG_TPB_STATE(J), J + M, l16);  // b1 | C1 are contiguous
     } else {
         const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
         if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) return;
@@ -112,19 +113,19 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, con
     }
     tpg::wsync();
     const int64_t first = ev * n + (int64_t)k * gsize;
+    tpg::Pre<J> pre;
+    tpg::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l16);
 #pragma unroll 1
     for (int i = 0; i < gsize; ++i) {
-        double *s = states + (first + i) * MTG_TPB_STATE(J);
-        tpg::gcopy(s, L.b1, J, l16);
-        tpg::gcopy(s + J, L.C1, M, l16);
+        tpg::gcopy(states + (first + i) * MTG_TPB_STATE(J), L.b1, J + M, l16);
+        if (!CORR && i + 1 == gsize) break;
+        tpg::put_second<J>(L, pre, l16);
+        if (i + 1 < gsize) tpg::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l16);
+        tpg::wsync();
         if (CORR) {
-            tpg::load_second<J>(L, elems + (first + i) * MTG_TPB_ELEM(J), l16);
-            tpg::wsync();
             const double corr = i + 1 < gsize ? tpg::apply<J, true, true>(L, r) : tpg::apply<J, true, false>(L, r);
             if (l16 == 0) parts[(first + i) * 4 + 3] = corr;
-        } else if (i + 1 < gsize) {
-            tpg::load_second<J>(L, elems + (first + i) * MTG_TPB_ELEM(J), l16);
-            tpg::wsync();
+        } else {
             tpg::apply<J>(L, r);
         }
     }
