@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -284,18 +285,25 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
+    sa.tp_gsize = 0;
     sa.tp_direct = ctx->tp_direct;
     bool small_ok = small;
     if (small && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
             if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
         const int C = mtg_tp_big_chunks(ctx->N, B);
-        const size_t need = (size_t)mtg_tp_big_plan(Jmodel, B, C).total * sizeof(double);
+        int g = mtg_tp_big_gsize(B, C);
+        if (const char *env = getenv("MTG_TP_GSIZE")) {  // measurements only
+            const int v = atoi(env);
+            if (v == 4 || v == 8 || v == 16) g = v;
+        }
+        const size_t need = (size_t)mtg_tp_big_plan(Jmodel, B, C, g).total * sizeof(double);
         if (B > 65535 || need > ((size_t)16 << 30)) small_ok = false;  // grid / workspace limits: the serial sweep
         if (small_ok) {
             HIP_TRY(ctx, ctx->tp_ws.reserve(need));
             sa.tp_ws = ctx->tp_ws.as<double>();
             sa.tp_chunks = C;
+            sa.tp_gsize = g;
         }
     }
     const bool wide = B <= 256 && ctx->N >= 4096;  // four waves per evaluation
@@ -730,6 +738,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.has_mean = mean_params != nullptr || jitter != nullptr;
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
+    sa.tp_gsize = 0;
     sa.tp_direct = 0;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));

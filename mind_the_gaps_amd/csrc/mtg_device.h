@@ -89,6 +89,7 @@ struct MtgSolveArgs {
     // mtg_tp_big_plan(J, B, tp_chunks) and the number of chunks per evaluation; NULL / 0 otherwise
     double *tp_ws;
     int tp_chunks;
+    int tp_gsize;   // elements per scan group (mtg_tp_big_gsize)
     int tp_direct;  // likelihood without the filter pass (mtg_tp_big.h)
 };
 

@@ -493,7 +493,7 @@ static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t
     constexpr int J = NR + 2 * NC;
     if (nevals <= 0 || !a.tp_ws) return;
     const int C = a.tp_chunks;
-    const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C);
+    const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C, a.tp_gsize);
     double *ws = a.tp_ws;
     const dim3 grid((unsigned)(C / 64), (unsigned)nevals);
     hipLaunchKernelGGL((mtg_tpb_compose2_kernel<NR, NC>), grid, dim3(128), 0, s, a, ws + plan.elem_off[0], ws + plan.part_off, C);

@@ -9,14 +9,14 @@
 // product costs each lane J (J + J/2) issue slots and ~60 VGPRs; four groups share a wave.
 //
 // Structure of the scan (per evaluation, C chunk elements e_0 .. e_{C-1} in global memory):
-//   up-sweep    mtg_tpb_reduce_kernel: groups of 16 consecutive elements are composed into one
-//               (15 sequential combinations per lane group), level after level while more than 16
+//   up-sweep    mtg_tpb_reduce_kernel: groups of g (mtg_tp_big_gsize) consecutive elements are composed into
+//               one (g - 1 sequential combinations per lane group), level after level while more than g
 //               elements remain;
 //   down-sweep  mtg_tpb_down_kernel: from the state after sample 0 the start state of every top-level
 //               element by sequential application, then level by level down to the chunks: the
-//               start state of element 16 k + i follows from that of group k by applying i elements.
-// Work: ~C combinations + ~C applications per evaluation (a Hillis-Steele scan needs C log2 C
-// combinations); depth: 15 combinations + 16 + 15 applications per level.
+//               start state of element g k + i follows from that of group k by applying i elements.
+// Work: ~C g/(g-1) combinations + as many applications per evaluation (a Hillis-Steele scan needs
+// C log2 C combinations); depth: g - 1 combinations + g - 1 applications per level.
 //
 // Global layouts (full matrices, so that loading is a plain copy):
 //   element: A[J][J] | b[J] | eta[J] | C[J][J] | Jm[J][J]     MTG_TPB_ELEM(J) doubles
@@ -26,31 +26,33 @@
 
 #define MTG_TPB_ELEM(J) (3 * (J) * (J) + 2 * (J))
 #define MTG_TPB_STATE(J) ((J) * (J) + (J))
-#define MTG_TPB_GROUP 16   /* lanes per lane group = elements per scan group */
-#define MTG_TPB_MAX_LEVELS 4
+#define MTG_TPB_LANES 16    /* lanes per lane group */
+#define MTG_TPB_MAX_LEVELS 8
 
 // Workspace of the big-J path, in doubles from a.tp_ws: element and state arrays per scan level,
 // per-chunk partial sums of the final filter pass, per-evaluation head (sample 0).
 struct MtgTpBigPlan {
     int C;                         // chunks per evaluation (a power of two >= 64)
+    int g;                         // elements per scan group (4, 8 or 16)
     int nlev;                      // scan levels; level 0 = the chunks
     int n[MTG_TPB_MAX_LEVELS];     // elements per evaluation at each level
     int64_t elem_off[MTG_TPB_MAX_LEVELS], state_off[MTG_TPB_MAX_LEVELS];
     int64_t part_off, head_off, redo_off, total;
 };
 
-static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C)
+static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C, int g)
 {
     MtgTpBigPlan p;
     p.C = C;
+    p.g = g;
     p.nlev = 0;
     int64_t off = 0;
-    for (int n = C;; n /= MTG_TPB_GROUP) {
+    for (int n = C;; n /= g) {
         p.n[p.nlev] = n;
         p.elem_off[p.nlev] = off; off += B * n * MTG_TPB_ELEM(J);
         p.state_off[p.nlev] = off; off += B * n * MTG_TPB_STATE(J);
         ++p.nlev;
-        if (n <= MTG_TPB_GROUP || p.nlev == MTG_TPB_MAX_LEVELS) break;
+        if (n <= g || p.nlev == MTG_TPB_MAX_LEVELS) break;
     }
     p.part_off = off; off += B * C * 4;
     p.head_off = off; off += B * 4;
@@ -68,6 +70,14 @@ static inline int mtg_tp_big_chunks(int64_t N, int64_t B)
     int C = 64;
     while (C < 4096 && (int64_t)C * B < 65536 && (int64_t)C * 2 * 24 <= N) C *= 2;
     return C;
+}
+
+// elements per scan group.  The scan is a chain of dependent J x J operations per group: few, long
+// chains (16) do the least work, many short ones over more levels (4) finish soonest while the GPU is
+// not full -- measured on configs[4]: 1.46 -> 1.05 ms at 32 evaluations, no gain at 256.
+static inline int mtg_tp_big_gsize(int64_t B, int C)
+{
+    return B * C >= 65536 ? 16 : 4;
 }
 
 // corr != 0: the level-0 down-sweep also leaves every chunk's likelihood correction in parts[..][3]
@@ -329,28 +339,28 @@ template <int J, bool CORR = false, bool UPDATE = true> __device__ __forceinline
 // copy n doubles global <-> LDS by the 16 lanes of a group
 __device__ __forceinline__ void gcopy(double *dst, const double *src, int n, int l16)
 {
-    for (int i = l16; i < n; i += MTG_TPB_GROUP) dst[i] = src[i];
+    for (int i = l16; i < n; i += MTG_TPB_LANES) dst[i] = src[i];
 }
 
 // The next element travels global memory -> registers (issued before the current combination, whose
 // arithmetic hides the latency) -> LDS (after it): MTG_TPB_ELEM(J) / 16 doubles per lane.
-template <int J> struct Pre { double v[(MTG_TPB_ELEM(J) + MTG_TPB_GROUP - 1) / MTG_TPB_GROUP]; };
+template <int J> struct Pre { double v[(MTG_TPB_ELEM(J) + MTG_TPB_LANES - 1) / MTG_TPB_LANES]; };
 template <int J> __device__ __forceinline__ void fetch(Pre<J> &p, const double *e, int l16)
 {
-    constexpr int N = MTG_TPB_ELEM(J), Q = (N + MTG_TPB_GROUP - 1) / MTG_TPB_GROUP;
+    constexpr int N = MTG_TPB_ELEM(J), Q = (N + MTG_TPB_LANES - 1) / MTG_TPB_LANES;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int i = l16 + MTG_TPB_GROUP * q;
+        const int i = l16 + MTG_TPB_LANES * q;
         p.v[q] = e[i < N ? i : N - 1];
     }
 }
 template <int J> __device__ __forceinline__ void put_second(Lds<J> &L, const Pre<J> &p, int l16)
 {
-    constexpr int N = MTG_TPB_ELEM(J), Q = (N + MTG_TPB_GROUP - 1) / MTG_TPB_GROUP;
+    constexpr int N = MTG_TPB_ELEM(J), Q = (N + MTG_TPB_LANES - 1) / MTG_TPB_LANES;
     double *dst = L.A2;  // A2 | b2 | eta2 | C2 | J2 are contiguous and in the global order
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int i = l16 + MTG_TPB_GROUP * q;
+        const int i = l16 + MTG_TPB_LANES * q;
         if (i < N) dst[i] = p.v[q];
     }
 }

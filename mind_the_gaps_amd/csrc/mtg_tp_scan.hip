@@ -24,13 +24,13 @@ __device__ __forceinline__ bool tpb_group(const MtgSolveArgs &a, int groups_per_
     return true;
 }
 
-// out[ev][k] = in[ev][16 k] o in[ev][16 k + 1] o ... o in[ev][16 k + 15]
+// out[ev][k] = in[ev][g k] o in[ev][g k + 1] o ... o in[ev][g k + g - 1],  
 template <int J>
-__global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_GROUP */, 1) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
-                                                                                           double *out, int n_in)
+__global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_LANES */, 1) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
+                                                                                           double *out, int n_in, int g)
 {
     __shared__ tpg::Lds<J> lds[GROUPS];
-    const int gpe = n_in / MTG_TPB_GROUP;
+    const int gpe = n_in / g;
     int64_t ev;
     int k;
     if (!tpb_group(a, gpe, ev, k)) return;
@@ -38,14 +38,14 @@ __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_GROUP */, 1) mtg_tpb_
     tpg::Lds<J> &L = lds[threadIdx.x >> 4];
     const int l16 = threadIdx.x & 15;
     const int r = l16 < J ? l16 : J - 1;
-    const double *e = in + (ev * n_in + (int64_t)k * MTG_TPB_GROUP) * MTG_TPB_ELEM(J);
+    const double *e = in + (ev * n_in + (int64_t)k * g) * MTG_TPB_ELEM(J);
     tpg::load_first<J>(L, e, l16);
     tpg::Pre<J> pre;
     tpg::fetch<J>(pre, e + MTG_TPB_ELEM(J), l16);
 #pragma unroll 1
-    for (int i = 1; i < MTG_TPB_GROUP; ++i) {
+    for (int i = 1; i < g; ++i) {
         tpg::put_second<J>(L, pre, l16);
-        if (i + 1 < MTG_TPB_GROUP) tpg::fetch<J>(pre, e + (int64_t)(i + 1) * MTG_TPB_ELEM(J), l16);
+        if (i + 1 < g) tpg::fetch<J>(pre, e + (int64_t)(i + 1) * MTG_TPB_ELEM(J), l16);
         tpg::wsync();
         tpg::combine<J>(L, r);
     }
@@ -215,8 +215,8 @@ void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, i
     double *ws = a.tp_ws;
     auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
     for (int l = 0; l + 1 < p.nlev; ++l)
-        hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
-                           ws + p.elem_off[l], ws + p.elem_off[l + 1], p.n[l]);
+        hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
+                           ws + p.elem_off[l], ws + p.elem_off[l + 1], p.n[l], p.g);
     const int top = p.nlev - 1;
     // (the chunk count is at least 64, so the top level is never level 0)
     hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top],
@@ -224,13 +224,13 @@ void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, i
                        nr, nc);
     for (int l = top - 1; l >= 0; --l) {
         if (l == 0 && corr)
-            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, true>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
+            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, true>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
                                ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
-                               ws + p.part_off, p.n[l], MTG_TPB_GROUP, nr, nc);
+                               ws + p.part_off, p.n[l], p.g, nr, nc);
         else
-            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(p.n[l] / MTG_TPB_GROUP), dim3(64), 0, s, a,
+            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
                                ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
-                               (double *)nullptr, p.n[l], MTG_TPB_GROUP, nr, nc);
+                               (double *)nullptr, p.n[l], p.g, nr, nc);
     }
 }
 
