@@ -4,21 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (per GPU, weak scaling): BASELINE.json configs[3], the Protassov
-posterior-predictive sweep -- L = 2000 simulated light curves sharing one
-irregular sampling (N = 10 000), W = 256 walkers each, alternative model
-DRW + SHO + Lorentzian (celerite rank J = 6, P = 8 free parameters).  One step =
+Workload: BASELINE.json configs[3], the Protassov posterior-predictive sweep -- L = 2000
+simulated light curves sharing one irregular sampling (N = 10 000), W = 256 walkers each,
+alternative model DRW + SHO + Lorentzian (celerite rank J = 6, P = 8 free parameters).  One step =
 one full-ensemble sweep = L x W = 512 000 log-probability evaluations through
-mtg_loglike_batch_device (prior + coefficients + fused Cholesky/solve), with
-t, y, sigma^2 and theta already resident in HBM.  No collective is needed on
-the data path (independent light curves); ranks only agree on the timing.
+mtg_loglike_batch_device (prior + coefficients + fused Cholesky/solve), with t, y, sigma^2 and theta
+already resident in HBM.
+
+Scaling (--scaling, default "strong" for --gpus N > 1, SURVEY.md 8(d) Config 4): the 2000 light
+curves are cut into contiguous blocks, one per rank (distributed.shard_lightcurves); every rank
+sweeps its own block -- no collective on the data path -- and each step ends with the only exchange
+the path has: the all-gather of the per-light-curve maxima of lnP (RCCL over xGMI), inside the timed
+region.  "weak" gives every rank its own 2000 light curves instead.
 
 The JSON line also carries
-  roofline     : algorithmic bytes (24 N + 8 P + 12 per evaluation, SURVEY.md
-                 section 8(d)) / mean duration of the dominant kernel
-                 (mtg_solve_kernel<1,2>), HIP events on the launch stream;
-  cpu_baseline : oracle/celerite_ref.c (a plain-C port of celerite's algorithm)
-                 on the host cores of this box, bounded sample (rank 0, N=1 only).
+  roofline        : algorithmic bytes (24 N + 8 P + 12 per evaluation) / mean
+                    duration of the dominant kernel (mtg_solve_kernel<1,2>), HIP events on the launch
+                    stream; the binding resource is FP64 vector issue (bound: "fp64_valu");
+  end_to_end      : the same sweep through the host-pointer entry point (H2D theta, kernels, D2H);
+  strong_shard_8  : one GPU on the share it gets of the 2000 light curves at 8 GPUs (250);
+  cpu_baseline    : oracle/celerite_ref.c (a plain-C port of celerite's algorithm, fused one-sweep
+                    variant, built -O3 -march=native on this host) single thread and on all usable
+                    cores, bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -32,6 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+# FP64 operations per sample and lane of mtg_solve_kernel<1,2> (93 fma + 53 mul/add in kernel v7;
+# scripts/loop_stats.py counts the compiled loop)
+FLOP_PER_SAMPLE = 2 * 93 + 53
 
 
 def parse():
@@ -44,6 +54,9 @@ def parse():
     ap.add_argument("--walkers", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="time box of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
+                    help="default: strong when --gpus > 1 (the light curves are split over the ranks)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     return ap.parse_args()
 
 
@@ -64,23 +77,38 @@ def usable_cores():
 
 
 def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds, bounds=None, gpu_out=None, gpu_status=None):
-    """oracle/celerite_ref.c on all usable host cores, same inputs, bounded sample.  The values it
-    produces are the first evaluations of the timed GPU batch, so they double as a parity check of
-    that batch (outside both timed regions): the worst relative difference goes into the line."""
+    """oracle/celerite_ref.c on the host cores, same inputs, bounded sample: the fused one-sweep
+    recurrence built -O3 -march=native for this host, on all usable cores (`value`)
+    and on one thread.  The values it produces are the first evaluations of the timed GPU batch, so they
+    double as a parity check of that batch (outside both timed regions): the worst relative difference
+    goes into the line."""
+    import tempfile
     from oracle import celerite as oracle_c
     cores = usable_cores()
     oracle_c.lib()
+    native = oracle_c.build_native(tempfile.mkdtemp(prefix="mtg_bench_"))
+    build = "gcc -O3 -march=native" if native is not None else "gcc -O2 (prebuilt; no compiler on this host)"
     L = y.shape[0]
+
+    def run(idx, nthreads):
+        lc = (idx // (theta.shape[0] // L)).astype(np.int32) % L
+        full = np.hstack([theta[idx], y_mean[lc][:, None]])
+        t0 = time.perf_counter()
+        ref, rstatus = oracle_c.logprob_batch(t, y, dy, kinds, full, bounds=bounds, lc_index=lc, add_prior=bounds is not None,
+                                              nthreads=nthreads, fused=True, handle=native)
+        return ref, rstatus, time.perf_counter() - t0
+
+    # one thread: a quarter of the time box
+    done1, spent1 = 0, 0.0
+    while spent1 < 0.25 * seconds:
+        _, _, dt = run((np.arange(16) + done1) % theta.shape[0], 1)
+        done1 += 16; spent1 += dt
     chunk = max(cores * 32, 64)
     done, spent, worst, compared = 0, 0.0, 0.0, 0
     while True:
         idx = (np.arange(chunk) + done) % theta.shape[0]
-        lc = (idx // (theta.shape[0] // L)).astype(np.int32) % L
-        full = np.hstack([theta[idx], y_mean[lc][:, None]])
-        t0 = time.perf_counter()
-        ref, rstatus = oracle_c.logprob_batch(t, y, dy, kinds, full, bounds=bounds, lc_index=lc,
-                                              add_prior=bounds is not None, nthreads=cores)
-        spent += time.perf_counter() - t0
+        ref, rstatus, dt = run(idx, cores)
+        spent += dt
         if gpu_out is not None and done + chunk <= theta.shape[0]:
             ok = (rstatus == 0) & (gpu_status[idx] == 0)
             if not np.array_equal(rstatus == 0, gpu_status[idx] == 0):
@@ -88,13 +116,16 @@ def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds, bounds=None, gpu_out=N
             worst = max(worst, float(np.max(np.abs(gpu_out[idx][ok] - ref[ok]) / np.abs(ref[ok]))))
             compared += int(ok.sum())
         done += chunk
-        if spent >= seconds:
+        if spent >= 0.75 * seconds:
             break
     if compared and worst > 1e-8:
         raise SystemExit("bench: GPU batch differs from the CPU port by %.3e relative (> 1e-8)" % worst)
     return {"value": done / spent, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "%d evaluations of the same workload (N=%d, J=6) in %.1f s, OpenMP over %d "
-                      "threads, oracle/celerite_ref.c (gcc -O2)" % (done, len(t), spent, cores),
+            "single_thread": done1 / spent1,
+            "sample": "%d evaluations of the same workload (N=%d) in %.1f s on %d threads + %d in %.1f s on one, "
+                      "oracle/celerite_ref.c, fused one-sweep recurrence, %s; the port carries the Lorentzian's null "
+                      "real term as celerite would (J = 6), the GPU sweep drops it (J = 5 of arithmetic)"
+                      % (done, len(t), spent, cores, done1, spent1, build),
             "max_rel_diff_vs_gpu": worst if compared else None, "compared": compared}
 
 
@@ -173,17 +204,32 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
 
     from mind_the_gaps_amd import synthetic as synth
+    from mind_the_gaps_amd.distributed import block_bounds
     from mind_the_gaps_amd.engine import Engine
 
-    N, L, W = args.n, args.lightcurves, args.walkers
+    N, L_total, W = args.n, args.lightcurves, args.walkers
     kinds = synth.ALT_MODEL
     P = len(synth.truth(kinds))
+    # seed = 20250704 + config index.  strong: one set of light curves, rank r owns a
+    # contiguous block of it; weak: every rank owns its own set of L_total
+    if scaling == "strong":
+        t, y_all, dy_all = synth.make_lightcurves(N, L_total, seed=20250704 + 4)
+        theta_all = synth.draw_thetas(kinds, L_total * W, seed=20250704 + 40)
+        blocks = block_bounds(L_total, world)
+        l0, l1 = int(blocks[rank]), int(blocks[rank + 1])
+        y, dy, theta = y_all[l0:l1], dy_all[l0:l1], theta_all[l0 * W:l1 * W]
+        L_pad = int(np.max(np.diff(blocks)))
+        del y_all, dy_all, theta_all
+    else:
+        t, y, dy = synth.make_lightcurves(N, L_total, seed=20250704 + 4 + 1000 * rank)
+        theta = synth.draw_thetas(kinds, L_total * W, seed=20250704 + 40 + 1000 * rank)
+        L_pad = L_total
+    L = y.shape[0]
     B = L * W
-    # seed = 20250704 + config index; every rank owns different light curves
-    t, y, dy = synth.make_lightcurves(N, L, seed=20250704 + 4 + 1000 * rank)
-    theta = synth.draw_thetas(kinds, B, seed=20250704 + 40 + 1000 * rank)
+    B_job = (L_total if scaling == "strong" else world * L_total) * W   # evaluations of the whole job per step
     # every light curve keeps its own frozen mean, as GPModelling does (gpmodelling.py:83-87)
     full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
     y_mean = y.mean(axis=1)
@@ -196,11 +242,21 @@ def main():
     d_lc = torch.from_numpy(lc).to(dev)
     d_out = torch.empty(B, dtype=torch.float64, device=dev)
     d_status = torch.empty(B, dtype=torch.int32, device=dev)
+    # the exchange step of the sharded sweep: per-light-curve maxima of lnP, all-gathered
+    d_best = torch.full((L_pad,), -np.inf, dtype=torch.float64, device=dev)
+    gdev = "cpu" if oversubscribed else dev
+    d_gather = torch.empty(world * L_pad, dtype=torch.float64, device=gdev) if world > 1 else None
     stream = torch.cuda.current_stream(dev)
 
-    def step():
-        eng.loglike_device(B, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(),
+    def sweep(n_eval=B):
+        eng.loglike_device(n_eval, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(),
                            d_status.data_ptr(), add_prior=True, stream=stream.cuda_stream)
+
+    def step():
+        sweep()
+        if world > 1:
+            torch.amax(d_out.view(L, W), dim=1, out=d_best[:L])
+            dist.all_gather_into_tensor(d_gather, d_best.cpu() if oversubscribed else d_best)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -220,9 +276,14 @@ def main():
     prep_ms, solve_ms = eng.profile_read()
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversubscribed else dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if scaling == "strong":  # the gathered maxima are those of the whole set, in order, on every rank
+            got = d_gather.cpu().numpy().reshape(world, L_pad)
+            mine = d_out.cpu().numpy().reshape(L, W).max(axis=1)
+            if not np.array_equal(got[rank, :L], mine):
+                raise SystemExit("bench: gathered maxima differ from the local ones")
 
     # sanity: every evaluation finite or prior-rejected, and a spot check of the values
     status = d_status.cpu().numpy()
@@ -231,62 +292,103 @@ def main():
     if not np.all(np.isfinite(out[status == 0])) or n_ok < B // 2:
         raise SystemExit("bench: non-finite log-likelihoods in the timed batch")
 
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status
+        reps = max(3, min(args.steps, 10))
+        eng.loglike(theta, lc, add_prior=True)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.loglike(theta, lc, add_prior=True)
+        e2e = (time.perf_counter() - t1) / reps
+        extras["end_to_end"] = {"value": B / e2e, "unit": "evals/s", "ms_per_step": e2e * 1e3,
+                                "what": "mtg_loglike_batch: pageable host theta [B][P] + light-curve index up, kernels, "
+                                        "lnP + status down, every step (%d MB + %d MB over PCIe)"
+                                        % (theta.nbytes // 2**20 + lc.nbytes // 2**20, (B * 12) // 2**20)}
+        # (b) the share one GPU gets of the 2000 light curves at 8 GPUs: is a 1/8 batch still efficient?
+        L8 = max(1, L // 8)
+        B8 = L8 * W
+        for _ in range(3):
+            sweep(B8)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(4 * reps):
+            sweep(B8)
+        torch.cuda.synchronize(dev)
+        dt8 = (time.perf_counter() - t1) / (4 * reps)
+        extras["strong_shard_8"] = {"lightcurves": L8, "evals_per_step": B8, "ms_per_step": dt8 * 1e3,
+                                    "evals_per_s": B8 / dt8,
+                                    "per_gpu_factor": (B8 / dt8) / (B * args.steps / elapsed),
+                                    "what": "one MI355X sweeping 1/8 of the light curves (its share at 8 GPUs, ~1 wave per "
+                                            "SIMD); 8 x per_gpu_factor is the strong-scaling speed-up the kernels allow "
+                                            "before the all-gather of 2000 doubles"}
+
     if rank == 0:
         bytes_eval = 24 * N + 8 * P + 12
         solve_s = float(np.mean(solve_ms)) * 1e-3
         achieved = n_ok * bytes_eval / solve_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("N") == N and rec.get("B") == B:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (%s), not measured in this run" % rec.get("round", "round 1")
             except Exception:
                 traffic = None
         line = {
             "metric": "celerite log-likelihood evals/sec (N=1e4, J=6)",
-            "value": world * B * args.steps / elapsed,
+            "value": B_job * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[3] per GPU: Protassov PPP sweep, %d light curves x %d "
-                            "walkers = %d evals/step, alt model DRW+SHO+Lorentzian (J=6, P=%d), "
-                            "N=%d irregular samples" % (L, W, B, P, N),
-                "N": N, "J": 6, "P": P, "lightcurves_per_gpu": L, "walkers": W,
-                "evals_per_step_per_gpu": B, "sharding": "light curves across ranks, no data-path collective",
+                "workload": "BASELINE configs[3]: Protassov PPP sweep, %d light curves x %d walkers = %d evals/step%s, "
+                            "alt model DRW+SHO+Lorentzian (J=6, P=%d), N=%d irregular samples"
+                            % (L_total, W, L_total * W, " per GPU" if scaling == "weak" and world > 1 else "", P, N),
+                "N": N, "J": 6, "J_arith": 5, "P": P, "lightcurves": L_total if scaling == "strong" else world * L_total,
+                "lightcurves_per_gpu": L, "walkers": W, "evals_per_step": B_job, "evals_per_step_per_gpu": B,
+                "sharding": ("light curves split over the ranks (contiguous blocks), no data-path collective; each step "
+                             "ends with the all-gather of the per-light-curve maxima of lnP (%d doubles per rank)" % L_pad)
+                            if world > 1 else "one GPU",
             },
             "roofline": {
-                "bound": "hbm",
+                # nominal roofline of SURVEY.md 8(d): algorithmic bytes over HBM peak (achieved / peak / frac);
+                # what binds the kernel is FP64 vector issue (fp64_valu below, profiles/): 256 walkers share a
+                # light curve through L2 / MALL and the real HBM traffic is ~1 % of the algorithmic bytes
+                "bound": "fp64_valu",
                 "kernel": "mtg_solve_kernel<1,2>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "bytes_per_eval": bytes_eval,
                 "evals_per_launch": n_ok,
                 "kernel_ms": solve_s * 1e3,
                 "prepare_kernel_ms": float(np.mean(prep_ms)),
-                # the binding resource: FP64 vector issue (and, under it, board power).  93 FMA + 53
-                # mul/add per sample and lane in the J = 6 sweep of kernel v7 (scripts/loop_stats.py: 186
-                # fma, 96 mul, 10 add per two-step trip) against the 78.6 TFLOP/s FP64 vector peak
-                "fp64_valu": {"flop_per_sample": 2 * 93 + 53,
-                              "achieved_tflops": n_ok * N * (2 * 93 + 53) / solve_s / 1e12,
-                              "peak_tflops": 78.6},
+                "J_arith": 5,   # the Lorentzian's null real term (a = 0, c = 0) never enters D_n or z_n: not expanded
+                # FP64 vector work of the J = 6 sweep (scripts/loop_stats.py on the sweep loop) against the
+                # 78.6 TFLOP/s FP64 vector peak
+                "fp64_valu": {"flop_per_sample": FLOP_PER_SAMPLE,
+                              "achieved_tflops": n_ok * N * FLOP_PER_SAMPLE / solve_s / 1e12,
+                              "peak_tflops": 78.6,
+                              "frac": n_ok * N * FLOP_PER_SAMPLE / solve_s / 1e12 / 78.6},
             },
         }
+        line.update(extras)
         if oversubscribed:
             line["oversubscribed"] = "%d ranks on %d GPU(s): rehearsal of the multi-rank path, not a scaling number" % (world, ndev)
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds, bounds, out, status)
             try:
                 line["other_configs"] = single_lightcurve_configs()

@@ -144,10 +144,15 @@ MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const 
 MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index,
                               int add_prior, double *out, int32_t *status);
 /*
- * Same with DEVICE pointers, enqueued on `stream` (a hipStream_t passed as
- * void*; NULL = the context's own stream) without synchronising: inputs stay
- * resident in HBM, results are valid once the stream reaches this point.
+ * Same with DEVICE pointers, enqueued on `stream` (a hipStream_t passed as void*) without
+ * synchronising: inputs stay resident in HBM, results are valid once the stream reaches this point.
+ * NULL is what it is everywhere in HIP: the (legacy) default stream -- PyTorch's
+ * torch.cuda.current_stream().cuda_stream is 0 for its default stream, and work the caller has
+ * queued there (the producer of d_theta, the consumer of d_out) is ordered with the launch.
+ * MTG_STREAM_CONTEXT selects the context's own non-blocking stream (mtg_synchronize waits for it),
+ * which is NOT ordered against the default stream.
  */
+#define MTG_STREAM_CONTEXT ((void *)(intptr_t)-1)
 MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_theta,
                                      const int32_t *d_lc_index, int add_prior, double *d_out,
                                      int32_t *d_status, void *stream);

@@ -65,7 +65,7 @@ struct mtg_ctx {
     MtgModel model;
 
     // workspaces
-    DevBuf coef, lists, counts, tp_ws;
+    DevBuf coef, lists, counts, tp_ws, sig;
     int64_t cstride = 0;
     int nsig_ws = 1;  // signature lists the workspace was laid out for
     // staging for the host-pointer entry points
@@ -147,6 +147,7 @@ int reserve_workspace(mtg_ctx *ctx, int64_t B, int nslots, int nsig)
     HIP_TRY(ctx, ctx->lists.reserve((size_t)stride * (nsig > 1 ? nsig : 1) * 2 * sizeof(int)));
     ctx->nsig_ws = nsig > 1 ? nsig : 1;
     HIP_TRY(ctx, ctx->counts.reserve(64 * sizeof(int)));
+    HIP_TRY(ctx, ctx->sig.reserve((size_t)stride * sizeof(int32_t)));
     ctx->cstride = stride;
     return MTG_OK;
 }
@@ -185,7 +186,7 @@ MtgPrepArgs make_prep_args(mtg_ctx *ctx, int64_t B, const double *d_theta, int a
     pa.counts = ctx->counts.as<int>();
     pa.out = d_out;
     pa.status = d_status;
-    pa.sig = nullptr;
+    pa.sig = ctx->sig.as<int32_t>();  // structure of every evaluation: the rank-10 time-parallel path dispatches on it
     return pa;
 }
 
@@ -287,6 +288,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     sa.tp_chunks = 0;
     sa.tp_gsize = 0;
     sa.tp_direct = ctx->tp_direct;
+    sa.tp_nr0 = m.nr0; sa.tp_nc0 = m.nc0;
+    sa.sig = ctx->sig.as<int32_t>();
     bool small_ok = small;
     if (small && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
@@ -313,7 +316,11 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         if (!fused) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 64);
     }
     sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
-    if (fused) {  // every signature in one launch
+    if (small_ok && Jmodel > 6) {  // rank 10: every structure in one sequence of launches (mtg_tp_big.h)
+        sa.list = nullptr;
+        sa.count_ptr = nullptr;
+        mtg_launch_tp_big(sa, B, s);
+    } else if (fused) {  // every signature in one launch
         sa.list = ctx->lists.as<int>();
         sa.count_ptr = ctx->counts.as<int>();
         fused(sa, B, s);
@@ -415,7 +422,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
-                      &ctx->counts, &ctx->tp_ws, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
+                      &ctx->counts, &ctx->tp_ws, &ctx->sig, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
                       &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
                       &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_naccept,
                       &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,
@@ -605,7 +612,7 @@ MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_th
     if (B > INT32_MAX) return fail(ctx, MTG_E_ARG, "batch too large");
     rc = use_device(ctx);
     if (rc) return rc;
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = stream == MTG_STREAM_CONTEXT ? ctx->stream : (hipStream_t)stream;  // NULL: HIP's default stream
     return run_model_batch(ctx, B, d_theta, d_lc_index, add_prior, d_out, d_status, s);
 }
 
@@ -740,6 +747,8 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     sa.tp_chunks = 0;
     sa.tp_gsize = 0;
     sa.tp_direct = 0;
+    sa.tp_nr0 = jr; sa.tp_nc0 = jc;
+    sa.sig = nullptr;
     ctx->timed = true;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
     rc = sweep_launch(ctx, fn, sa, B, 0, s);

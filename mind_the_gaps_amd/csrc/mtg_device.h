@@ -91,6 +91,8 @@ struct MtgSolveArgs {
     int tp_chunks;
     int tp_gsize;   // elements per scan group (mtg_tp_big_gsize)
     int tp_direct;  // likelihood without the filter pass (mtg_tp_big.h)
+    int tp_nr0, tp_nc0;    // structure with no over-damped SHO term; evaluation ev has (tp_nr0 + 2 sig[ev], tp_nc0 - sig[ev])
+    const int32_t *sig;    // [B] over-damped SHO terms per evaluation (mtg_prepare_one), or NULL = 0
 };
 
 // doubles per filtering element (A | b | eta | C | Jm) of the time-parallel kernel

@@ -1,9 +1,9 @@
 // mtg_timeparallel.hip -- instantiations of the time-parallel kernel (mtg_timeparallel.h).
 // J <= 6: the filtering element lives in registers; compiled here.
-// J = 10 structures of a five-SHOTerm model (BASELINE configs[4]): one translation unit each
-// (mtg_timeparallel_big.hip, built six times), because a single instance takes a minute to
-// compile; their elements spill to scratch, which still beats 200 000 serial steps by ~10x.
+// J = 10 structures of a five-SHOTerm model (BASELINE configs[4]): their own path, mtg_tp_big.h
+// (mtg_tp_big_compose.hip, mtg_tp_big_filter.hip, mtg_tp_scan.hip).
 #include "mtg_timeparallel.h"
+#include "mtg_tp_scan.h"
 
 template <int NR, int NC, bool OK = (NR + NC > 0 && NR + 2 * NC <= 6)>
 struct MtgTpSel { static constexpr mtg_solve_launcher fn = mtg_launch_tp<NR, NC>; };
@@ -42,25 +42,11 @@ mtg_solve_launcher mtg_find_tp_fused_solver(int nr0, int nc0, int nsig, int lane
     return nullptr;
 }
 
-void mtg_launch_tp_big_0_5(const MtgSolveArgs &, int64_t, hipStream_t);
-void mtg_launch_tp_big_2_4(const MtgSolveArgs &, int64_t, hipStream_t);
-void mtg_launch_tp_big_4_3(const MtgSolveArgs &, int64_t, hipStream_t);
-void mtg_launch_tp_big_6_2(const MtgSolveArgs &, int64_t, hipStream_t);
-void mtg_launch_tp_big_8_1(const MtgSolveArgs &, int64_t, hipStream_t);
-void mtg_launch_tp_big_10_0(const MtgSolveArgs &, int64_t, hipStream_t);
-
 mtg_solve_launcher mtg_find_tp_solver(int nr, int nc)
 {
-    if (nr + 2 * nc == 10) {  // the signatures of five SHO terms
-        switch (nc) {
-        case 5: return mtg_launch_tp_big_0_5;
-        case 4: return mtg_launch_tp_big_2_4;
-        case 3: return mtg_launch_tp_big_4_3;
-        case 2: return mtg_launch_tp_big_6_2;
-        case 1: return mtg_launch_tp_big_8_1;
-        case 0: return mtg_launch_tp_big_10_0;
-        }
-    }
+    // the rank-10 structures of a five-SHO family: ONE launch sequence serves every structure of a model
+    // (mtg_tp_big.h); the caller passes the whole batch, not a structure's list
+    if (nr + 2 * nc == 10 && nr % 2 == 0 && nc >= 0 && nc <= 5) return mtg_launch_tp_big;
     if (nr < 0 || nc < 0 || nr > 6 || nc > 3) return nullptr;
     return mtg_tp_table[nr][nc];
 }

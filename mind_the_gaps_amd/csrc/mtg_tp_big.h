@@ -386,34 +386,29 @@ __device__ __forceinline__ void tpb2_filter(const MtgSolveArgs &a, const TpModel
     part[2] = kap[2];
 }
 
-// grid (C / 64, evaluations of this structure), 128 lanes: lane & 63 = chunk, lane >> 6 = role
+// One evaluation of structure <NR, NC> by this workgroup of 128 lanes: lane & 63 = chunk, lane >> 6 = role
 template <int NR, int NC>
-__global__ void __launch_bounds__(128, 1) mtg_tpb_compose2_kernel(MtgSolveArgs a, double *elems, double *parts, int C)
+__device__ __forceinline__ void tpb2_compose_eval(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
+                                                  TpbRing<NR + 2 * NC> &ring, const MtgMathTables *tab)
 {
     constexpr int J = NR + 2 * NC;
-    __shared__ TpbRing<J> ring;
-    __shared__ MtgMathTablesT<(NC > 0)> tab;
-    const int64_t ev = tpb_evaluation(a, blockIdx.y);
-    if (ev < 0) return;
     TpModel<NR, NC> M;
     double jitter, slope, icpt;
     int64_t lc;
     bool fast;
     if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;  // the finish kernel reports it
-    mtg_fill_tables(&tab, threadIdx.x, 128);
-    __syncthreads();
     const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
     uint32_t lo, hi;
     tpb_chunk_range(a.N, C, c, lo, hi);
     const uint32_t per = ((uint32_t)a.N - 1u + (uint32_t)C - 1u) / (uint32_t)C;
     double *slot = elems + (ev * C + c) * MTG_TPB_ELEM(J);
-    if (threadIdx.x < 64) tpb2_columns<NR, NC>(a, M, lc, &tab, fast, ring, slot, lo, hi, per);
+    if (threadIdx.x < 64) tpb2_columns<NR, NC>(a, M, lc, tab, fast, ring, slot, lo, hi, per);
     else tpb2_filter<NR, NC>(a, M, jitter, slope, icpt, lc, ring, slot, parts + (ev * C + c) * 4, lo, hi, per);
 }
 
 template <int NR, int NC>
 __device__ __forceinline__ void tpb_filter_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
-                                                double icpt, int64_t lc, const MtgMathTablesT<(NC > 0)> *tab, bool fast, const double *st,
+                                                double icpt, int64_t lc, const MtgMathTables *tab, bool fast, const double *st,
                                                 double *part, uint32_t lo, uint32_t hi)
 {
     constexpr int J = NR + 2 * NC;
@@ -452,16 +447,12 @@ __device__ __forceinline__ void tpb_filter_body(const MtgSolveArgs &a, const TpM
     part[2] = dmin;
 }
 
-// grid (ceil(C / 256), evaluations), 256 lanes: lane = chunk; four waves share one set of tables
+// One evaluation of structure <NR, NC> by a workgroup of 256 lanes (lane = chunk)
 template <int NR, int NC>
-__global__ void __launch_bounds__(256, 1) mtg_tpb_filter_kernel(MtgSolveArgs a, const double *states, double *parts, int C)
+__device__ __forceinline__ void tpb_filter_eval(const MtgSolveArgs &a, int64_t ev, const double *states, double *parts, int C,
+                                                const MtgMathTables *tab)
 {
     constexpr int J = NR + 2 * NC;
-    __shared__ MtgMathTablesT<(NC > 0)> tab;
-    const int64_t ev = tpb_evaluation(a, blockIdx.y);
-    if (ev < 0) return;
-    mtg_fill_tables(&tab, threadIdx.x, 256);
-    __syncthreads();
     TpModel<NR, NC> M;
     double jitter, slope, icpt;
     int64_t lc;
@@ -473,8 +464,43 @@ __global__ void __launch_bounds__(256, 1) mtg_tpb_filter_kernel(MtgSolveArgs a, 
     tpb_chunk_range(a.N, C, c, lo, hi);
     const double *st = states + (ev * C + c) * MTG_TPB_STATE(J);
     double *part = parts + (ev * C + c) * 4;
-    tpb_filter_body<NR, NC>(a, M, jitter, slope, icpt, lc, &tab, fast, st, part, lo, hi);
+    tpb_filter_body<NR, NC>(a, M, jitter, slope, icpt, lc, tab, fast, st, part, lo, hi);
 }
+
+// Every rank-10 structure of a model -- (nr0 + 2 k, nc0 - k), k = number of over-damped SHO terms of the
+// evaluation (a.sig) -- is one of (0,5) (2,4) (4,3) (6,2) (8,1) (10,0); one kernel holds all six and each
+// workgroup branches, uniformly, into the structure of its evaluation.  (Round 1 and the first version
+// of this path launched every kernel once per structure on its own stream: 6 x 10 launches per
+// half-step, most of them for empty lists whose workgroups still queued behind the busy ones.)
+template <template <int, int> class F, class... Args>
+__device__ __forceinline__ void tpb_dispatch(int nr, Args &&...args)
+{
+    switch (nr) {
+    case 0: F<0, 5>::run(args...); break;
+    case 2: F<2, 4>::run(args...); break;
+    case 4: F<4, 3>::run(args...); break;
+    case 6: F<6, 2>::run(args...); break;
+    case 8: F<8, 1>::run(args...); break;
+    case 10: F<10, 0>::run(args...); break;
+    default: break;
+    }
+}
+template <int NR, int NC> struct TpbComposeF {
+    static __device__ __forceinline__ void run(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
+                                               TpbRing<10> &ring, const MtgMathTables *tab)
+    {
+        tpb2_compose_eval<NR, NC>(a, ev, elems, parts, C, ring, tab);
+    }
+};
+template <int NR, int NC> struct TpbFilterF {
+    static __device__ __forceinline__ void run(const MtgSolveArgs &a, int64_t ev, const double *states, double *parts, int C,
+                                               const MtgMathTables *tab)
+    {
+        tpb_filter_eval<NR, NC>(a, ev, states, parts, C, tab);
+    }
+};
+
+__device__ __forceinline__ int tpb_nr(const MtgSolveArgs &a, int64_t ev) { return a.tp_nr0 + 2 * (a.sig ? a.sig[ev] : 0); }
 
 }  // namespace
 
@@ -483,30 +509,6 @@ void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const dou
                            hipStream_t stream);
 void mtg_launch_tpb_finish_direct(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
                                   int *redo_list, int *redo_count, hipStream_t stream);
-
-// a.tp_direct: the likelihood from the composition pass and the scan alone (see
-// mtg_tpb_finish_direct_kernel); the filter pass then runs for the evaluations on the redo list only --
-// as a rule none, and its workgroups leave at once.  Otherwise the filter pass runs for everybody.
-template <int NR, int NC>
-static void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
-{
-    constexpr int J = NR + 2 * NC;
-    if (nevals <= 0 || !a.tp_ws) return;
-    const int C = a.tp_chunks;
-    const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C, a.tp_gsize);
-    double *ws = a.tp_ws;
-    const dim3 grid((unsigned)(C / 64), (unsigned)nevals);
-    hipLaunchKernelGGL((mtg_tpb_compose2_kernel<NR, NC>), grid, dim3(128), 0, s, a, ws + plan.elem_off[0], ws + plan.part_off, C);
-    mtg_launch_tpb_scan(J, a, plan, nevals, NR, NC, a.tp_direct, s);
-    MtgSolveArgs f = a;
-    if (a.tp_direct) {
-        int *redo_list = (int *)(ws + plan.redo_off) + (int64_t)NR * (a.B + 16), *redo_count = redo_list + a.B;
-        (void)hipMemsetAsync(redo_count, 0, sizeof(int), s);
-        mtg_launch_tpb_finish_direct(a, ws + plan.part_off, ws + plan.head_off, C, nevals, redo_list, redo_count, s);
-        f.list = redo_list;
-        f.count_ptr = redo_count;
-    }
-    hipLaunchKernelGGL((mtg_tpb_filter_kernel<NR, NC>), dim3((unsigned)((C + 255) / 256), (unsigned)nevals), dim3(256), 0, s, f,
-                       ws + plan.state_off[0], ws + plan.part_off, C);
-    mtg_launch_tpb_finish(f, ws + plan.part_off, ws + plan.head_off, C, nevals, s);
-}
+// mtg_tp_big_compose.hip / mtg_tp_big_filter.hip: the two kernels that hold all six structures
+void mtg_launch_tpb_compose(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
+void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *parts, int C, int64_t nevals, hipStream_t stream);

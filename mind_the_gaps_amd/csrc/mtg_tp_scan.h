@@ -56,9 +56,8 @@ static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C, int g)
     }
     p.part_off = off; off += B * C * 4;
     p.head_off = off; off += B * 4;
-    // evaluations sent back through the filter pass (mtg_tp_big.h): one int list + counter per structure,
-    // indexed by its number of real terms (0 .. 10)
-    p.redo_off = off; off += 11 * ((B + 16) / 2 + 1);
+    // evaluations sent back through the filter pass (mtg_tp_big.h): int list + counter
+    p.redo_off = off; off += (B + 16) / 2 + 1;
     p.total = off;
     return p;
 }
@@ -81,8 +80,9 @@ static inline int mtg_tp_big_gsize(int64_t B, int C)
 }
 
 // corr != 0: the level-0 down-sweep also leaves every chunk's likelihood correction in parts[..][3]
-void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc, int corr,
-                         hipStream_t stream);
+void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int corr, hipStream_t stream);
+// the whole path (mtg_tp_big_filter.hip): every prepared evaluation of a rank-10 model, whatever its structure
+void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t stream);
 
 #ifdef __HIPCC__
 namespace tpg {

@@ -60,8 +60,7 @@ __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_LANES */, 1) mtg_tpb_
 // chunk likelihood correction of tpg::apply goes to parts[chunk][3].
 template <int J, bool CORR>
 __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, const double *elems, const double *up,
-                                                          double *states, double *head, double *parts, int n, int gsize,
-                                                          int nr, int nc)
+                                                          double *states, double *head, double *parts, int n, int gsize)
 {
     constexpr int M = J * J;
     __shared__ tpg::Lds<J> lds[GROUPS];
@@ -77,6 +76,7 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, con
     } else {
         const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
         if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) return;
+        const int nover = a.sig ? a.sig[ev] : 0, nr = a.tp_nr0 + 2 * nover, nc = a.tp_nc0 - nover;  // structure of this evaluation
         if (l16 == 0) {  // stationary covariance P_inf and P_inf h, rank by rank
             const double *cf = a.coef + ev;
             const int64_t cs = a.cstride;
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(64) mtg_tpb_finish_direct_kernel(MtgSolveArgs 
 }
 
 template <int J>
-void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int nr, int nc, int corr, hipStream_t s)
+void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int corr, hipStream_t s)
 {
     double *ws = a.tp_ws;
     auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
@@ -220,26 +220,24 @@ void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, i
     const int top = p.nlev - 1;
     // (the chunk count is at least 64, so the top level is never level 0)
     hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top],
-                       (const double *)nullptr, ws + p.state_off[top], ws + p.head_off, (double *)nullptr, p.n[top], p.n[top],
-                       nr, nc);
+                       (const double *)nullptr, ws + p.state_off[top], ws + p.head_off, (double *)nullptr, p.n[top], p.n[top]);
     for (int l = top - 1; l >= 0; --l) {
         if (l == 0 && corr)
             hipLaunchKernelGGL((mtg_tpb_down_kernel<J, true>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
                                ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
-                               ws + p.part_off, p.n[l], p.g, nr, nc);
+                               ws + p.part_off, p.n[l], p.g);
         else
             hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
                                ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
-                               (double *)nullptr, p.n[l], p.g, nr, nc);
+                               (double *)nullptr, p.n[l], p.g);
     }
 }
 
 }  // namespace
 
-void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int nr, int nc, int corr,
-                         hipStream_t stream)
+void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int corr, hipStream_t stream)
 {
-    if (J == 10) launch_scan<10>(a, plan, nevals, nr, nc, corr, stream);
+    if (J == 10) launch_scan<10>(a, plan, nevals, corr, stream);
 }
 
 void mtg_launch_tpb_finish_direct(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,

@@ -262,10 +262,13 @@ class Engine:
         return out, status
 
     def loglike_device(self, B, theta_ptr, lc_ptr, out_ptr, status_ptr, add_prior=True, stream=None):
-        """Raw device pointers (ints); asynchronous on ``stream`` (int, hipStream_t)."""
+        """Raw device pointers (ints); asynchronous on ``stream``: a hipStream_t as an int -- 0 is
+        HIP's default stream, e.g. ``torch.cuda.current_stream().cuda_stream`` -- or None for the
+        context's own stream (``synchronize()`` waits for that one)."""
+        handle = ctypes.c_void_p(-1 if stream is None else int(stream))   # MTG_STREAM_CONTEXT
         self._check(self._lib.mtg_loglike_batch_device(self._ctx, int(B), theta_ptr, lc_ptr,
                                                        int(bool(add_prior)), out_ptr, status_ptr,
-                                                       stream))
+                                                       handle))
 
     def loglike_coeffs(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=None,
                        mean_kind=MEAN_CONSTANT, mean_params=None, lc_index=None):

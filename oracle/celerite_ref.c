@@ -255,6 +255,92 @@ ORACLE_API double oracle_loglike_coeffs(long N, const double *t, const double *y
 }
 
 /*
+ * The same recurrences in ONE sweep with nothing materialised ("fused variant"):
+ * per sample the generators, the S update, D, W, the forward-solve step and the two running sums.  This is
+ * what a CPU implementation written for the likelihood alone would do, and the CPU baseline bench.py times
+ * (celerite itself stores U, V, phi, W, D and sweeps twice: oracle_loglike_coeffs above).  J is a
+ * compile-time constant in the specialised copies below so that the small loops unroll.
+ */
+static inline __attribute__((always_inline)) double
+fused_impl(const int J, long N, const double *t, const double *y, const double *dy, int jr, const double *ar,
+           const double *cr, int jc, const double *ac, const double *bc, const double *cc, const double *dc,
+           double jitter, int mean_kind, const double *mean_params, int *status)
+{
+    double S[32 * 32], f[32], W[32], U[32], V[32], ph[32];
+    *status = 0;
+    double asum = jitter;
+    for (int j = 0; j < jr; ++j) asum += ar[j];
+    for (int k = 0; k < jc; ++k) asum += ac[k];
+    memset(S, 0, sizeof(double) * (size_t)J * J);
+    memset(f, 0, sizeof(double) * J);
+    memset(W, 0, sizeof(double) * J);
+    double logdet = 0.0, dot = 0.0, zprev = 0.0, Dp = 1.0;
+    for (long n = 0; n < N; ++n) {
+        const double dx = n > 0 ? t[n] - t[n - 1] : 0.0;
+        for (int j = 0; j < jr; ++j) { U[j] = ar[j]; V[j] = 1.0; ph[j] = exp(-cr[j] * dx); }
+        for (int k = 0; k < jc; ++k) {
+            const double cd = cos(dc[k] * t[n]), sd = sin(dc[k] * t[n]), e = exp(-cc[k] * dx);
+            U[jr + 2 * k] = ac[k] * cd + bc[k] * sd;
+            U[jr + 2 * k + 1] = ac[k] * sd - bc[k] * cd;
+            V[jr + 2 * k] = cd;
+            V[jr + 2 * k + 1] = sd;
+            ph[jr + 2 * k] = ph[jr + 2 * k + 1] = e;
+        }
+        const double yerr = dy[n] + 1e-12; /* gpmodelling.py:54 */
+        const double mu = mean_kind == 1 ? mean_params[0] * t[n] + mean_params[1] : mean_params[0];
+        double Dn = yerr * yerr + asum, z = y[n] - mu;
+        if (n > 0) {
+            for (int i = 0; i < J; ++i) {
+                for (int j = 0; j <= i; ++j) {
+                    const double s = ph[i] * ph[j] * (S[i * J + j] + Dp * W[i] * W[j]);
+                    S[i * J + j] = s; S[j * J + i] = s;
+                }
+                f[i] = ph[i] * (f[i] + W[i] * zprev);
+                z -= U[i] * f[i];
+            }
+        }
+        for (int i = 0; i < J; ++i) {
+            double q = 0.0;
+            for (int j = 0; j < J; ++j) q += S[i * J + j] * U[j];
+            W[i] = V[i] - q;
+            Dn -= U[i] * q;
+        }
+        if (!(Dn > 0.0)) { *status = 2; return -INFINITY; }
+        for (int i = 0; i < J; ++i) W[i] /= Dn;
+        logdet += log(Dn);
+        dot += z * z / Dn;
+        zprev = z;
+        Dp = Dn;
+    }
+    const double ll = -0.5 * (dot + logdet + (double)N * log(2.0 * M_PI));
+    if (!isfinite(ll)) { *status = 3; return -INFINITY; }
+    return ll;
+}
+
+#define FUSED_ARGS N, t, y, dy, jr, ar, cr, jc, ac, bc, cc, dc, jitter, mean_kind, mean_params, status
+ORACLE_API double oracle_loglike_coeffs_fused(long N, const double *t, const double *y, const double *dy,
+                                              int jr, const double *ar, const double *cr, int jc,
+                                              const double *ac, const double *bc, const double *cc,
+                                              const double *dc, double jitter, int mean_kind,
+                                              const double *mean_params, int *status)
+{
+    const int J = jr + 2 * jc;
+    switch (J) {
+    case 1: return fused_impl(1, FUSED_ARGS);
+    case 2: return fused_impl(2, FUSED_ARGS);
+    case 3: return fused_impl(3, FUSED_ARGS);
+    case 4: return fused_impl(4, FUSED_ARGS);
+    case 5: return fused_impl(5, FUSED_ARGS);
+    case 6: return fused_impl(6, FUSED_ARGS);
+    case 8: return fused_impl(8, FUSED_ARGS);
+    case 10: return fused_impl(10, FUSED_ARGS);
+    default:
+        if (J > 32) { *status = -1; return NAN; }
+        return fused_impl(J, FUSED_ARGS);
+    }
+}
+
+/*
  * _log_probability / log_likelihood for a batch of parameter vectors.
  * params: [B][PF] FULL parameter vectors (kernel terms in `+` order, then the
  * mean parameters: 1 for constant, 2 = (slope, intercept) for linear).
@@ -263,12 +349,12 @@ ORACLE_API double oracle_loglike_coeffs(long N, const double *t, const double *y
  * first, likelihood skipped when the prior is -inf (status 1).
  * nthreads <= 1 runs serially.
  */
-ORACLE_API int oracle_logprob_batch(long N, long L, const double *t, const double *y,
-                                    const double *dy, int nterms, const int *kinds,
-                                    const double *extra, int mean_kind, int PF,
-                                    const double *bounds, long B, const double *params,
-                                    const int *lc_index, int add_prior, int nthreads,
-                                    double *out, int *status)
+static int logprob_batch_impl(int fused, long N, long L, const double *t, const double *y,
+                              const double *dy, int nterms, const int *kinds,
+                              const double *extra, int mean_kind, int PF,
+                              const double *bounds, long B, const double *params,
+                              const int *lc_index, int add_prior, int nthreads,
+                              double *out, int *status)
 {
     int bad = 0;
     (void)L;
@@ -299,13 +385,39 @@ ORACLE_API int oracle_logprob_batch(long N, long L, const double *t, const doubl
             }
             int nk = 0;
             for (int i = 0; i < nterms; ++i) nk += oracle_term_nparams(kinds[i]);
-            out[b] = oracle_loglike_coeffs(N, t, y + (size_t)lc * N, dy + (size_t)lc * N, jr, ar, cr,
-                                           jc, ac, bc, cc, dc, jitter, mean_kind, p + nk, work, &st);
+            out[b] = fused
+                         ? oracle_loglike_coeffs_fused(N, t, y + (size_t)lc * N, dy + (size_t)lc * N, jr, ar, cr, jc,
+                                                       ac, bc, cc, dc, jitter, mean_kind, p + nk, &st)
+                         : oracle_loglike_coeffs(N, t, y + (size_t)lc * N, dy + (size_t)lc * N, jr, ar, cr, jc,
+                                                 ac, bc, cc, dc, jitter, mean_kind, p + nk, work, &st);
             status[b] = st;
         }
         free(work);
     }
     return bad ? -1 : 0;
+}
+
+ORACLE_API int oracle_logprob_batch(long N, long L, const double *t, const double *y,
+                                    const double *dy, int nterms, const int *kinds,
+                                    const double *extra, int mean_kind, int PF,
+                                    const double *bounds, long B, const double *params,
+                                    const int *lc_index, int add_prior, int nthreads,
+                                    double *out, int *status)
+{
+    return logprob_batch_impl(0, N, L, t, y, dy, nterms, kinds, extra, mean_kind, PF, bounds, B, params, lc_index,
+                              add_prior, nthreads, out, status);
+}
+
+/* the same with the fused one-sweep recurrence (oracle_loglike_coeffs_fused) */
+ORACLE_API int oracle_logprob_batch_fused(long N, long L, const double *t, const double *y,
+                                          const double *dy, int nterms, const int *kinds,
+                                          const double *extra, int mean_kind, int PF,
+                                          const double *bounds, long B, const double *params,
+                                          const int *lc_index, int add_prior, int nthreads,
+                                          double *out, int *status)
+{
+    return logprob_batch_impl(1, N, L, t, y, dy, nterms, kinds, extra, mean_kind, PF, bounds, B, params, lc_index,
+                              add_prior, nthreads, out, status);
 }
 
 ORACLE_API int oracle_max_threads(void)

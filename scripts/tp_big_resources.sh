@@ -4,7 +4,7 @@
 cd /root/repo/mind_the_gaps_amd/csrc
 report() {
 python3 -c '
-import sys,re
+import sys,re,subprocess
 cur=None; rows={}
 for l in sys.stdin:
     m=re.search(r"Function Name: (\S+)",l)
@@ -12,17 +12,11 @@ for l in sys.stdin:
     for key in ("VGPRs","AGPRs","ScratchSize \[bytes/lane\]","Occupancy \[waves/SIMD\]","TotalSGPRs","LDS Size \[bytes/block\]"):
         m=re.search(key+r": (\d+)",l)
         if m and cur: rows[cur][key.split(" ")[0]]=int(m.group(1))
-import subprocess
 for k,v in rows.items():
     name=subprocess.run(["/usr/bin/c++filt",k],capture_output=True,text=True).stdout.strip().split("(MtgSolveArgs")[0].replace("void ","").replace("(anonymous namespace)::","")
     print("%-46s VGPR %3d AGPR %3d SGPR %3d scratch %5d B/lane  LDS %6d B  waves/SIMD %d"%(name,v.get("VGPRs",0),v.get("AGPRs",0),v.get("TotalSGPRs",0),v.get("ScratchSize",0),v.get("LDS",0),v.get("Occupancy",0)))
 '
 }
-STRUCTS=("0 5" "2 4" "4 3" "6 2" "8 1" "10 0")
-[ "$1" = scan ] && STRUCTS=()
-[ "$1" = one ] && STRUCTS=("0 5")
-for s in "${STRUCTS[@]}"; do
-  set -- $s
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DMTG_TP_BIG_NR=$1 -DMTG_TP_BIG_NC=$2 -c mtg_timeparallel_big.hip -o /tmp/tpb_res.o -Rpass-analysis=kernel-resource-usage 2>&1 | report
+for f in mtg_tp_big_compose mtg_tp_big_filter mtg_tp_scan; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f.hip -o /tmp/tpb_res.o -Rpass-analysis=kernel-resource-usage 2>&1 | report
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c mtg_tp_scan.hip -o /tmp/tpb_res.o -Rpass-analysis=kernel-resource-usage 2>&1 | report

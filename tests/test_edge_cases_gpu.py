@@ -211,3 +211,39 @@ def test_ensemble_guards(engine):
         engine.ensemble_run(1)
     with pytest.raises(EngineError, match="walkers"):
         engine.ensemble_init(np.zeros((1, 4098, 2)), seed=1)
+
+
+def test_default_stream_ordering(engine):
+    """mtg_loglike_batch_device(stream = 0) runs on HIP's default stream, which is PyTorch's default
+    stream: a slow producer of d_theta queued there before the launch and a consumer of d_out queued
+    after it need no synchronisation in between (a private non-blocking stream would read the stale
+    theta)."""
+    import torch
+    kinds = synth.ALT_MODEL
+    N, L, B = 2000, 2, 512
+    t, y, dy = synth.make_lightcurves(N, L, seed=77)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, free, bounds)
+    theta = synth.draw_thetas(kinds, B, seed=5)
+    lc = (np.arange(B) % L).astype(np.int32)
+    ref, rst = engine.loglike(theta, lc)
+    dev = torch.device("cuda", 0)
+    src = torch.from_numpy(theta).to(dev)
+    d_lc = torch.from_numpy(lc).to(dev)
+    d_theta = torch.zeros_like(src)
+    d_out = torch.zeros(B, dtype=torch.float64, device=dev)
+    d_st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    x = torch.randn(4096, 4096, device=dev)
+    torch.cuda.synchronize(dev)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0
+    for _ in range(30):                    # ~tens of ms of queued work in front of the producer
+        x = (x @ x) * 1e-4
+    d_theta.copy_(src)                     # producer, default stream
+    engine.loglike_device(B, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(), d_st.data_ptr(),
+                          add_prior=True, stream=torch.cuda.current_stream(dev).cuda_stream)
+    got = d_out.clone()                    # consumer, default stream
+    got_st = d_st.clone()
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(got_st.cpu().numpy(), rst)
+    assert np.array_equal(got.cpu().numpy(), ref)
