@@ -14,7 +14,7 @@ for sub in ("p1","p2"):
         for r in csv.DictReader(open(f)):
             k=re.sub(r"\(anonymous namespace\)::|void ","",r["Kernel_Name"]).split("(")[0]
             if "tpb" not in k or "finish" in k: continue
-            if "compose" in k or "filter" in k:
+            if False:
                 if "<0, 5>" not in k: continue
             acc.setdefault((k,r["Counter_Name"]),[]).append(float(r["Counter_Value"]))
         for (k,c),v in sorted(acc.items()): print(sub,"%-34s %-22s max %.4g mean %.4g n %d"%(k,c,max(v),sum(v)/len(v),len(v)))
