@@ -241,13 +241,26 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
  *   make_resident  != 0: the simulated set becomes the context's light curves (frozen mean
  *                  = each curve's average, yerr = dy + 1e-12), ready for
  *                  mtg_loglike_batch / mtg_ensemble_* with no host round trip
- * The PSD is celerite's Term.get_psd of the model; the inverse FFTs are one batched hipFFT
- * plan; random numbers are Philox4x32-10 keyed by `seed`.
+ *   psd_table      NULL: the PSD is celerite's Term.get_psd of the context's model at theta[S][P].  Otherwise
+ *                  (any callable PSD, simulator.py:149,272-280) the spectrum tabulated by the caller at the
+ *                  angular frequencies 2 pi k / (nfft sim_dt), k = 0 .. nfft/2: [psd_rows][nfft/2 + 1] with
+ *                  psd_rows = 1 (shared) or S; theta and the model are then not used
+ *   segments       NULL, or [S][seg_len]: the cut segments themselves as rates on the fine grid (what the
+ *                  reference hands to its E13 flux-PDF adjustment before down-sampling)
+ * The inverse FFTs are one batched hipFFT plan; random numbers are Philox4x32-10 keyed by `seed`.
  */
-MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint64_t seed, int64_t nfft,
-                              double sim_dt, double mean_rate, int64_t seg_len, const int32_t *win_lo,
-                              const int32_t *win_hi, int noise_kind, double sigma_noise, const double *exposures,
-                              double *clean, double *rates, double *dy, double *lc_means, int make_resident);
+MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, const double *psd_table, int64_t psd_rows,
+                              uint64_t seed, int64_t nfft, double sim_dt, double mean_rate, int64_t seg_len,
+                              const int32_t *win_lo, const int32_t *win_hi, int noise_kind, double sigma_noise,
+                              const double *exposures, double *clean, double *rates, double *dy, double *lc_means,
+                              double *segments, int make_resident);
+/*
+ * Test entry: the down-sampling step of mtg_simulate_tk95 alone on caller-provided fine-grid series
+ * [S][nfft] with the segment starting at fine sample `start`: rates[S][N] = plain average of
+ * series[s][start + lo .. start + hi) per epoch (simulator.py:340-367).
+ */
+MTG_API int mtg_tk95_observe_series(mtg_ctx *ctx, int64_t S, int64_t nfft, int64_t seg_len, int64_t start,
+                                    const double *series, const int32_t *win_lo, const int32_t *win_hi, double *rates);
 
 /*
  * celerite.GP.predict(y, return_var=True) at the training times, as

@@ -891,17 +891,20 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     return MTG_OK;
 }
 
-MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint64_t seed, int64_t nfft,
-                              double sim_dt, double mean_rate, int64_t seg_len, const int32_t *win_lo,
-                              const int32_t *win_hi, int noise_kind, double sigma_noise, const double *exposures,
-                              double *clean, double *rates, double *dy, double *lc_means, int make_resident)
+MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, const double *psd_table, int64_t psd_rows,
+                              uint64_t seed, int64_t nfft, double sim_dt, double mean_rate, int64_t seg_len,
+                              const int32_t *win_lo, const int32_t *win_hi, int noise_kind, double sigma_noise,
+                              const double *exposures, double *clean, double *rates, double *dy, double *lc_means,
+                              double *segments, int make_resident)
 {
-    int rc = check_ready(ctx, true);
+    int rc = check_ready(ctx, psd_table == nullptr);   // a tabulated spectrum needs no model
     if (rc) return rc;
+    if (psd_table && psd_rows != 1 && psd_rows != S)
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: psd_rows must be 1 or S");
     const int64_t N = ctx->N;
     if (nfft > ((int64_t)1 << 30)) return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: nfft above 2^30");
     if (S <= 0 || nfft < 4 || !(sim_dt > 0.0) || seg_len <= 0 || seg_len > nfft || !win_lo || !win_hi || !rates || !dy ||
-        (!theta && ctx->model.P > 0))
+        (!psd_table && !theta && ctx->model.P > 0))
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad arguments");
     if (noise_kind < 0 || noise_kind > 2 || (noise_kind == 2 && !exposures) || (noise_kind == 1 && !(sigma_noise >= 0.0)))
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad noise specification");
@@ -913,10 +916,12 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: make_resident needs a shared sampling");
     rc = use_device(ctx);
     if (rc) return rc;
-    const MtgModel &m = ctx->model;
+    MtgModel m0;
+    memset(&m0, 0, sizeof m0);
+    const MtgModel &m = psd_table ? m0 : ctx->model;
     const int P = m.P;
     MtgCoefLayout lay{m.nr_max, m.nc_max};
-    rc = reserve_workspace(ctx, S, lay.nslots(), 1);
+    rc = reserve_workspace(ctx, S, lay.nslots() > 4 ? lay.nslots() : 4, 1);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     const int64_t nk = nfft / 2 + 1;
@@ -924,14 +929,14 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
     int64_t chunk = (int64_t)(2.0e9 / (16.0 * (double)nfft));
     if (chunk < 1) chunk = 1;
     if (chunk > S) chunk = S;
-    DevBuf spec, series, d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means;
+    DevBuf spec, series, d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means, d_psd, d_seg;
     hipfftHandle plan = 0;
     bool have_plan = false;
     hipError_t e = hipSuccess;
     const char *what = "allocation";
     auto cleanup = [&]() {
         if (have_plan) (void)hipfftDestroy(plan);
-        DevBuf *bufs[] = {&spec, &series, &d_lo, &d_hi, &d_expo, &d_clean, &d_rates, &d_dy, &d_sig, &d_means};
+        DevBuf *bufs[] = {&spec, &series, &d_lo, &d_hi, &d_expo, &d_clean, &d_rates, &d_dy, &d_sig, &d_means, &d_psd, &d_seg};
         for (DevBuf *b : bufs) b->release();
     };
     HIP_TRY(ctx, ctx->theta.reserve((size_t)S * (P > 0 ? P : 1) * 8));
@@ -947,11 +952,14 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
     if (e == hipSuccess) e = d_dy.reserve((size_t)S * N * 8);
     if (e == hipSuccess) e = d_sig.reserve((size_t)S * 4);
     if (e == hipSuccess) e = d_means.reserve((size_t)S * 8);
+    if (e == hipSuccess && psd_table) e = d_psd.reserve((size_t)psd_rows * nk * 8);
+    if (e == hipSuccess && psd_table) e = hipMemcpyAsync(d_psd.p, psd_table, (size_t)psd_rows * nk * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && segments) e = d_seg.reserve((size_t)S * seg_len * 8);
     if (e == hipSuccess) e = hipMemcpyAsync(d_lo.p, win_lo, (size_t)N * 4, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, win_hi, (size_t)N * 4, hipMemcpyHostToDevice, s);
     if (e == hipSuccess && exposures) e = hipMemcpyAsync(d_expo.p, exposures, (size_t)N * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess && P > 0) e = hipMemcpyAsync(ctx->theta.p, theta, (size_t)S * P * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && !psd_table) {
         // theta -> celerite coefficients (no prior: the samples come from the posterior itself)
         MtgPrepArgs pa;
         pa.model = m; pa.theta = ctx->theta.as<double>(); pa.B = S; pa.add_prior = 0;
@@ -976,14 +984,18 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
         const int64_t sc = s0 + chunk <= S ? chunk : S - s0;
         what = "simulation kernels";
         mtg_launch_tk95_spectrum(sc, s0, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
-                                 d_sig.as<int32_t>(), seed, spec.as<double2>(), s);
+                                 d_sig.as<int32_t>(), psd_table ? d_psd.as<double>() : nullptr, psd_rows, seed,
+                                 spec.as<double2>(), s);
         if (hipfftExecZ2D(plan, (hipfftDoubleComplex *)spec.p, series.as<double>()) != HIPFFT_SUCCESS) {
             cleanup();
-            return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");
+            return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");  // (the resident set is untouched so far)
         }
         mtg_launch_tk95_observe(sc, s0, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
                                 d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
-                                seed, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+                                -1, seed, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+        if (segments)
+            mtg_launch_tk95_segment(sc, s0, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
+                                    d_seg.as<double>(), s);
         e = hipGetLastError();
     }
     DevBuf yv_tmp;
@@ -999,13 +1011,54 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, uint
         if (e == hipSuccess && lc_means) e = hipMemcpyAsync(lc_means, d_means.p, (size_t)S * 8, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess && clean) e = hipMemcpyAsync(clean, d_clean.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && segments) e = hipMemcpyAsync(segments, d_seg.p, (size_t)S * seg_len * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(rates, d_rates.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(dy, d_dy.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     cleanup();
     yv_tmp.release();
-    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95 (%s): %s", what, hipGetErrorString(e));
+    if (e != hipSuccess) {
+        // the resident set may have been freed or partly overwritten on the way: nothing is resident any more
+        if (make_resident) { ctx->N = 0; ctx->L = 0; }
+        return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95 (%s): %s", what, hipGetErrorString(e));
+    }
     if (make_resident) ctx->L = S;  // the simulated light curves replace the resident set (same sampling)
+    return MTG_OK;
+}
+
+MTG_API int mtg_tk95_observe_series(mtg_ctx *ctx, int64_t S, int64_t nfft, int64_t seg_len, int64_t start,
+                                    const double *series, const int32_t *win_lo, const int32_t *win_hi, double *rates)
+{
+    int rc = check_ready(ctx, false);
+    if (rc) return rc;
+    const int64_t N = ctx->N;
+    if (S <= 0 || nfft <= 0 || seg_len <= 0 || start < 0 || start + seg_len > nfft || !series || !win_lo || !win_hi || !rates)
+        return fail(ctx, MTG_E_ARG, "mtg_tk95_observe_series: bad arguments");
+    for (int64_t n = 0; n < N; ++n)
+        if (win_lo[n] < 0 || win_hi[n] < win_lo[n] || win_hi[n] > seg_len)
+            return fail(ctx, MTG_E_ARG, "mtg_tk95_observe_series: window %lld outside the segment", (long long)n);
+    rc = use_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    DevBuf d_series, d_lo, d_hi, d_rates, d_dy;
+    hipError_t e = d_series.reserve((size_t)S * nfft * 8);
+    if (e == hipSuccess) e = d_lo.reserve((size_t)N * 4);
+    if (e == hipSuccess) e = d_hi.reserve((size_t)N * 4);
+    if (e == hipSuccess) e = d_rates.reserve((size_t)S * N * 8);
+    if (e == hipSuccess) e = d_dy.reserve((size_t)S * N * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_series.p, series, (size_t)S * nfft * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lo.p, win_lo, (size_t)N * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, win_hi, (size_t)N * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        // scale = dt = 1, mean 0, no noise: the plain window average of the series
+        mtg_launch_tk95_observe(S, 0, N, nfft, seg_len, 1.0, 1.0, 0.0, d_series.as<double>(), d_lo.as<int32_t>(),
+                                d_hi.as<int32_t>(), 0, 0.0, nullptr, start, 0, nullptr, d_rates.as<double>(),
+                                d_dy.as<double>(), s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rates, d_rates.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(ctx, MTG_E_HIP, "mtg_tk95_observe_series: %s", hipGetErrorString(e));
     return MTG_OK;
 }
 

@@ -78,8 +78,8 @@ __device__ inline double mtg_psd(const double *cf, int64_t cs, const MtgCoefLayo
 // X[s][k], k = 0..nfft/2 (hipFFT Z2D input layout)
 __global__ void __launch_bounds__(256)
 mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
-                         MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, uint32_t seed_lo,
-                         uint32_t seed_hi, double2 *X)
+                         MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
+                         int64_t psd_rows, uint32_t seed_lo, uint32_t seed_hi, double2 *X)
 {
     const int64_t nk = nfft / 2 + 1;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,9 +88,15 @@ mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t nfft, double dt, const d
     double re = 0.0, im = 0.0;
     if (k > 0) {
         const int64_t sg = s0 + s;
-        const int nr = nr0 + 2 * sig[sg], nc = nc0 - sig[sg];
-        const double w = 6.28318530717958647692 * (double)k / ((double)nfft * dt);
-        const double amp = sqrt(0.5 * mtg_psd(coef + sg, cstride, lay, nr, nc, w));
+        double power;
+        if (psd_table) {  // any callable PSD, evaluated by the host at the angular frequencies 2 pi k / (nfft dt)
+            power = psd_table[(psd_rows > 1 ? sg : 0) * nk + k];
+        } else {
+            const int nr = nr0 + 2 * sig[sg], nc = nc0 - sig[sg];
+            const double w = 6.28318530717958647692 * (double)k / ((double)nfft * dt);
+            power = mtg_psd(coef + sg, cstride, lay, nr, nc, w);
+        }
+        const double amp = sqrt(0.5 * power);
         const Philox r = philox4x32_10((uint32_t)k, PURPOSE_SPECTRUM, (uint32_t)sg, (uint32_t)(k >> 32), seed_lo, seed_hi);
         normal2(r, &re, &im);
         re *= amp; im *= amp;
@@ -99,22 +105,44 @@ mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t nfft, double dt, const d
     X[i] = make_double2(re, im);
 }
 
-// Segment cut + bin average onto the observing pattern + noise.  One thread per (simulation, epoch).
-__global__ void __launch_bounds__(256)
-mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
-                        double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
-                        int noise_kind, double sigma_noise, const double *exposures, uint32_t seed_lo,
-                        uint32_t seed_hi, double *clean, double *rates, double *dy)
+// cut_random_segment (simulator.py:536-539): start ~ U(time[0], time[-1] - duration), first fine sample at
+// or after it; fixed_start >= 0 (tests) overrides the draw
+__device__ inline int64_t tk95_segment_start(int64_t sg, int64_t nfft, int64_t seg_len, int64_t fixed_start,
+                                             uint32_t seed_lo, uint32_t seed_hi)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S * N) return;
-    const int64_t s = i / N, n = i % N, sg = s0 + s;
-    // cut_random_segment: start ~ U(time[0], time[-1] - duration), first fine sample at or after it
+    if (fixed_start >= 0) return fixed_start;
     const Philox rs = philox4x32_10(0u, PURPOSE_SHIFT, (uint32_t)sg, 0u, seed_lo, seed_hi);
     const double span = (double)(nfft - 1) - (double)seg_len;  // in units of dt
     int64_t j0 = span > 0.0 ? (int64_t)ceil(u01(rs.c[0], rs.c[1]) * span) : 0;
     if (j0 > nfft - seg_len) j0 = nfft - seg_len;
     if (j0 < 0) j0 = 0;
+    return j0;
+}
+
+// The cut segment itself, as rates on the fine grid (the light curve the reference hands to its E13
+// amplitude adjustment before down-sampling): out[sg][j] = series[s][j0 + j] scale / dt + mean.
+__global__ void __launch_bounds__(256)
+mtg_tk95_segment_kernel(int64_t S, int64_t s0, int64_t nfft, int64_t seg_len, double dt, double scale, double mean_rate,
+                        const double *series, uint32_t seed_lo, uint32_t seed_hi, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * seg_len) return;
+    const int64_t s = i / seg_len, j = i % seg_len, sg = s0 + s;
+    const int64_t j0 = tk95_segment_start(sg, nfft, seg_len, -1, seed_lo, seed_hi);
+    out[sg * seg_len + j] = series[s * nfft + j0 + j] * scale / dt + mean_rate;
+}
+
+// Segment cut + bin average onto the observing pattern + noise.  One thread per (simulation, epoch).
+__global__ void __launch_bounds__(256)
+mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
+                        double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
+                        int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
+                        uint32_t seed_lo, uint32_t seed_hi, double *clean, double *rates, double *dy)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * N) return;
+    const int64_t s = i / N, n = i % N, sg = s0 + s;
+    const int64_t j0 = tk95_segment_start(sg, nfft, seg_len, fixed_start, seed_lo, seed_hi);
     const double *x = series + s * nfft + j0;
     const int lo = win_lo[n], hi = win_hi[n];
     double acc = 0.0;
@@ -206,21 +234,29 @@ void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const d
 }
 
 void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
-                              MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, uint64_t seed, double2 *X,
-                              hipStream_t st)
+                              MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
+                              int64_t psd_rows, uint64_t seed, double2 *X, hipStream_t st)
 {
     const int64_t n = S * (nfft / 2 + 1);
     hipLaunchKernelGGL(mtg_tk95_spectrum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, nfft, dt,
-                       coef, cstride, lay, nr0, nc0, sig, (uint32_t)seed, (uint32_t)(seed >> 32), X);
+                       coef, cstride, lay, nr0, nc0, sig, psd_table, psd_rows, (uint32_t)seed, (uint32_t)(seed >> 32), X);
+}
+
+void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t nfft, int64_t seg_len, double dt, double scale,
+                             double mean_rate, const double *series, uint64_t seed, double *out, hipStream_t st)
+{
+    const int64_t n = S * seg_len;
+    hipLaunchKernelGGL(mtg_tk95_segment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, nfft, seg_len,
+                       dt, scale, mean_rate, series, (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
 
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
-                             int noise_kind, double sigma_noise, const double *exposures, uint64_t seed, double *clean,
-                             double *rates, double *dy, hipStream_t st)
+                             int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
+                             uint64_t seed, double *clean, double *rates, double *dy, hipStream_t st)
 {
     const int64_t n = S * N;
     hipLaunchKernelGGL(mtg_tk95_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, N, nfft,
                        seg_len, dt, scale, mean_rate, series, win_lo, win_hi, noise_kind, sigma_noise, exposures,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), clean, rates, dy);
+                       fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), clean, rates, dy);
 }

@@ -30,7 +30,7 @@ EXPORTS = (
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
-    "mtg_apply_inverse", "mtg_set_tp_direct",
+    "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series",
 )
 
 
@@ -127,8 +127,10 @@ def load_library():
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_simulate_tk95.restype = c_int
-    lib.mtg_simulate_tk95.argtypes = [c_vp, c_i64, _dp, ctypes.c_uint64, c_i64, ctypes.c_double, ctypes.c_double,
-                                      c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, c_int]
+    lib.mtg_simulate_tk95.argtypes = [c_vp, c_i64, _dp, _dp, c_i64, ctypes.c_uint64, c_i64, ctypes.c_double, ctypes.c_double,
+                                      c_i64, _ip, _ip, c_int, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp, c_int]
+    lib.mtg_tk95_observe_series.restype = c_int
+    lib.mtg_tk95_observe_series.argtypes = [c_vp, c_i64, c_i64, c_i64, c_i64, _dp, _ip, _ip, _dp]
     lib.mtg_set_time_parallel.restype = c_int
     lib.mtg_set_time_parallel.argtypes = [c_vp, c_int]
     lib.mtg_set_tp_direct.restype = c_int
@@ -343,11 +345,21 @@ class Engine:
         return out
 
     def simulate_tk95(self, theta, seed, nfft, sim_dt, mean_rate, seg_len, win_lo, win_hi, noise_kind=0,
-                      sigma_noise=0.0, exposures=None, want_clean=False, make_resident=False):
-        """TK95 light curves for S posterior samples on the resident sampling ->
-        dict(rates[S][N], dy[S][N], means[S], clean[S][N] or None)."""
-        theta = np.atleast_2d(_f64(theta))
-        S = theta.shape[0]
+                      sigma_noise=0.0, exposures=None, want_clean=False, make_resident=False, psd_table=None,
+                      want_segments=False):
+        """TK95 light curves on the resident sampling for S posterior samples ``theta`` of the model, or --
+        ``psd_table`` [1 or S][nfft/2 + 1], ``theta`` = S -- for a spectrum tabulated by the caller ->
+        dict(rates[S][N], dy[S][N], means[S], clean[S][N] or None, segments[S][seg_len] or None)."""
+        table = None
+        if psd_table is not None:
+            table = np.atleast_2d(_f64(psd_table))
+            S = int(theta)
+            if table.shape[1] != int(nfft) // 2 + 1 or table.shape[0] not in (1, S):
+                raise ValueError("psd_table must be [1 or S][nfft / 2 + 1]")
+            theta = None
+        else:
+            theta = np.atleast_2d(_f64(theta))
+            S = theta.shape[0]
         lo = np.ascontiguousarray(win_lo, dtype=np.int32)
         hi = np.ascontiguousarray(win_hi, dtype=np.int32)
         if lo.shape != (self.N,) or hi.shape != (self.N,):
@@ -355,13 +367,25 @@ class Engine:
         expo = None if exposures is None else _f64(np.broadcast_to(exposures, (self.N,)))
         rates, dy, means = np.empty((S, self.N)), np.empty((S, self.N)), np.empty(S)
         clean = np.empty((S, self.N)) if want_clean else None
+        segments = np.empty((S, int(seg_len))) if want_segments else None
         self._check(self._lib.mtg_simulate_tk95(
-            self._ctx, S, _ptr(theta), int(seed) & 0xFFFFFFFFFFFFFFFF, int(nfft), float(sim_dt), float(mean_rate),
+            self._ctx, S, _ptr(theta), _ptr(table), 0 if table is None else table.shape[0],
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(nfft), float(sim_dt), float(mean_rate),
             int(seg_len), _iptr(lo), _iptr(hi), int(noise_kind), float(sigma_noise), _ptr(expo), _ptr(clean),
-            _ptr(rates), _ptr(dy), _ptr(means), int(bool(make_resident))))
+            _ptr(rates), _ptr(dy), _ptr(means), _ptr(segments), int(bool(make_resident))))
         if make_resident:
             self.L = S
-        return dict(rates=rates, dy=dy, means=means, clean=clean)
+        return dict(rates=rates, dy=dy, means=means, clean=clean, segments=segments)
+
+    def tk95_observe_series(self, series, seg_len, start, win_lo, win_hi):
+        """Test entry: window averages of fine-grid ``series`` [S][nfft] -> rates [S][N]."""
+        series = np.atleast_2d(_f64(series))
+        lo = np.ascontiguousarray(win_lo, dtype=np.int32)
+        hi = np.ascontiguousarray(win_hi, dtype=np.int32)
+        rates = np.empty((series.shape[0], self.N))
+        self._check(self._lib.mtg_tk95_observe_series(self._ctx, series.shape[0], series.shape[1], int(seg_len), int(start),
+                                                      _ptr(series), _iptr(lo), _iptr(hi), _ptr(rates)))
+        return rates
 
     def predict(self, theta, lc_index=None):
         """Conditional mean / variance at the training times -> (mu[B][N], var[B][N], status[B]);

@@ -128,6 +128,12 @@ class LogProbEvaluator:
     def n_lightcurves(self):
         return self.y.shape[0]
 
+    def _bind_lightcurves(self):
+        """The engine with these light curves resident and no particular model (tabulated spectra)."""
+        class _NoModel:
+            device_terms = ()
+        return self._bind(_NoModel())
+
     def _bind(self, model):
         eng = get_engine(self.device)
         offset = self.y_offset if self.y_offset is not None else getattr(model, "y_offset", None)

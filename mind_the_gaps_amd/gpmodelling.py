@@ -66,6 +66,7 @@ class GPModelling:
         self._loglikelihoods = None
         self._mcmc_samples = None
         self._quiet = quiet
+        self._fit_evaluations = 1   # fit() resets it: only the first evaluation of a fit may raise LinAlgError
         self._y = np.asarray(self._lightcurve.y, dtype=np.float64)
 
     def _build_mean_model(self, meanmodel: str = None):
@@ -135,7 +136,13 @@ class GPModelling:
         vals = np.where(status == _engine.ST_OK, -out, np.inf)
         f0 = float(vals[0])
         if not np.isfinite(f0):
+            if self._fit_evaluations == 0 and not self._quiet:
+                # the STARTING point itself cannot be factorised: returning a plateau would make
+                # L-BFGS-B "converge" there at once; the reference raises here (gpmodelling.py:192)
+                raise LinAlgError("failed to factorize or solve matrix")
+            self._fit_evaluations += 1
             return 1e300, np.zeros_like(x)
+        self._fit_evaluations += 1
         dx = pts[1:].diagonal() - x
         with np.errstate(divide="ignore", invalid="ignore"):
             grad = np.where((dx != 0.0) & np.isfinite(vals[1:]), (vals[1:] - f0) / dx, 0.0)
@@ -149,8 +156,13 @@ class GPModelling:
         bounds = self.gp.get_parameter_bounds()
         lower = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
         upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        self._fit_evaluations = 0
         solution = minimize(self._neg_log_like_and_grad, initial_params, args=(lower, upper), jac=True,
                             method="L-BFGS-B", bounds=bounds)
+        if not np.isfinite(solution.fun) or solution.fun >= 1e300:   # quiet mode: say so instead of "success"
+            solution.success = False
+            solution.message = "the covariance could not be factorised at the starting point"
+            warnings.warn("fit(): " + solution.message)
         return solution
 
     def derive_posteriors(self, initial_chain_params=None, fit: bool = True, converge: bool = True,
@@ -324,6 +336,20 @@ class GPModelling:
         if self._loglikelihoods is None:
             raise AttributeError(self._NOT_DERIVED)
         return np.max(self._loglikelihoods)
+
+    @property
+    def best_loglikelihood(self):
+        """Largest log-posterior over EVERYTHING the chains stored, burn-in included (new; the
+        reference has only ``max_loglikelihood``, the maximum over the burned-in, thinned chain).  It
+        is the estimator the lock-step refits of ``ppp.derive_posteriors_batch`` keep when they do not
+        store chains, so a likelihood-ratio test compares like with like (``ppp.protassov_test``)."""
+        if self._loglikelihoods is None:
+            raise AttributeError(self._NOT_DERIVED)
+        best = float(np.max(self._sampler.get_log_prob(flat=True)))
+        state = getattr(self._sampler, "state", None)
+        if isinstance(state, dict) and "best_log_prob" in state:   # the device sampler also saw the starting ensemble
+            best = max(best, float(np.max(state["best_log_prob"])))
+        return best
 
     @property
     def max_parameters(self):

@@ -378,7 +378,10 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         null, alt = observed(null_kernel), observed(alt_kernel)
-    t_obs = float(lrt_statistic(null.max_loglikelihood, alt.max_loglikelihood))
+    # one estimator on both sides of the test: the largest log-posterior over everything the chains
+    # visited (the refits below store no chains and keep exactly that; the maximum over the burned-in,
+    # thinned chain is systematically smaller, the more so the more parameters a model has)
+    t_obs = float(lrt_statistic(null.best_loglikelihood, alt.best_loglikelihood))
     samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
     sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
                     lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,

@@ -1,19 +1,31 @@
-"""Light-curve simulation from the GP's power spectrum, on the device.
+"""Light-curve simulation from a power spectrum, on the device.
 
-Mirror of the part of /root/reference/mind_the_gaps/simulator.py that the Protassov
-loop uses: ``Simulator(psd_model, times, exposures, mean, pdf, bkg_rate, bkg_rate_err,
-sigma_noise, aliasing_factor, extension_factor, epsilon, ...)`` (:143-275) with
-``generate_lightcurve`` (:397-420: Timmer & Koenig 1995 on a fine, extended regular grid,
-random segment cut, bin-averaging onto the observing pattern) and ``add_noise`` (:300-338;
-noise_models.py Gaussian :152-184 and Poisson :29-78).  The grid / window arithmetic
-below is the reference's; the spectrum draw, the inverse FFT (hipFFT), the cut, the
-downsampling and the noise run on the GPU for ALL requested simulations at once
-(``mtg_simulate_tk95``), and the result can stay resident as the light-curve set of the
-next fitting sweep.
+Mirror of /root/reference/mind_the_gaps/simulator.py as the Protassov loop uses it:
+``Simulator(psd_model, times, exposures, mean, pdf, bkg_rate, bkg_rate_err, sigma_noise,
+aliasing_factor, extension_factor, epsilon, ...)`` (:143-275) with ``generate_lightcurve``
+(:397-420: Timmer & Koenig 1995 on a fine, extended regular grid, random segment cut,
+bin-averaging onto the observing pattern) and ``add_noise`` (:300-338).  The grid arithmetic
+below is the reference's; the spectrum draw, the inverse FFT (hipFFT), the cut, the down-sampling
+and Gaussian / Poisson noise run on the GPU for ALL requested simulations at once
+(``mtg_simulate_tk95``), and the result can stay resident as the light-curve set of the next
+fitting sweep.
 
-Not provided: the Emmanoulopoulos et al. (2013) amplitude-adjustment loop for non-Gaussian
-flux PDFs (``pdf="lognormal" | "uniform"``) and the Kraft low-count posterior noise.
+What drives the spectrum:
+* a celerite ``Term`` (or its bound ``get_psd``, what gpmodelling.py:509 passes), or one of the
+  closed-form spectra of ``models.psd_models`` that has a celerite twin: the device evaluates
+  the PSD of every posterior sample from its coefficients;
+* ANY other callable ``psd(omega)`` (simulator.py:149,272-280; the reference's tests use astropy's
+  ``PowerLaw1D``): evaluated once on the host at the grid's angular frequencies and uploaded as a
+  table.
+
+Host-side parts (the reference's behaviour, at the reference's kind of speed -- they are not on the
+Protassov hot path): the Emmanoulopoulos et al. (2013) amplitude adjustment for
+``pdf="lognormal" | "uniform"`` (simulator.py:65-131), applied to the fine-grid segments the device
+returns, and the Kraft et al. (1991) treatment of low-count epochs with background
+(noise_models.py:81-150).
 """
+import warnings
+
 import numpy as np
 
 from .gp import DeviceModel, LogProbEvaluator
@@ -21,18 +33,57 @@ from .modeling import ConstantModel
 from .models.psd_models import PSDModel
 from .terms import Term
 
-__all__ = ["Simulator"]
+__all__ = ["Simulator", "kraft_median", "kraft_interval"]
+
+
+# -- Kraft, Burrows & Nousek (1991): posterior of the source counts s given N total and B background --
+def kraft_median(N, B):
+    """Median of f(s | N, B) = C e^-(s+B) (s+B)^N / N!, s >= 0 (reference stats.py:10-19 ``kraft_pdf``):
+    its distribution function is [P(N+1, s+B) - P(N+1, B)] / Q(N+1, B) with the regularised incomplete
+    gamma functions, so the median is one inverse incomplete gamma away."""
+    from scipy.special import gammainc, gammaincinv
+    p0 = gammainc(N + 1.0, B)                   # P(N + 1, B): the mass "below zero", cut away
+    return max(float(gammaincinv(N + 1.0, p0 + 0.5 * (1.0 - p0))) - B, 0.0)
+
+
+def kraft_interval(N, B, confidence_level=0.68):
+    """Shortest interval [s_lo, s_hi] holding ``confidence_level`` of that posterior: equal density at
+    both ends, or s_lo = 0 when the density there is already higher (what astropy's
+    ``poisson_conf_interval(..., "kraft-burrows-nousek")`` computes, noise_models.py:139-141)."""
+    from scipy.optimize import brentq
+    from scipy.special import gammainc, gammaincinv
+    N, B = float(N), float(B)
+    p0 = gammainc(N + 1.0, B)
+    norm = 1.0 - p0
+
+    def cdf(s):
+        return (gammainc(N + 1.0, s + B) - p0) / norm
+
+    def logpdf(s):
+        return -(s + B) + N * np.log(s + B) if s + B > 0 else (0.0 if N == 0 else -np.inf)
+
+    def upper_for(lo):   # the upper end that makes the interval hold the requested mass
+        target = cdf(lo) + confidence_level
+        return np.inf if target >= 1.0 else float(gammaincinv(N + 1.0, p0 + target * norm)) - B
+
+    mode = max(N - B, 0.0)
+    hi0 = upper_for(0.0)
+    if mode == 0.0 or logpdf(0.0) >= logpdf(hi0):
+        return 0.0, hi0
+    # lo in (0, mode): density at lo rises with lo, density at the matching upper end falls
+    lo_max = mode
+    while not np.isfinite(upper_for(lo_max)):
+        lo_max *= 0.999
+    lo = brentq(lambda s: logpdf(s) - logpdf(upper_for(s)), 0.0, lo_max, xtol=1e-10)
+    return lo, upper_for(lo)
 
 
 class Simulator:
-    """Simulate light curves with the PSD of a celerite kernel and Gaussian flux PDF."""
+    """Simulate light curves with a given power spectrum and flux probability density."""
 
     def __init__(self, psd_model, times, exposures, mean, pdf="gaussian", bkg_rate=None, bkg_rate_err=None,
                  sigma_noise=None, aliasing_factor=2, extension_factor=10, epsilon=1.001, max_iter=400,
-                 random_state=None, device=0):
-        """``psd_model``: the kernel ``Term`` whose PSD drives the simulation, its bound
-        ``get_psd`` (what gpmodelling.py:509 passes), or one of the closed-form spectra of
-        ``models.psd_models`` (what the tutorials pass).  Other arguments as in the reference."""
+                 random_state=None, device=0, kraft_counts=15):
         if extension_factor < 1:
             raise ValueError("Extension factor must be greater than 1")
         if epsilon < 1:
@@ -40,14 +91,13 @@ class Simulator:
         if np.any(np.asarray(exposures) == 0):
             raise ValueError("Some exposure times are 0!")
         times = np.asarray(times, dtype=np.float64)
-        self._exposures = np.full(len(times), exposures, dtype=np.float64) if np.isscalar(exposures) \
+        n = len(times)
+        self._exposures = np.full(n, exposures, dtype=np.float64) if np.isscalar(exposures) \
             else np.asarray(exposures, dtype=np.float64)
-        if pdf.lower() not in ["gaussian", "lognormal", "uniform"]:
+        if pdf.lower() not in ("gaussian", "lognormal", "uniform"):
             raise ValueError("%s not implemented! Currently implemented: Gaussian, Uniform or Lognormal" % pdf)
-        if pdf.lower() != "gaussian":
-            raise NotImplementedError("only the Gaussian flux PDF (Timmer & Koenig 1995) runs on the device; "
-                                      "the E13 amplitude adjustment is not provided")
         self.pdf = pdf
+        self.max_iter = int(max_iter)
         self.random_state = np.random.RandomState(random_state)
         self.sim_dt = float(np.min(self._exposures) / aliasing_factor)
         dt = np.diff(times)
@@ -66,79 +116,185 @@ class Simulator:
         self._times = times
         self.mean = float(mean)
         self.device = device
-        # noise model (simulator.py:255-262)
-        if sigma_noise is None:
-            if bkg_rate is None or np.all(np.asarray(bkg_rate) == 0):
-                self.noise_name, self._noise_kind, self.sigma_noise = "Poisson", 2, 0.0
-            else:
-                raise NotImplementedError("Kraft noise (background counts) is not provided on the device")
-        else:
+        # noise model (simulator.py:255-262): Gaussian if a sigma is given, else Poisson, with the
+        # Kraft treatment of faint epochs when there is a background
+        self._bkg_counts = np.zeros(n)
+        self._bkg_rate_err = np.zeros(n)
+        self.kraft_counts = kraft_counts
+        if sigma_noise is not None:
             self.noise_name, self._noise_kind, self.sigma_noise = "Gaussian", 1, float(sigma_noise)
-        # observing windows ("strategy", simulator.py:265-267) as index ranges of the cut segment,
-        # whose first fine sample sits sim_dt / 2 after the start of the first window
+        elif bkg_rate is None or np.all(np.asarray(bkg_rate) == 0):
+            self.noise_name, self._noise_kind, self.sigma_noise = "Poisson", 2, 0.0
+        else:
+            self.noise_name, self._noise_kind, self.sigma_noise = "Kraft", 3, 0.0
+            self._bkg_counts = np.broadcast_to(np.asarray(bkg_rate, dtype=np.float64), (n,)) * self._exposures
+            if bkg_rate_err is not None:
+                self._bkg_rate_err = np.broadcast_to(np.asarray(bkg_rate_err, dtype=np.float64), (n,)).copy()
+        # observing windows ("strategy", simulator.py:265-267) as index ranges of the cut segment, whose
+        # first fine sample sits sim_dt / 2 after the start of the first window
         half_bins = self._exposures / 2 * epsilon
         self.strategy = [(t - h, t + h) for t, h in zip(times, half_bins)]
         self.seg_len = min(int(np.ceil(self.sim_duration / self.sim_dt)), self.fftndatapoints)
-        seg_times = self.strategy[0][0] + self.sim_dt / 2 + np.arange(self.seg_len) * self.sim_dt
-        self.win_lo = np.searchsorted(seg_times, times - half_bins, side="left").astype(np.int32)
-        self.win_hi = np.searchsorted(seg_times, times + half_bins, side="left").astype(np.int32)
+        self.segment_times = self.strategy[0][0] + self.sim_dt / 2 + np.arange(self.seg_len) * self.sim_dt
+        self.win_lo, self.win_hi = self._windows(self.segment_times)
         self._evaluator = None
+
+    # -- down-sampling rule ------------------------------------------------------------
+    def _windows(self, grid_times):
+        """[lo, hi) index ranges of ``grid_times`` (ascending) that fall in every epoch's window
+        ``start <= time < end`` (simulator.py:358-362)."""
+        starts = np.array([s for s, _ in self.strategy])
+        ends = np.array([e for _, e in self.strategy])
+        lo = np.searchsorted(grid_times, starts, side="left")     # first time >= start
+        hi = np.searchsorted(grid_times, ends, side="left")       # first time >= end: excluded
+        return lo.astype(np.int32), hi.astype(np.int32)
+
+    def downsample(self, lc, countrate=None):
+        """Average of a regularly sampled light curve over every epoch's window (simulator.py:340-367).
+        ``lc``: an object with ``time`` and ``countrate`` (stingray's Lightcurve in the reference), or the
+        times with the rates as second argument.  Returns the list of mean rates."""
+        time = np.asarray(lc.time if countrate is None else lc, dtype=np.float64)
+        rate = np.asarray(lc.countrate if countrate is None else countrate, dtype=np.float64)
+        lo, hi = self._windows(time)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                        # an empty window is NaN, as numpy's mean of nothing
+            return [float(np.mean(rate[a:b])) for a, b in zip(lo, hi)]
 
     # -- PSD model ---------------------------------------------------------------------
     @property
     def psd_model(self):
-        return self._kernel.get_psd
+        return self._kernel.get_psd if self._kernel is not None else self._psd_callable
 
     @psd_model.setter
     def psd_model(self, new_psd_model):
+        if not callable(new_psd_model) and not isinstance(new_psd_model, Term):
+            raise ValueError("PSD model must be callable (e.g., a function or Astropy model).")
         kernel = getattr(new_psd_model, "__self__", new_psd_model)
         if isinstance(kernel, PSDModel):
-            # the reference's closed-form spectra (models/psd_models.py): every one that is the
-            # spectrum of a celerite term is simulated through that term's coefficients
-            kernel = kernel.to_term()
-        if not isinstance(kernel, Term):
-            raise ValueError("PSD model must be a Term, its get_psd method, or a models.psd_models spectrum "
-                             "with a celerite equivalent")
-        self._kernel = kernel
+            try:
+                # the reference's closed-form spectra (models/psd_models.py): every one that is the spectrum
+                # of a celerite term is simulated through that term's coefficients
+                kernel = kernel.to_term()
+            except (ValueError, NotImplementedError, AttributeError):
+                kernel = None
+        self._kernel = kernel if isinstance(kernel, Term) else None
+        self._psd_callable = None if self._kernel is not None else new_psd_model
 
-    def _engine_and_model(self):
+    def _engine(self):
         if self._evaluator is None:
             n = len(self._times)
             self._evaluator = LogProbEvaluator(self._times, np.zeros(n), np.ones(n), device=self.device)
+        if self._kernel is None:
+            return self._evaluator._bind_lightcurves(), None
         model = DeviceModel(self._kernel, ConstantModel(0.0), np.zeros(1, dtype=bool))
         if not model.device_terms:
             raise ValueError("the device simulator needs device-expandable terms")
         return self._evaluator._bind(model), model
 
+    def _psd_table(self):
+        """The callable PSD on the grid's angular frequencies; the k = 0 entry is not used (the mean of
+        the series is set afterwards) and a power law would be infinite there."""
+        omega = np.fft.rfftfreq(self.fftndatapoints, self.sim_dt) * 2 * np.pi
+        table = np.zeros(len(omega))
+        table[1:] = np.asarray(self._psd_callable(omega[1:]), dtype=np.float64)
+        if not np.all(np.isfinite(table)) or np.any(table < 0):
+            raise ValueError("the PSD model returned negative or non-finite power")
+        return table[None, :]
+
     # -- simulation --------------------------------------------------------------------
-    def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None):
-        """Light curves for S kernel parameter vectors ``thetas`` [S][P] (default: the
-        kernel's current one) in one device call ->
+    def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None, nsims=None):
+        """Light curves for S kernel parameter vectors ``thetas`` [S][P] (default: the kernel's
+        current one; with a callable PSD: ``nsims`` realisations of it) in one device call ->
         dict(rates[S][N], dy[S][N], means[S], clean[S][N] | None)."""
-        eng, model = self._engine_and_model()
-        if thetas is None:
-            thetas = model.full[model.free_index][None, :]
+        eng, model = self._engine()
         if seed is None:
             seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
-        out = eng.simulate_tk95(thetas, seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
-                                self.win_lo, self.win_hi, noise_kind=self._noise_kind if noise else 0,
-                                sigma_noise=self.sigma_noise, exposures=self._exposures, want_clean=want_clean,
-                                make_resident=make_resident)
-        if make_resident:
-            eng.bound_to = None        # the engine now holds the simulated set, not this evaluator's dummy data
+        host_side = self.pdf.lower() != "gaussian" or (noise and self._noise_kind == 3)
+        kw = dict(noise_kind=0 if (host_side or not noise) else self._noise_kind, sigma_noise=self.sigma_noise,
+                  exposures=self._exposures, want_clean=want_clean and not host_side,
+                  make_resident=make_resident and not host_side, want_segments=self.pdf.lower() != "gaussian")
+        try:
+            if model is None:
+                out = eng.simulate_tk95(int(nsims or 1), seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
+                                        self.win_lo, self.win_hi, psd_table=self._psd_table(), **kw)
+            else:
+                if thetas is None:
+                    thetas = np.tile(model.full[model.free_index][None, :], (int(nsims or 1), 1))
+                out = eng.simulate_tk95(thetas, seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
+                                        self.win_lo, self.win_hi, **kw)
+        finally:
+            if make_resident:
+                eng.bound_to = None    # whatever happened, the engine no longer holds this evaluator's dummy data
+        if host_side:
+            out = self._finish_on_host(out, noise, want_clean)
+            if make_resident:          # the refits want the set resident: upload what the host produced
+                eng.set_lightcurves(self._times, out["rates"], out["dy"] + 1e-12, y_offset=out["means"])
+        out.pop("segments", None)
         return out
+
+    def _finish_on_host(self, out, noise, want_clean):
+        """Flux-PDF adjustment of the fine-grid segments, down-sampling and noise for the cases the device
+        kernels do not cover (module docstring)."""
+        rates = out["rates"]
+        if self.pdf.lower() != "gaussian":
+            rates = np.array([self.downsample(self.segment_times, self._adjust_pdf(seg)) for seg in out["segments"]])
+        clean = rates.copy() if want_clean else None
+        dy = np.zeros_like(rates)
+        if noise:
+            noisy = [self.add_noise(r) for r in rates]
+            rates = np.array([r for r, _ in noisy])
+            dy = np.array([e for _, e in noisy])
+        return dict(rates=rates, dy=dy, means=rates.mean(axis=1), clean=clean)
+
+    def _adjust_pdf(self, segment):
+        """Emmanoulopoulos et al. (2013), as simulator.py:65-140 runs it: a white series drawn from the
+        wanted flux PDF (mean = the simulator's, standard deviation = the segment's) repeatedly takes the
+        Fourier amplitudes of the TK95 segment and gives its values back by rank, until it stops changing."""
+        from scipy import stats
+        mean, std = self.mean, float(np.std(segment))
+        if self.pdf.lower() == "lognormal":     # stats.py:116-129
+            var = std ** 2
+            pdf = stats.lognorm(np.sqrt(np.log(var / mean ** 2 + 1.0)), scale=mean ** 2 / np.sqrt(var + mean ** 2))
+        else:                                   # uniform with that mean and variance, stats.py:132-146
+            half = np.sqrt(3.0) * std
+            pdf = stats.uniform(loc=mean - half, scale=2.0 * half)
+        n = len(segment)
+        amplitudes = np.abs(np.fft.rfft(segment))
+        values = np.sort(pdf.rvs(size=n, random_state=self.random_state))[::-1]     # the flux values, descending
+        current = self.random_state.permutation(values)
+        for iteration in range(self.max_iter + 1):
+            spectrum = amplitudes * np.exp(1j * np.angle(np.fft.rfft(current)))
+            adjusted = np.fft.irfft(spectrum, n=n)
+            new = np.empty(n)
+            new[np.argsort(-adjusted)] = values                                       # same ranks, the PDF's values
+            if np.allclose(new, current, rtol=1e-4):
+                return new
+            current = new
+        warnings.warn("Lightcurve did not converge after %d iterations, PDF might be inaccurate. Try increase the "
+                      "maximum number of iterations" % self.max_iter)
+        return current
 
     def generate_lightcurve(self):
         """One noise-free realisation on the observing pattern (simulator.py:397-420)."""
         return self.simulate(noise=False)["rates"][0]
 
     def add_noise(self, rates):
-        """Noisy rates and their uncertainties (simulator.py:300-338) for ONE light curve, on
-        the host with this simulator's RandomState; the batched path adds noise on the device."""
+        """Noisy rates and their uncertainties (simulator.py:300-338; noise_models.py) for ONE light curve,
+        on the host with this simulator's RandomState; the batched path adds Gaussian and Poisson noise on
+        the device."""
         rates = np.asarray(rates, dtype=np.float64)
         if self._noise_kind == 1:
             return rates + self.random_state.normal(scale=self.sigma_noise, size=len(rates)), \
                 self.sigma_noise * np.ones(len(rates))
-        total_counts = rates * self._exposures
-        poiss = self.random_state.poisson(total_counts)
-        return poiss / self._exposures, np.sqrt((np.sqrt(poiss) / self._exposures) ** 2)
+        expo, bkg = self._exposures, self._bkg_counts
+        total = self.random_state.poisson(rates * expo + bkg).astype(np.float64)
+        net_rates = (total - bkg) / expo
+        dy = np.sqrt((np.sqrt(total) / expo) ** 2 + self._bkg_rate_err ** 2)
+        if self._noise_kind == 3:
+            faint = total < self.kraft_counts          # Bayesian treatment of the faint epochs
+            for i in np.nonzero(faint)[0]:
+                n_i = int(round(total[i]))
+                net_rates[i] = kraft_median(n_i, bkg[i]) / expo[i]
+                lo, hi = kraft_interval(n_i, bkg[i], 0.68)
+                dy[i] = (hi - lo) / 2.0 / expo[i]
+        return net_rates, dy

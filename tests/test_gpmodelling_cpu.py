@@ -119,3 +119,61 @@ def test_likelihood_fails_loudly_without_gpu():
     g = GPModelling(lc, DampedRandomWalk(1.0, -1.0))
     with pytest.raises(engine.EngineUnavailable):
         g._log_probability(g.initial_params)
+
+
+class _StubGP:
+    """Stands in for gp.GP inside GPModelling: log_probability_batch from a table of statuses."""
+    def __init__(self, real, statuses):
+        self._real, self._statuses, self.calls = real, list(statuses), 0
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    def log_probability_batch(self, theta, y, add_prior=True):
+        theta = np.atleast_2d(theta)
+        st = self._statuses[min(self.calls, len(self._statuses) - 1)]
+        self.calls += 1
+        out = -np.sum((theta - 1.0) ** 2, axis=1) - 10.0
+        status = np.full(len(theta), st, dtype=np.int32)
+        return np.where(status == 0, out, -np.inf), status
+
+
+def test_fit_raises_when_the_starting_point_cannot_be_factorised():
+    """gpmodelling.py:192: celerite's LinAlgError aborts the reference's fit; a flat plateau would make
+    L-BFGS-B report success at the starting point instead."""
+    gpmodel, parameters, bounds = make([(4.0, 6.0), (8.0, 12.0)], [(5, 15), (1, 6), (-7, -1)])
+    gpmodel.gp = _StubGP(gpmodel.gp, [engine.ST_NOTPD])
+    from mind_the_gaps_amd.gp import LinAlgError
+    with pytest.raises(LinAlgError):
+        gpmodel.fit()
+    # quiet=True: no exception, but the result says it did not succeed
+    gpmodel._quiet = True
+    gpmodel.gp = _StubGP(gpmodel.gp._real, [engine.ST_NOTPD])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        sol = gpmodel.fit()
+    assert not sol.success and any("factorised" in str(w.message) for w in caught)
+    # a bad point LATER in the line search is just a bad point
+    gpmodel._quiet = False
+    gpmodel.gp = _StubGP(gpmodel.gp._real, [engine.ST_OK, engine.ST_NOTPD, engine.ST_OK])
+    sol = gpmodel.fit()
+    assert np.isfinite(sol.fun)
+
+
+def test_best_loglikelihood_is_the_maximum_over_the_whole_chain():
+    gpmodel, _, _ = make([(4.0, 6.0), (8.0, 12.0)], [(5, 15), (1, 6), (-7, -1)])
+    with pytest.raises(AttributeError):
+        gpmodel.best_loglikelihood
+
+    class _Sampler:
+        state = {"best_log_prob": np.array([-1.5])}
+
+        def get_log_prob(self, flat=False, discard=0, thin=1):
+            return np.array([-9.0, -2.0, -5.0, -7.0])[discard::thin]
+
+    gpmodel._sampler = _Sampler()
+    gpmodel._loglikelihoods = np.array([-5.0, -7.0])      # what survived burn-in and thinning
+    gpmodel._mcmc_samples = np.zeros((2, 5))
+    assert gpmodel.max_loglikelihood == -5.0 and gpmodel.best_loglikelihood == -1.5
+    del _Sampler.state
+    assert gpmodel.best_loglikelihood == -2.0
