@@ -2,6 +2,7 @@
 // One context = one MI355X + resident light curves + model + workspaces.
 #include "mtg_device.h"
 #include "mtg_tp_scan.h"
+#include "mtg_trace.h"
 
 #include <hipfft/hipfft.h>
 
@@ -231,10 +232,16 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     hipEvent_t *pe = prof ? &ctx->prof_ev[3 * (size_t)ctx->prof_n] : nullptr;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[0], s));
-    if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
-    mtg_launch_prepare(make_prep_args(ctx, B, d_theta, add_prior, d_out, d_status), s);
+    {
+        mtg_trace::Range range("mtg:prepare (theta -> prior, coefficients)");
+        if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
+        mtg_launch_prepare(make_prep_args(ctx, B, d_theta, add_prior, d_out, d_status), s);
+    }
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
-    rc = solve_prepared(ctx, B, d_lc, d_out, d_status, s);
+    {
+        mtg_trace::Range range("mtg:solve (factorisation + forward solve)");
+        rc = solve_prepared(ctx, B, d_lc, d_out, d_status, s);
+    }
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
     if (prof) {
@@ -467,6 +474,7 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     if (L > 0x7fffffff) return fail(ctx, MTG_E_ARG, "too many light curves (32-bit indices)");
     int rc = use_device(ctx);
     if (rc) return rc;
+    mtg_trace::Range range("mtg:set_lightcurves (upload, sigma^2, dx)");
     const int64_t t_rows = t_per_lc ? L : 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, ctx->dxt.reserve((size_t)t_rows * N * 16));
@@ -647,6 +655,7 @@ MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, cons
     rc = run_model_batch(ctx, B, ctx->theta.as<double>(), d_lc, add_prior, ctx->out.as<double>(),
                          ctx->status.as<int32_t>(), s);
     if (rc) return rc;
+    mtg_trace::Range range("mtg:gather (lnP, status -> host)");
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(status, ctx->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -833,6 +842,7 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     const int E = (int)ctx->ens_E, W = ctx->ens_W, P = ctx->ens_P, H = W / 2;
     const int64_t EW = (int64_t)E * W, EH = (int64_t)E * H;
     hipStream_t s = ctx->stream;
+    mtg_trace::Range range("mtg:ensemble_run (stretch moves, device resident)");
     if (chain) HIP_TRY(ctx, ctx->ens_chain.reserve((size_t)steps * EW * P * 8));
     if (lnp_chain) HIP_TRY(ctx, ctx->ens_lnp_chain.reserve((size_t)steps * EW * 8));
     rc = check_model_workspace(ctx, EH);
@@ -916,6 +926,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: make_resident needs a shared sampling");
     rc = use_device(ctx);
     if (rc) return rc;
+    mtg_trace::Range range("mtg:simulate_tk95");
     MtgModel m0;
     memset(&m0, 0, sizeof m0);
     const MtgModel &m = psd_table ? m0 : ctx->model;

@@ -15,6 +15,7 @@ import pytest
 import golden_util
 from oracle import celerite as oc
 from oracle import dense
+from mind_the_gaps_amd import synthetic as synth
 
 K = dense
 
@@ -148,3 +149,61 @@ def test_not_positive_definite_status():
     out, st = oc.logprob_batch(t, y, dy, [K.K_COMPLEX4], full)
     assert st[0] == 2 and np.isneginf(out[0])
     assert dense.dense_loglike(t, y, dy, dense.build_coeffs([K.K_COMPLEX4], full[:4]), 0, [0.0]) == -np.inf
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """ASan + UBSan build of the C restatement on the CPU (never on the GPU box's
+    card): every term kind, prior on, several light curves, threads; clean exit and the same numbers as
+    the plain library."""
+    import shutil
+    import struct
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    here = os.path.dirname(os.path.abspath(oc.__file__))
+    exe = str(tmp_path / "oracle_sanitized")
+    build = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-fno-omit-frame-pointer", "-fopenmp", os.path.join(here, "celerite_ref.c"),
+                            os.path.join(here, "sanitize_driver.c"), "-lm", "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this gcc has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr
+    kinds = [synth.K_DRW, synth.K_SHO, synth.K_LORENTZIAN, synth.K_MATERN32, synth.K_JITTER, synth.K_BPL]
+    N, L, B = 257, 3, 24
+    t, y, dy = synth.make_lightcurves(N, L, seed=3)
+    theta = synth.draw_thetas(kinds, B, seed=4, percent=0.2)
+    theta[::5, 4] = np.log(0.2)                                   # over-damped SHO rows
+    theta[3, 0] = 99.0                                            # outside the box
+    full = np.hstack([theta, y.mean(axis=1)[np.arange(B) % L][:, None]])
+    bounds = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)]])
+    lc = (np.arange(B) % L).astype(np.int32)
+    extra = np.full(len(kinds), 0.01)
+    case = tmp_path / "case.bin"
+    with open(case, "wb") as f:
+        f.write(struct.pack("8q", N, L, B, len(kinds), full.shape[1], 0, 1, 3))
+        for arr, dt in ((kinds, np.int32), (extra, np.float64), (t, np.float64), (y, np.float64), (dy, np.float64),
+                        (bounds, np.float64), (full, np.float64), (lc, np.int32)):
+            f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([exe, str(case)], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0 and run.stderr.strip() == "", run.stderr[-2000:]
+    rows = np.array([line.split() for line in run.stdout.split("\n") if line], dtype=float)
+    assert rows.shape == (2 * B, 2)
+    ref, rst = oc.logprob_batch(t, y, dy, kinds, full, bounds=bounds, lc_index=lc, add_prior=True, nthreads=3)
+    for block in (rows[:B], rows[B:]):                            # two-sweep, then fused
+        assert np.array_equal(block[:, 1].astype(int), rst)
+        ok = rst == 0
+        assert np.all(np.isneginf(block[~ok, 0]))
+        assert np.max(np.abs(block[ok, 0] - ref[ok]) / np.abs(ref[ok])) < 1e-12
+
+
+def test_fused_sweep_equals_the_two_sweep_restatement():
+    """The one-sweep variant bench.py times as the CPU baseline is the same arithmetic in another order of
+    loops: identical results."""
+    kinds = synth.ALT_MODEL
+    t, y, dy = synth.make_lightcurves(3000, 2, seed=8)
+    th = synth.draw_thetas(kinds, 16, seed=9)
+    full = np.hstack([th, np.full((16, 1), y.mean())])
+    a, sa = oc.logprob_batch(t, y, dy, kinds, full, nthreads=4)
+    b, sb = oc.logprob_batch(t, y, dy, kinds, full, nthreads=4, fused=True)
+    assert np.array_equal(sa, sb) and np.max(np.abs(a - b) / np.abs(a)) < 1e-13
