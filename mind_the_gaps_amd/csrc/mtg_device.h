@@ -96,7 +96,7 @@ struct MtgSolveArgs {
 };
 
 // doubles per filtering element (A | b | eta | C | Jm) of the time-parallel kernel
-#define MTG_TP_ELEM(J) ((J) * (J) + 2 * (J) + (J) * ((J) + 1))
+#define MTG_TP_ELEM(J) ((J) * (J) + 2 * (J) + (J) * ((J) + 1) + 5)
 
 struct MtgPredictArgs {
     const double *coef;     // SoA coefficient workspace (mtg_prepare_kernel)

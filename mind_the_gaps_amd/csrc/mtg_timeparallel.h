@@ -14,18 +14,27 @@
 // Sarkka & Garcia-Fernandez (2021): the N samples are cut into 64 chunks, one per lane;
 //   pass 1  every lane composes the element (A, b, C, eta, J) of its chunk: a Kalman filter
 //           started from (0, 0) that also carries A, eta and J along, O(J^2) per step;
-//   pass 2  an inclusive scan of the 64 chunk elements across the lanes (Hillis-Steele through
-//           LDS, six rounds of the general element combination, one J x J inverse each);
-//           every lane then applies the prefix of the earlier chunks to the state after
-//           sample 0: its chunk's start state;
-//   pass 3  every lane runs the ordinary Kalman filter over its chunk from its start
-//           state and accumulates ln prod D and sum z^2 / D; a wave reduction finishes.
-// Work is ~3x the serial sweep, depth ~2 N/64 + 6 combinations instead of N.
+//           started from (0, 0) that also carries A, eta and J along, O(J^2) per step, and
+//           with it the chunk's likelihood given x_in = 0 (the filter's own pivots and residuals);
+//   pass 2  an inclusive scan of the chunk elements across the lanes (Hillis-Steele through
+//           LDS, log2(lanes) rounds of the general element combination, one J x J inverse each).
+//           The combination carries the likelihood along (the later chunk's Gaussian likelihood in
+//           x_in integrated against the earlier chunk's N(b, C)), so the last lane's element,
+//           integrated against the state after sample 0, IS lnL: the samples are read once.
+//   pass 3  only when that number is suspect (a pivot or determinant not positive, non-finite,
+//           or cancellation beyond 1e3): every lane applies the prefix of the earlier chunks to
+//           the state after sample 0 -- its chunk's start state -- runs the ordinary Kalman
+//           filter over its chunk and accumulates ln prod D and sum z^2 / D; a reduction
+//           finishes.  This pass also decides "not positive definite".
+// Work is ~2x the serial sweep, depth ~N/lanes + log2(lanes) combinations instead of N.
 #pragma once
 #include "mtg_device.h"
 
-// the chunk elements of a workgroup sit in LDS when they fit (160 KiB per CU), else in a.tp_ws
-#define MTG_TP_IN_LDS(J, LANES) ((LANES) * MTG_TP_ELEM(J) * 8 <= 150 * 1024)
+// the chunk elements of a workgroup sit in LDS (160 KiB per CU)
+// (rank 6: two buffers of them, see tp_combine_lds)
+#define MTG_TP_PINGPONG(J) ((J) >= 6)
+#define MTG_TP_LDS_DOUBLES(J, LANES) ((MTG_TP_PINGPONG(J) ? 2 : 1) * (LANES) * MTG_TP_ELEM(J))
+#define MTG_TP_IN_LDS(J, LANES) (MTG_TP_LDS_DOUBLES(J, LANES) * 8 <= 150 * 1024)
 
 // 256-entry tables here (2 KiB + 4 KiB): LDS is needed for the chunk elements (the rank-10 path,
 // mtg_tp_big.h, keeps its elements in registers / global memory and asks for the 2048-entry tables)
@@ -244,10 +253,15 @@ __device__ __forceinline__ void tp_filter_step(const TpModel<NR, NC> &M, const T
 }
 
 // filtering element of a chunk: x_out | x_in ~ N(A x_in + b, C), p(y_chunk | x_in) ~ N_I(eta, Jm)
+// and the likelihood of the chunk given x_in = 0, ln p(y_chunk | 0) = kq - 1/2 (ln kdm + kde ln 2) (without
+// the 2 pi terms): the combination below carries it along, so the scanned element of the whole series IS
+// the likelihood and no second pass over the samples is needed.  kmin = smallest pivot met (not positive,
+// or NaN: the evaluation goes through the filter pass), kmag = sum of the magnitudes that went into kq.
 template <int J> struct TpElem {
     double A[J][J];
     double b[J], eta[J];
     Sym<J> C, Jm;
+    double kq, kdm, kde, kmin, kmag;
 };
 
 template <int J>
@@ -261,6 +275,7 @@ __device__ __forceinline__ void tp_identity(TpElem<J> &e)
     }
 #pragma unroll
     for (int i = 0; i < J * (J + 1) / 2; ++i) { e.C.v[i] = 0.0; e.Jm.v[i] = 0.0; }
+    e.kq = 0.0; e.kdm = 1.0; e.kde = 0.0; e.kmin = INFINITY; e.kmag = 0.0;
 }
 
 // e <- e o step(T, r, R).  Combining an element with a single-step element is the Kalman filter
@@ -269,12 +284,11 @@ __device__ __forceinline__ void tp_identity(TpElem<J> &e)
 //   A <- (I - K h) F A,   eta <- eta + g z / D,   Jm <- Jm + g g^T / D
 // (the general combination's (I + C J)^-1 with the step's rank-one J is that filter update).
 // Dv = C - P_inf is carried by the caller across the steps of a chunk.
-// ACC_STRIDE > 0: eta and Jm are accumulated in `acc` (LDS, entry k of this lane at acc[k * ACC_STRIDE],
-// eta first, then the triangle of Jm) instead of e.eta / e.Jm: at J = 10 the element alone is 230
-// doubles and the step's temporaries push the lane past its 512 registers into scratch.
-template <int NR, int NC, int J, int ACC_STRIDE = 0>
+// kap: (sum z^2/D, prod D [renormalised by the caller], min D) of this recursion, i.e. the likelihood of
+// the chunk given x_in = 0.
+template <int NR, int NC, int J>
 __device__ __forceinline__ void tp_compose_step(const TpModel<NR, NC> &M, const TpTrans<NR, NC> &T, double y, double R,
-                                                TpElem<J> &e, Sym<J> &Dv, double *acc = nullptr)
+                                                TpElem<J> &e, Sym<J> &Dv, double (&kap)[3])
 {
     tp_left_F<NR, NC, J>(T, e.A);
     double g[J];
@@ -294,28 +308,76 @@ __device__ __forceinline__ void tp_compose_step(const TpModel<NR, NC> &M, const 
 #pragma unroll
         for (int j = 0; j < J; ++j) e.A[i][j] = fma(-kd[i], g[j], e.A[i][j]);
     const double zi = z * inv;
-    if (ACC_STRIDE == 0) {
+    kap[0] = fma(z, zi, kap[0]);
+    kap[1] *= D;
+    kap[2] = fmin(kap[2], D);
 #pragma unroll
-        for (int j = 0; j < J; ++j) e.eta[j] = fma(g[j], zi, e.eta[j]);
+    for (int j = 0; j < J; ++j) e.eta[j] = fma(g[j], zi, e.eta[j]);
 #pragma unroll
-        for (int i = 0; i < J; ++i) {
-            const double gi = g[i] * inv;
+    for (int i = 0; i < J; ++i) {
+        const double gi = g[i] * inv;
 #pragma unroll
-            for (int j = 0; j <= i; ++j) e.Jm(i, j) = fma(gi, g[j], e.Jm(i, j));
-        }
-    } else {
+        for (int j = 0; j <= i; ++j) e.Jm(i, j) = fma(gi, g[j], e.Jm(i, j));
+    }
+}
+
+// Likelihood of a chunk given its start state N(m, C), relative to its likelihood given x_in = 0:
+//   ln p(y_chunk | m, C) - kappa = -1/2 ln det G + eta^T m - 1/2 m^T Jm m + 1/2 t^T G^-1 C t,
+//   G = I + C Jm,  t = eta - Jm m
+// (p(y_chunk | x_in) = exp(kappa + eta^T x_in - 1/2 x_in^T Jm x_in), integrated against N(m, C)).
+// NaN when det G is not positive.
+template <int J>
+__device__ __forceinline__ double tp_chunk_correction(const double *eta, const Sym<J> &Jm, const double *m, const Sym<J> &C)
+{
+    double t[J], G[J][J], x[J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) acc[j * ACC_STRIDE] = fma(g[j], zi, acc[j * ACC_STRIDE]);
+    for (int i = 0; i < J; ++i) {
+        double s = eta[i];
 #pragma unroll
-        for (int i = 0; i < J; ++i) {
-            const double gi = g[i] * inv;
+        for (int k = 0; k < J; ++k) s = fma(-Jm(i, k), m[k], s);
+        t[i] = s;
+    }
+    double quad = 0.0;   // eta^T m - 1/2 m^T Jm m = 1/2 m^T (eta + t)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double *p = acc + (J + i * (i + 1) / 2 + j) * ACC_STRIDE;
-                *p = fma(gi, g[j], *p);
-            }
+    for (int i = 0; i < J; ++i) quad = fma(0.5 * m[i], eta[i] + t[i], quad);
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(C(i, k), t[k], s);
+        x[i] = s;                                              // C t
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double g = i == j ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) g = fma(C(i, k), Jm(k, j), g);
+            G[i][j] = g;
         }
     }
+    // x <- G^-1 (C t) by Gauss-Jordan without pivoting; det G = product of the pivots
+    double dm = 1.0;
+    int de = 0;
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+        const double ip = 1.0 / G[p][p];
+        const double pr = dm * G[p][p];
+        dm = __builtin_amdgcn_frexp_mant(pr);
+        de += __builtin_amdgcn_frexp_exp(pr);
+#pragma unroll
+        for (int j = p + 1; j < J; ++j) G[p][j] *= ip;
+        x[p] *= ip;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            if (i == p) continue;
+            const double f = G[i][p];
+#pragma unroll
+            for (int j = p + 1; j < J; ++j) G[i][j] = fma(-f, G[p][j], G[i][j]);
+            x[i] = fma(-f, x[p], x[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) quad = fma(0.5 * t[i], x[i], quad);
+    return dm > 0.0 ? quad - 0.5 * (log(dm) + (double)de * 0.69314718055994530942) : __builtin_nan("");
 }
 
 // (m, C) <- element applied to the filtered state (m, C):
@@ -385,10 +447,11 @@ __device__ __forceinline__ void tp_apply_elem(const TpElem<J> &e, double *m, Sym
         }
 }
 
-// View of an element stored by tp_store (A | b | eta | C | Jm)
+// View of an element stored by tp_store (A | b | eta | C | Jm | kq kdm kde kmin kmag)
 template <int J> struct TpSlot {
     double *p;
-    static constexpr int OB = J * J, OE = OB + J, OC = OE + J, OJ = OC + J * (J + 1) / 2;
+    static constexpr int OB = J * J, OE = OB + J, OC = OE + J, OJ = OC + J * (J + 1) / 2, OK = OJ + J * (J + 1) / 2;
+    __device__ __forceinline__ double &k(int i) const { return p[OK + i]; }
     __device__ __forceinline__ static int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
     __device__ __forceinline__ double &A(int i, int j) const { return p[i * J + j]; }
     __device__ __forceinline__ double &b(int i) const { return p[OB + i]; }
@@ -400,6 +463,8 @@ template <int J> struct TpSlot {
 // e2 <- e1 o e2 (e1 earlier in time): the general combination of two filtering elements
 //   G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2
 //   eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1
+//   ln p(y_12 | 0) = ln p(y_1 | 0) + ln p(y_2 | 0) - 1/2 ln det G + 1/2 b1^T (eta2 + t) + 1/2 t^T G^-1 C1 t,
+//   t = eta2 - J2 b1   (the second chunk's likelihood integrated against N(b1, C1), see tp_chunk_correction)
 // e1 is in registers (it had to be read before the barrier); e2 stays in this lane's own LDS
 // slot and is read and overwritten piece by piece: both in registers would be 4 J (J + 1.5)
 // VGPRs plus the temporaries and spill to scratch from J = 5 on.
@@ -420,9 +485,15 @@ __device__ __forceinline__ void tp_combine(const TpElem<J> &e1, double *slot2)
             G[i][j] = g;
             Gi[i][j] = i == j ? 1.0 : 0.0;
         }
+    double dm = e1.kdm * e2.k(1), de = e1.kde + e2.k(2);  // det G = product of the pivots
+    de += (double)__builtin_amdgcn_frexp_exp(dm);
+    dm = __builtin_amdgcn_frexp_mant(dm);
 #pragma unroll
     for (int p = 0; p < J; ++p) {
         const double ip = 1.0 / G[p][p];
+        const double pr = dm * G[p][p];
+        dm = __builtin_amdgcn_frexp_mant(pr);
+        de += (double)__builtin_amdgcn_frexp_exp(pr);
 #pragma unroll
         for (int j = 0; j < J; ++j) { G[p][j] *= ip; Gi[p][j] *= ip; }
 #pragma unroll
@@ -433,6 +504,10 @@ __device__ __forceinline__ void tp_combine(const TpElem<J> &e1, double *slot2)
             for (int j = 0; j < J; ++j) { G[i][j] = fma(-f, G[p][j], G[i][j]); Gi[i][j] = fma(-f, Gi[p][j], Gi[i][j]); }
         }
     }
+    // (single pivots of the non-symmetric G may be negative; only the sign of det G matters)
+    e2.k(3) = dm > 0.0 ? fmin(e1.kmin, e2.k(3)) : __builtin_nan("");
+    e2.k(1) = dm;
+    e2.k(2) = de;
     // w = b1 + C1 eta2 (state part, needs the OLD eta2)
     double w[J];
 #pragma unroll
@@ -458,6 +533,19 @@ __device__ __forceinline__ void tp_combine(const TpElem<J> &e1, double *slot2)
 #pragma unroll
             for (int k = 0; k < J; ++k) s = fma(Gi[k][i], t[k], s);
             yeta[i] = s;
+        }
+        {   // likelihood part
+            double lin = 0.0, quad = 0.0;
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                double c1t = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) c1t = fma(e1.C(i, k), t[k], c1t);
+                quad = fma(0.5 * yeta[i], c1t, quad);
+                lin = fma(0.5 * e1.b[i], e2.eta(i) + t[i], lin);
+            }
+            e2.k(0) += e1.kq + lin + quad;
+            e2.k(4) += e1.kmag + fabs(lin) + fabs(quad);
         }
         double YJ[J][J], Z[J][J];  // YJ = G^-T J2 ; Z = YJ A1
 #pragma unroll
@@ -553,186 +641,227 @@ __device__ __forceinline__ void tp_combine(const TpElem<J> &e1, double *slot2)
     }
 }
 
-// The same combination with both elements in registers: for J = 10 neither variant fits the
-// register file, and the compiler's scratch spills of this one are cheaper than re-reading e2's
-// entries from LDS inside the J^3 loops.
-//   G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2
-//   eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1
+// dst <- e1 o e2 with all three in LDS (dst a slot of the OTHER buffer of a ping-pong pair): nothing of e1
+// is held in registers across the barrier and the pieces are read where they are used.  For the rank
+// where tp_combine's register version no longer fits the register file (J = 6: G, G^-1, e1 and the
+// temporaries are ~560 VGPRs; its scratch spills are slow and were miscompiled, scripts/agpr_lint.py).
 template <int J>
-__device__ __forceinline__ void tp_combine_regs(const TpElem<J> &e1, TpElem<J> &e2)
+__device__ __forceinline__ void tp_combine_lds(const double *slot1, const double *slot2, double *slotd)
 {
-    // Gi = (I + C1 J2)^-1 by Gauss-Jordan (similar to a symmetric positive definite matrix: no pivoting)
-    double G[J][J], Gi[J][J];
+    const TpSlot<J> e1{const_cast<double *>(slot1)}, e2{const_cast<double *>(slot2)}, d{slotd};
+    double Gi[J][J];
+    {
+        double G[J][J];
 #pragma unroll
-    for (int i = 0; i < J; ++i)
+        for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            double g = i == j ? 1.0 : 0.0;
+            for (int j = 0; j < J; ++j) {
+                double g = i == j ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < J; ++k) g = fma(e1.C(i, k), e2.Jm(k, j), g);
-            G[i][j] = g;
-            Gi[i][j] = i == j ? 1.0 : 0.0;
+                for (int k = 0; k < J; ++k) g = fma(e1.C(i, k), e2.Jm(k, j), g);
+                G[i][j] = g;
+                Gi[i][j] = i == j ? 1.0 : 0.0;
+            }
+        double dm = e1.k(1) * e2.k(1), de = e1.k(2) + e2.k(2);
+        de += (double)__builtin_amdgcn_frexp_exp(dm);
+        dm = __builtin_amdgcn_frexp_mant(dm);
+#pragma unroll
+        for (int p = 0; p < J; ++p) {
+            const double ip = 1.0 / G[p][p];
+            const double pr = dm * G[p][p];
+            dm = __builtin_amdgcn_frexp_mant(pr);
+            de += (double)__builtin_amdgcn_frexp_exp(pr);
+#pragma unroll
+            for (int j = 0; j < J; ++j) { G[p][j] *= ip; Gi[p][j] *= ip; }
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                if (i == p) continue;
+                const double f = G[i][p];
+#pragma unroll
+                for (int j = 0; j < J; ++j) { G[i][j] = fma(-f, G[p][j], G[i][j]); Gi[i][j] = fma(-f, Gi[p][j], Gi[i][j]); }
+            }
         }
-#pragma unroll
-    for (int p = 0; p < J; ++p) {
-        const double ip = 1.0 / G[p][p];
-#pragma unroll
-        for (int j = 0; j < J; ++j) { G[p][j] *= ip; Gi[p][j] *= ip; }
+        d.k(3) = dm > 0.0 ? fmin(e1.k(3), e2.k(3)) : __builtin_nan("");
+        d.k(1) = dm;
+        d.k(2) = de;
+    }
+    // ---- information part and likelihood ------------------------------------------------------
+    {
+        double t[J], yeta[J];
 #pragma unroll
         for (int i = 0; i < J; ++i) {
-            if (i == p) continue;
-            const double f = G[i][p];
+            double s = e2.eta(i);
 #pragma unroll
-            for (int j = 0; j < J; ++j) { G[i][j] = fma(-f, G[p][j], G[i][j]); Gi[i][j] = fma(-f, Gi[p][j], Gi[i][j]); }
+            for (int k = 0; k < J; ++k) s = fma(-e2.Jm(i, k), e1.b(k), s);
+            t[i] = s;
         }
-    }
-    // information part (uses A1, b1, eta1, J1 and the OLD eta2, J2)
-    double t[J], yeta[J];
 #pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double s = e2.eta[i];
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(-e2.Jm(i, k), e1.b[k], s);
-        t[i] = s;
-    }
-#pragma unroll
-    for (int i = 0; i < J; ++i) {  // G^-T t
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(Gi[k][i], t[k], s);
-        yeta[i] = s;
-    }
-    double YJ[J][J], Z[J][J];  // YJ = G^-T J2 ; Z = YJ A1
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
+        for (int i = 0; i < J; ++i) {  // G^-T t
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < J; ++k) s = fma(Gi[k][i], e2.Jm(k, j), s);
-            YJ[i][j] = s;
+            for (int k = 0; k < J; ++k) s = fma(Gi[k][i], t[k], s);
+            yeta[i] = s;
+        }
+        double lin = 0.0, quad = 0.0;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double c1t = 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) c1t = fma(e1.C(i, k), t[k], c1t);
+            quad = fma(0.5 * yeta[i], c1t, quad);
+            lin = fma(0.5 * e1.b(i), e2.eta(i) + t[i], lin);
+        }
+        d.k(0) = e1.k(0) + e2.k(0) + lin + quad;
+        d.k(4) = e1.k(4) + e2.k(4) + fabs(lin) + fabs(quad);
+        double YJ[J][J], Z[J][J];  // YJ = G^-T J2 ; Z = YJ A1
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) s = fma(Gi[k][i], e2.Jm(k, j), s);
+                YJ[i][j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) s = fma(YJ[i][k], e1.A(k, j), s);
+                Z[i][j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double s = e1.eta(i);
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(e1.A(k, i), yeta[k], s);
+            d.eta(i) = s;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double u = e1.Jm(i, j);
+#pragma unroll
+                for (int k = 0; k < J; ++k) u = fma(e1.A(k, i), Z[k][j], u);
+                d.Jm(i, j) = u;
+            }
+        }
+    }
+    // ---- state part --------------------------------------------------------------------------
+    {
+        double w[J], Xb[J];  // w = b1 + C1 eta2 ; Xb = Gi w ; b = A2 Xb + b2
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double s = e1.b(i);
+#pragma unroll
+            for (int k = 0; k < J; ++k) s = fma(e1.C(i, k), e2.eta(k), s);
+            w[i] = s;
         }
 #pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
+        for (int i = 0; i < J; ++i) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < J; ++k) s = fma(YJ[i][k], e1.A[k][j], s);
-            Z[i][j] = s;
-        }
-    double eta_new[J];
-    Sym<J> J_new;
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double s = e1.eta[i];
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(e1.A[k][i], yeta[k], s);
-        eta_new[i] = s;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double u = 0.0, v = 0.0;
-#pragma unroll
-            for (int k = 0; k < J; ++k) { u = fma(e1.A[k][i], Z[k][j], u); v = fma(e1.A[k][j], Z[k][i], v); }
-            J_new(i, j) = 0.5 * (u + v) + e1.Jm(i, j);
-        }
-    }
-    // state part: XA = Gi A1, Xb = Gi (b1 + C1 eta2), XC = Gi C1
-    double w[J], Xb[J], XA[J][J], XC[J][J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double s = e1.b[i];
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(e1.C(i, k), e2.eta[k], s);
-        w[i] = s;
-    }
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(Gi[i][k], w[k], s);
-        Xb[i] = s;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            double a = 0.0, c = 0.0;
-#pragma unroll
-            for (int k = 0; k < J; ++k) { a = fma(Gi[i][k], e1.A[k][j], a); c = fma(Gi[i][k], e1.C(k, j), c); }
-            XA[i][j] = a;
-            XC[i][j] = c;
-        }
-    }
-    double A_new[J][J], b_new[J], Y[J][J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        double s = e2.b[i];
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(e2.A[i][k], Xb[k], s);
-        b_new[i] = s;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            double a = 0.0, c = 0.0;
-#pragma unroll
-            for (int k = 0; k < J; ++k) { a = fma(e2.A[i][k], XA[k][j], a); c = fma(e2.A[i][k], XC[k][j], c); }
-            A_new[i][j] = a;
-            Y[i][j] = c;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double u = 0.0, v = 0.0;
-#pragma unroll
-            for (int k = 0; k < J; ++k) { u = fma(Y[i][k], e2.A[j][k], u); v = fma(Y[j][k], e2.A[i][k], v); }
-            e2.C(i, j) = 0.5 * (u + v) + e2.C(i, j);
+            for (int k = 0; k < J; ++k) s = fma(Gi[i][k], w[k], s);
+            Xb[i] = s;
         }
 #pragma unroll
-    for (int i = 0; i < J; ++i) {
-        e2.b[i] = b_new[i];
-        e2.eta[i] = eta_new[i];
+        for (int i = 0; i < J; ++i) {
+            double s = e2.b(i);
 #pragma unroll
-        for (int j = 0; j < J; ++j) e2.A[i][j] = A_new[i][j];
+            for (int k = 0; k < J; ++k) s = fma(e2.A(i, k), Xb[k], s);
+            d.b(i) = s;
+        }
     }
+    {
+        double X[J][J];  // XA = Gi A1 ; A = A2 XA
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) e2.Jm.v[i] = J_new.v[i];
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) a = fma(Gi[i][k], e1.A(k, j), a);
+                X[i][j] = a;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) a = fma(e2.A(i, k), X[k][j], a);
+                d.A(i, j) = a;
+            }
+    }
+    {
+        double X[J][J], Y[J][J];  // XC = Gi C1 ; Y = A2 XC ; C = Y A2^T + C2
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double c = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) c = fma(Gi[i][k], e1.C(k, j), c);
+                X[i][j] = c;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double c = 0.0;
+#pragma unroll
+                for (int k = 0; k < J; ++k) c = fma(e2.A(i, k), X[k][j], c);
+                Y[i][j] = c;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double u = e2.C(i, j);
+#pragma unroll
+                for (int k = 0; k < J; ++k) u = fma(Y[i][k], e2.A(j, k), u);
+                d.C(i, j) = u;
+            }
+    }
 }
 
-// Element <-> memory.  ST = distance between consecutive entries: 1 for the lane-major LDS slots,
-// the lane count for the entry-major global buffer of the J = 10 kernels (coalesced across lanes).
-template <int J, int ST = 1>
+// Element <-> its LDS slot (A | b | eta | C | Jm | kq kdm kde kmin kmag)
+template <int J>
 __device__ __forceinline__ void tp_store(const TpElem<J> &e, double *slot)
 {
     int o = 0;
 #pragma unroll
     for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j < J; ++j) slot[ST * o++] = e.A[i][j];
+        for (int j = 0; j < J; ++j) slot[o++] = e.A[i][j];
 #pragma unroll
-    for (int i = 0; i < J; ++i) slot[ST * o++] = e.b[i];
+    for (int i = 0; i < J; ++i) slot[o++] = e.b[i];
 #pragma unroll
-    for (int i = 0; i < J; ++i) slot[ST * o++] = e.eta[i];
+    for (int i = 0; i < J; ++i) slot[o++] = e.eta[i];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[ST * o++] = e.C.v[i];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[o++] = e.C.v[i];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[ST * o++] = e.Jm.v[i];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) slot[o++] = e.Jm.v[i];
+    slot[o] = e.kq; slot[o + 1] = e.kdm; slot[o + 2] = e.kde; slot[o + 3] = e.kmin; slot[o + 4] = e.kmag;
 }
 
-template <int J, int ST = 1>
+template <int J>
 __device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
 {
     int o = 0;
 #pragma unroll
     for (int i = 0; i < J; ++i)
 #pragma unroll
-        for (int j = 0; j < J; ++j) e.A[i][j] = slot[ST * o++];
+        for (int j = 0; j < J; ++j) e.A[i][j] = slot[o++];
 #pragma unroll
-    for (int i = 0; i < J; ++i) e.b[i] = slot[ST * o++];
+    for (int i = 0; i < J; ++i) e.b[i] = slot[o++];
 #pragma unroll
-    for (int i = 0; i < J; ++i) e.eta[i] = slot[ST * o++];
+    for (int i = 0; i < J; ++i) e.eta[i] = slot[o++];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) e.C.v[i] = slot[ST * o++];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e.C.v[i] = slot[o++];
 #pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) e.Jm.v[i] = slot[ST * o++];
+    for (int i = 0; i < J * (J + 1) / 2; ++i) e.Jm.v[i] = slot[o++];
+    e.kq = slot[o]; e.kdm = slot[o + 1]; e.kde = slot[o + 2]; e.kmin = slot[o + 3]; e.kmag = slot[o + 4];
 }
 
 }  // namespace
@@ -740,78 +869,66 @@ __device__ __forceinline__ void tp_load(TpElem<J> &e, const double *slot)
 // one wave per evaluation; lane = chunk
 // LANES = chunks per evaluation = workgroup size: 64 (one wave) or 256 (four waves, for the
 // smallest batches: the scan then crosses waves through LDS and workgroup barriers)
-// `elems`: LANES element slots -- LDS for J <= 6, this workgroup's slice of a.tp_ws (global
-// memory, workgroup-scope visibility through the barriers) for the J = 10 structures;
-// `red`: a few doubles of LDS for the final cross-wave reduction.
+// `elems`: LANES element slots in LDS; `red`: a few doubles of LDS for the cross-wave reductions.
 template <int NR, int NC, bool FAST, int LANES>
 __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
                                             double icpt, int64_t ev, int64_t lc, const MtgMathTables *tab, double *elems,
-                                            double *red, double *acc_lds = nullptr)
+                                            double *red, bool direct)
 {
-    double *sh = elems;
-    constexpr int MTG_TP_LANES = LANES;
     constexpr int J = NR + 2 * NC;
     constexpr int ELEM = MTG_TP_ELEM(J);  // doubles per element
-    constexpr bool IN_LDS = MTG_TP_IN_LDS(J, LANES);
-    constexpr int ST = IN_LDS ? 1 : LANES;            // entry stride of an element in the buffer
-    constexpr int SLOT = IN_LDS ? ELEM : 1;           // distance between the elements of two lanes
     const int lane = threadIdx.x;
     const int64_t N = a.N;
     const double2 *yv = a.yv + lc * N, *dxt = a.dxt + lc * a.t_stride;
 
     // chunk of this lane: samples [lo, hi); sample 0 is the prior update below
-    const int64_t per = (N + MTG_TP_LANES - 1) / MTG_TP_LANES;
+    const int64_t per = (N + LANES - 1) / LANES;
     int64_t lo = (int64_t)lane * per, hi = lo + per;
     if (lo > N) lo = N;
     if (hi > N) hi = N;
     if (lo == 0) lo = 1;
 
-    // ---- pass 1: element of the chunk ---------------------------------------------------
-    // the J = 10 kernels with 256 chunks keep their elements in global memory, so LDS is free to take
-    // the information part (eta, Jm: 65 doubles per lane, entry-major -> no bank conflicts) off the
-    // registers while the chunk is composed
-    constexpr bool ACC_LDS = !IN_LDS && LANES == 256;
-    constexpr int NACC = J + J * (J + 1) / 2;
+    // ---- pass 1: element of the chunk, with the chunk's likelihood given x_in = 0 -----------
     TpElem<J> e;
     tp_identity<J>(e);
     tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
-    if (ACC_LDS) {
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) acc_lds[k * LANES + lane] = 0.0;
-    }
-    for (int64_t n = lo; n < hi; ++n) {
-        TpTrans<NR, NC> T;
-        tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
-        const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
-        tp_compose_step<NR, NC, J, (ACC_LDS ? LANES : 0)>(M, T, r, yv[n].y + jitter, e, e.C, acc_lds + lane);
-    }
-    if (ACC_LDS) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) e.eta[j] = acc_lds[j * LANES + lane];
-#pragma unroll
-        for (int k = 0; k < J * (J + 1) / 2; ++k) e.Jm.v[k] = acc_lds[(J + k) * LANES + lane];
+    {
+        double kap[3] = {0.0, 1.0, INFINITY};
+        int kexp = 0;
+        for (int64_t n = lo; n < hi; ++n) {
+            TpTrans<NR, NC> T;
+            tp_transition<NR, NC, FAST>(M, dxt[n].x, T, tab);
+            const double r = yv[n].x - fma(slope, dxt[n].y, icpt);
+            tp_compose_step<NR, NC, J>(M, T, r, yv[n].y + jitter, e, e.C, kap);
+            kexp += __builtin_amdgcn_frexp_exp(kap[1]);
+            kap[1] = __builtin_amdgcn_frexp_mant(kap[1]);
+        }
+        e.kq = -0.5 * kap[0]; e.kdm = kap[1]; e.kde = (double)kexp; e.kmin = kap[2]; e.kmag = 0.5 * kap[0];
     }
     tp_add_pinf<NR, NC, J>(M, e.C);
 
-    // ---- pass 2: inclusive scan of the 64 chunk elements (Hillis-Steele through LDS) ------
-    double *buf = sh;
-    tp_store<J, ST>(e, buf + lane * SLOT);
+    // ---- pass 2: inclusive scan of the chunk elements (Hillis-Steele through LDS) -----------
+    double *buf = elems;
+    tp_store<J>(e, buf + lane * ELEM);
     __syncthreads();
-    for (int off = 1; off < MTG_TP_LANES; off <<= 1) {
-        TpElem<J> prev;
-        if (lane >= off) tp_load<J, ST>(prev, buf + (lane - off) * SLOT);
-        __syncthreads();  // everybody has read its partner before anybody overwrites
-        if (lane >= off) {
-            if (J <= 6) {
-                tp_combine<J>(prev, buf + lane * ELEM);  // own element stays in its LDS slot
-            } else {
-                tp_combine_regs<J>(prev, e);
-                tp_store<J, ST>(e, buf + lane * SLOT);
-            }
+    if (MTG_TP_PINGPONG(J)) {  // two buffers: read the round's inputs from one, write its outputs to the other
+        double *nxt = elems + LANES * ELEM;
+        for (int off = 1; off < LANES; off <<= 1) {
+            if (lane >= off) tp_combine_lds<J>(buf + (lane - off) * ELEM, buf + lane * ELEM, nxt + lane * ELEM);
+            else
+                for (int i = 0; i < ELEM; ++i) nxt[lane * ELEM + i] = buf[lane * ELEM + i];
+            __syncthreads();
+            double *sw = buf; buf = nxt; nxt = sw;
         }
-        __syncthreads();
+    } else {
+        for (int off = 1; off < LANES; off <<= 1) {
+            TpElem<J> prev;
+            if (lane >= off) tp_load<J>(prev, buf + (lane - off) * ELEM);
+            __syncthreads();  // everybody has read its partner before anybody overwrites
+            if (lane >= off) tp_combine<J>(prev, buf + lane * ELEM);  // own element stays in its LDS slot
+            __syncthreads();
+        }
     }
-    double *cur = buf;
     // filtered state after sample 0 (update of the stationary prior), identical on every lane
     double m[J];
     Sym<J> C;
@@ -836,15 +953,42 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     for (int i = 0; i < J; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) C(i, j) -= ch[i] * ch[j] / D0;
-    // start state of this lane's chunk: the prefix of the earlier chunks applied to it
+
+    // ---- the last lane holds the element of samples 1 .. N-1: integrated against the state after
+    // sample 0 it is the likelihood.  Anything suspicious sends the evaluation through pass 3.
+    int *flag = (int *)(red + 3 * (LANES / 64));
+    if (lane == LANES - 1) {
+        const TpSlot<J> tot{buf + lane * ELEM};
+        double eta[J];
+        Sym<J> Jm;
+#pragma unroll
+        for (int i = 0; i < J; ++i) eta[i] = tot.eta(i);
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Jm(i, j) = tot.Jm(i, j);
+        const double corr = tp_chunk_correction<J>(eta, Jm, m, C);
+        const double ld = log(tot.k(1)) + tot.k(2) * 0.69314718055994530942 + log(D0);
+        const double q0 = 0.5 * z0 * z0 / D0;
+        const double ll = tot.k(0) + corr - q0 - 0.5 * (ld + (double)N * MTG_LN_2PI);
+        const double mag = tot.k(4) + fabs(corr) + q0;
+        const bool good = direct && fmin(tot.k(3), D0) > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll);
+        if (good) { a.out[ev] = ll; a.status[ev] = MTG_ST_OK; }
+        *flag = good ? 0 : 1;
+    }
+    __syncthreads();
+    if (*flag == 0) return;  // (uniform over the workgroup: one evaluation)
+
+    // ---- pass 3: ordinary Kalman filter over the chunk from its start state -----------------
+    // start state of this lane's chunk: the prefix of the earlier chunks applied to the state after sample 0
     if (lane > 0) {
         TpElem<J> pre;
-        tp_load<J, ST>(pre, cur + (lane - 1) * SLOT);
+        tp_load<J>(pre, buf + (lane - 1) * ELEM);
         tp_apply_elem<J>(pre, m, C);
     }
-
-    // ---- pass 3: ordinary Kalman filter over the chunk from its start state -------------
-    double dot = lane == 0 ? z0 * z0 / D0 : 0.0, dprod = 1.0, dmin = lane == 0 ? D0 : INFINITY;
+    double dot = lane == 0 ? z0 * z0 / D0 : 0.0;
+    double dmin = lane == 0 ? D0 : INFINITY;
+    double dprod = 1.0;
     int dexp = 0;
     tp_sub_pinf<NR, NC, J>(M, C);  // deviation form from here on
     for (int64_t n = lo; n < hi; ++n) {
@@ -866,11 +1010,16 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
         dmin = fmin(dmin, __shfl_down(dmin, off));
     }
     if (LANES > 64) {  // combine the waves' partial sums through LDS
-        __syncthreads();
-        if ((lane & 63) == 0) { red[3 * (lane >> 6)] = dot; red[3 * (lane >> 6) + 1] = ld; red[3 * (lane >> 6) + 2] = dmin; }
+        if ((lane & 63) == 0) {
+            double *w = red + 3 * (lane >> 6);
+            w[0] = dot; w[1] = ld; w[2] = dmin;
+        }
         __syncthreads();
         if (lane == 0)
-            for (int w = 1; w < LANES / 64; ++w) { dot += red[3 * w]; ld += red[3 * w + 1]; dmin = fmin(dmin, red[3 * w + 2]); }
+            for (int k = 1; k < LANES / 64; ++k) {
+                const double *w = red + 3 * k;
+                dot += w[0]; ld += w[1]; dmin = fmin(dmin, w[2]);
+            }
     }
     if (lane == 0) {
         double ll = -0.5 * (dot + ld + (double)N * MTG_LN_2PI);
@@ -886,13 +1035,14 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
 // trigonometric path, run the three passes.
 template <int NR, int NC, int LANES>
 __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, const MtgMathTables *tab, double *elems,
-                                            double *red, double *acc_lds = nullptr)
+                                            double *red)
 {
     // ---- model of this evaluation (same on every lane) ------------------------------------
     TpModel<NR, NC> M;
     const double *cf = a.coef + ev;
     const int64_t cs = a.cstride;
     double dmax = 0.0;
+    bool direct = a.tp_direct != 0;
 #pragma unroll
     for (int j = 0; j < NR; ++j) { M.ar[j] = cf[a.lay.ar(j) * cs]; M.cr[j] = cf[a.lay.cr(j) * cs]; }
 #pragma unroll
@@ -902,6 +1052,12 @@ __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, c
         // free entry of P_inf: the value maximising det(noise covariance) (proto/kalman_scan.py)
         M.pc[k] = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
         dmax = fmax(dmax, fabs(d));
+        // A complex term's power spectrum is non-negative iff b d <= a c.  Terms with a free b (ComplexTerm,
+        // BendingPowerlaw outside their prior) can break that, the covariance matrix then need not be
+        // positive definite, and the scanned likelihood cannot tell: it sees det and quadratic form, not the
+        // sign of every pivot (two negative pivots cancel).  Those evaluations take the filter pass.
+        // (1e-12: SHOTerm and Matern32Term sit ON the boundary, b d = a c up to rounding.)
+        if (!(fabs(bb * d) <= aa * c * (1.0 + 1.0e-12))) direct = false;
     }
     const double jitter = cf[a.lay.jit() * cs];
     const double slope = cf[a.lay.mean(0) * cs], icpt = cf[a.lay.mean(1) * cs];
@@ -913,21 +1069,18 @@ __device__ __forceinline__ void mtg_tp_eval(const MtgSolveArgs &a, int64_t ev, c
         return;
     }
     if (dmax * *a.dxmax <= MTG_TRIG_FAST_MAX)
-        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red, acc_lds);
+        mtg_tp_body<NR, NC, true, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red, direct);
     else
-        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red, acc_lds);
+        mtg_tp_body<NR, NC, false, LANES>(a, M, jitter, slope, icpt, ev, lc, tab, elems, red, direct);
 }
 
 template <int NR, int NC, int LANES>
 __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;
-    constexpr bool IN_LDS = MTG_TP_IN_LDS(J, LANES);  // 256 J = 10 elements live in a.tp_ws
-    // elements in LDS when they fit; otherwise (J = 10, 256 chunks) the elements go through a.tp_ws and
-    // LDS holds the information part (eta, Jm) of the chunk being composed
-    constexpr int NACC = J + J * (J + 1) / 2;
-    __shared__ double sh[IN_LDS ? LANES * MTG_TP_ELEM(J) : (LANES == 256 ? LANES * NACC : 1)];
-    __shared__ double red[3 * (LANES / 64)];
+    static_assert(MTG_TP_IN_LDS(J, LANES), "the chunk elements of a workgroup live in LDS (rank 10: mtg_tp_big.h)");
+    __shared__ double sh[MTG_TP_LDS_DOUBLES(J, LANES)];
+    __shared__ double red[3 * (LANES / 64) + 1];
     __shared__ MtgMathTables tab;
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
     if ((int64_t)blockIdx.x >= count) return;
@@ -935,10 +1088,7 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     if (!a.list && a.status[ev] != MTG_ST_OK) return;
     mtg_fill_tables(&tab, threadIdx.x, LANES);
     __syncthreads();
-    // workspace slice by EVALUATION, not by workgroup: the structures of a batch run concurrently on
-    // their own streams (solve_prepared) and share a.tp_ws
-    double *elems = IN_LDS ? sh : a.tp_ws + ev * (LANES * MTG_TP_ELEM(J));
-    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, elems, red, IN_LDS ? nullptr : sh);
+    mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, sh, red);
 }
 
 template <int NR, int NC, int LANES = 64>
@@ -967,8 +1117,8 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_fused_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR0 + 2 * NC0;
     static_assert(NSIG >= 2 && NSIG - 1 <= NC0, "one structure per number of over-damped SHO terms");
-    __shared__ double sh[LANES * MTG_TP_ELEM(J)];
-    __shared__ double red[3 * (LANES / 64)];
+    __shared__ double sh[MTG_TP_LDS_DOUBLES(J, LANES)];
+    __shared__ double red[3 * (LANES / 64) + 1];
     __shared__ MtgMathTables tab;
     int64_t r = blockIdx.x;
     int k = 0;

@@ -200,7 +200,16 @@ __global__ void __launch_bounds__(64) mtg_tpb_finish_direct_kernel(MtgSolveArgs 
         mag += 0.5 * dot;
         dot += h[0]; ld += h[1]; dmin = fmin(dmin, h[2]);
         const double ll = corr - 0.5 * (dot + ld + (double)a.N * MTG_LN_2PI);
-        if (a.tp_direct >= 2 || (dmin > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll))) {  // 2: diagnostic, never redo
+        // a complex term with b d > a c has a power spectrum that goes negative: the matrix need not be positive
+        // definite and only the filter pass sees every pivot's sign (mtg_timeparallel.h, mtg_tp_eval)
+        bool psd = true;
+        const int nc = a.tp_nc0 - (a.sig ? a.sig[ev] : 0);
+        const double *cf = a.coef + ev;
+        for (int k = 0; k < nc; ++k)
+            if (!(fabs(cf[a.lay.bc(k) * a.cstride] * cf[a.lay.dc(k) * a.cstride])
+                  <= cf[a.lay.ac(k) * a.cstride] * cf[a.lay.cc(k) * a.cstride] * (1.0 + 1.0e-12)))
+                psd = false;
+        if (a.tp_direct >= 2 || (psd && dmin > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll))) {  // 2: diagnostic, never redo
             a.out[ev] = a.tp_direct == 3 ? dot : a.tp_direct == 4 ? ld : a.tp_direct == 5 ? corr : a.tp_direct == 6 ? mag : ll;
             a.status[ev] = MTG_ST_OK;
         } else {
