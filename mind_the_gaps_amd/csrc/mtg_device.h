@@ -95,8 +95,11 @@ struct MtgSolveArgs {
     const int32_t *sig;    // [B] over-damped SHO terms per evaluation (mtg_prepare_one), or NULL = 0
 };
 
-// doubles per filtering element (A | b | eta | C | Jm) of the time-parallel kernel
-#define MTG_TP_ELEM(J) ((J) * (J) + 2 * (J) + (J) * ((J) + 1) + 5)
+// doubles per filtering element (A | b | eta | C | Jm | five likelihood scalars) of the time-parallel kernel,
+// rounded up to an odd number: lane l's element starts l * MTG_TP_ELEM doubles into LDS, and an even stride
+// puts many lanes on the same bank (rank 3 would be 32 doubles: all 64 lanes on ONE bank, every access
+// serialised 64-fold -- measured as 5.6 us per scan round instead of ~1)
+#define MTG_TP_ELEM(J) (((J) * (J) + 2 * (J) + (J) * ((J) + 1) + 5) | 1)
 
 struct MtgPredictArgs {
     const double *coef;     // SoA coefficient workspace (mtg_prepare_kernel)
