@@ -254,9 +254,13 @@ __device__ __forceinline__ void tp_filter_step(const TpModel<NR, NC> &M, const T
 
 // The samples a lane walks through are 16 bytes apart in two arrays, each lane in its own cache lines: a
 // load issued where its value is needed stalls the step for a memory round trip (~1 us against ~0.4 us of
-// arithmetic at rank 3).  This keeps the next MTG_TP_AHEAD samples in flight in registers.
-#define MTG_TP_AHEAD 2
-struct TpSamples {
+// arithmetic at rank 3).  This keeps the next one or two samples in flight in registers.
+// (rank 6 is at the register limit: one sample ahead there)
+#define MTG_TP_AHEAD_OF(J) ((J) >= 6 ? 1 : 2)
+#ifndef MTG_TP_TREE
+#define MTG_TP_TREE 1
+#endif
+template <int MTG_TP_AHEAD> struct TpSamples {
     double2 y[MTG_TP_AHEAD], x[MTG_TP_AHEAD];
     __device__ __forceinline__ TpSamples(const double2 *yv, const double2 *dxt, int64_t lo, int64_t N)
     {
@@ -851,6 +855,270 @@ __device__ __forceinline__ void tp_combine_lds(const double *slot1, const double
     }
 }
 
+// ---- the combination split into parts that different WAVES compute (tp_reduce_tree) ------------------
+// R <- G^-1 R by Gauss-Jordan without pivoting (G is destroyed); (dm, de): det G as mantissa and exponent
+template <int J, int NRHS>
+__device__ __forceinline__ void tp_eliminate(double (&G)[J][J], double (&R)[J][NRHS], double &dm, double &de)
+{
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+        const double ip = mtg_rcp(G[p][p]);
+        const double pr = dm * G[p][p];
+        dm = __builtin_amdgcn_frexp_mant(pr);
+        de += (double)__builtin_amdgcn_frexp_exp(pr);
+#pragma unroll
+        for (int j = p + 1; j < J; ++j) G[p][j] *= ip;
+#pragma unroll
+        for (int j = 0; j < NRHS; ++j) R[p][j] *= ip;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            if (i == p) continue;
+            const double f = G[i][p];
+#pragma unroll
+            for (int j = p + 1; j < J; ++j) G[i][j] = fma(-f, G[p][j], G[i][j]);
+#pragma unroll
+            for (int j = 0; j < NRHS; ++j) R[i][j] = fma(-f, R[p][j], R[i][j]);
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void tp_form_G(const TpSlot<J> &e1, const TpSlot<J> &e2, double (&G)[J][J])
+{
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double g = i == j ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < J; ++k) g = fma(e1.C(i, k), e2.Jm(k, j), g);
+            G[i][j] = g;
+        }
+}
+
+// Information part and likelihood of e1 o e2:  with XA = G^-1 A1 and t = eta2 - J2 b1,
+//   eta = XA^T t + eta1,  Jm = A1^T (J2 XA) + J1  (J2 G^-1 = (J2^-1 + C1)^-1 is symmetric),
+//   kq += 1/2 b1^T (eta2 + t) + 1/2 t^T G^-1 C1 t,  det G into (kdm, kde)
+template <int J> struct TpInfoPart {
+    double eta[J];
+    Sym<J> Jm;
+    double k[5];
+    __device__ __forceinline__ void compute(const double *slot1, const double *slot2)
+    {
+        const TpSlot<J> e1{const_cast<double *>(slot1)}, e2{const_cast<double *>(slot2)};
+        double G[J][J], R[J][J + 1], t[J];  // R = [A1 | C1 t]
+        tp_form_G<J>(e1, e2, G);
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double u = e2.eta(i);
+#pragma unroll
+            for (int q = 0; q < J; ++q) u = fma(-e2.Jm(i, q), e1.b(q), u);
+            t[i] = u;
+        }
+        double lin = 0.0;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double c1t = 0.0;
+#pragma unroll
+            for (int q = 0; q < J; ++q) c1t = fma(e1.C(i, q), t[q], c1t);
+            R[i][J] = c1t;
+#pragma unroll
+            for (int j = 0; j < J; ++j) R[i][j] = e1.A(i, j);
+            lin = fma(0.5 * e1.b(i), e2.eta(i) + t[i], lin);
+        }
+        double dm = e1.k(1) * e2.k(1), de = e1.k(2) + e2.k(2);
+        de += (double)__builtin_amdgcn_frexp_exp(dm);
+        dm = __builtin_amdgcn_frexp_mant(dm);
+        tp_eliminate<J, J + 1>(G, R, dm, de);
+        double quad = 0.0;
+#pragma unroll
+        for (int i = 0; i < J; ++i) quad = fma(0.5 * t[i], R[i][J], quad);
+        k[0] = e1.k(0) + e2.k(0) + lin + quad;
+        k[1] = dm;
+        k[2] = de;
+        k[3] = dm > 0.0 ? fmin(e1.k(3), e2.k(3)) : __builtin_nan("");
+        k[4] = e1.k(4) + e2.k(4) + fabs(lin) + fabs(quad);
+        double Z[J][J];  // J2 XA
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double u = 0.0;
+#pragma unroll
+                for (int q = 0; q < J; ++q) u = fma(e2.Jm(i, q), R[q][j], u);
+                Z[i][j] = u;
+            }
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            double u = e1.eta(i);
+#pragma unroll
+            for (int q = 0; q < J; ++q) u = fma(R[q][i], t[q], u);
+            eta[i] = u;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double v = e1.Jm(i, j);
+#pragma unroll
+                for (int q = 0; q < J; ++q) v = fma(e1.A(q, i), Z[q][j], v);
+                Jm(i, j) = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(double *slot) const
+    {
+        const TpSlot<J> d{slot};
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            d.eta(i) = eta[i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) d.Jm(i, j) = Jm(i, j);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) d.k(i) = k[i];
+    }
+};
+
+// State part of e1 o e2:  A = A2 G^-1 A1,  b = A2 G^-1 (b1 + C1 eta2) + b2  (WHAT & 1),
+//                         C = A2 G^-1 C1 A2^T + C2  (WHAT & 2)
+template <int J, int WHAT> struct TpStatePart {
+    static constexpr bool AB = (WHAT & 1) != 0, CC = (WHAT & 2) != 0;
+    static constexpr int NA = AB ? J + 1 : 0, NRHS = NA + (CC ? J : 0);
+    double A[AB ? J : 1][AB ? J : 1], b[AB ? J : 1];
+    Sym<CC ? J : 1> C;
+    __device__ __forceinline__ void compute(const double *slot1, const double *slot2)
+    {
+        const TpSlot<J> e1{const_cast<double *>(slot1)}, e2{const_cast<double *>(slot2)};
+        double G[J][J], R[J][NRHS];  // R = [A1 | b1 + C1 eta2 | C1]
+        tp_form_G<J>(e1, e2, G);
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            if (AB) {
+                double w = e1.b(i);
+#pragma unroll
+                for (int q = 0; q < J; ++q) w = fma(e1.C(i, q), e2.eta(q), w);
+                R[i][J] = w;
+#pragma unroll
+                for (int j = 0; j < J; ++j) R[i][j] = e1.A(i, j);
+            }
+            if (CC) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) R[i][NA + j] = e1.C(i, j);
+            }
+        }
+        double dm = 1.0, de = 0.0;
+        tp_eliminate<J, NRHS>(G, R, dm, de);
+        if (AB) {
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                double u = e2.b(i);
+#pragma unroll
+                for (int q = 0; q < J; ++q) u = fma(e2.A(i, q), R[q][J], u);
+                b[i] = u;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q < J; ++q) v = fma(e2.A(i, q), R[q][j], v);
+                    A[i][j] = v;
+                }
+            }
+        }
+        if (CC) {
+            double Y[J][J];
+#pragma unroll
+            for (int i = 0; i < J; ++i)
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q < J; ++q) v = fma(e2.A(i, q), R[q][NA + j], v);
+                    Y[i][j] = v;
+                }
+#pragma unroll
+            for (int i = 0; i < J; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double v = e2.C(i, j);
+#pragma unroll
+                    for (int q = 0; q < J; ++q) v = fma(Y[i][q], e2.A(j, q), v);
+                    C(i, j) = v;
+                }
+        }
+    }
+    __device__ __forceinline__ void store(double *slot) const
+    {
+        const TpSlot<J> d{slot};
+        if (AB) {
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                d.b(i) = b[i];
+#pragma unroll
+                for (int j = 0; j < J; ++j) d.A(i, j) = A[i][j];
+            }
+        }
+        if (CC) {
+#pragma unroll
+            for (int i = 0; i < J; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) d.C(i, j) = C(i, j);
+        }
+    }
+};
+
+// Reduction of the 256 chunk elements of a four-wave workgroup to the element of the whole series, in
+// slot 0.  Only the likelihood is wanted, so a tree of 255 combinations does instead of a scan, and the
+// lanes it leaves idle share each combination: the parts of e1 o e2 are independent once G = I + C1 J2 is
+// eliminated, so one WAVE computes the information part of all the level's combinations, another (A, b),
+// a third C -- each eliminating G for itself, ~4.5 J^3 multiply-adds instead of 10 J^3 per level (roles
+// must be wave-uniform: lanes of one wave on different parts would run one after the other).  Level 0 has
+// 128 combinations: two waves take the information parts, two the whole state part.
+// Layout: a level with n elements keeps element i in slot (i >> 1) + (i & 1) * n/2 -- left operands in
+// the first half, right operands in the second -- so that the lanes of a wave, working on consecutive
+// combinations, read consecutive slots (odd stride in doubles: no bank conflicts; slots 2c and 2c + 1 would
+// put four lanes on every bank, and the strided survivors of an in-place tree up to all of them).
+// Results are written after a barrier (the other waves read the same operands).
+__device__ __forceinline__ int tp_tree_slot(int i, int n) { return (i >> 1) + (i & 1) * (n >> 1); }
+
+template <int J>
+__device__ __forceinline__ void tp_reduce_tree(double *buf)
+{
+    constexpr int ELEM = MTG_TP_ELEM(J);
+    const int wave = threadIdx.x >> 6, sub = threadIdx.x & 63;
+    TpInfoPart<J> info;
+    {   // level 0: 256 elements, combinations c < 128
+        const int c = (wave & 1) * 64 + sub;
+        const double *L = buf + c * ELEM, *R = buf + (128 + c) * ELEM;
+        double *out = buf + tp_tree_slot(c, 128) * ELEM;
+        TpStatePart<J, 3> state;
+        if (wave < 2) info.compute(L, R);
+        else state.compute(L, R);
+        __syncthreads();  // every wave has read its operands
+        if (wave < 2) info.store(out);
+        else state.store(out);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int n = 128; n > 1; n >>= 1) {  // n elements, n / 2 <= 64 combinations
+        const bool active = sub < (n >> 1);
+        const int c = active ? sub : 0;
+        const double *L = buf + c * ELEM, *R = buf + ((n >> 1) + c) * ELEM;
+        double *out = buf + tp_tree_slot(c, n >> 1) * ELEM;
+        TpStatePart<J, 1> ab;
+        TpStatePart<J, 2> cc;
+        if (active) {
+            if (wave == 0) info.compute(L, R);
+            else if (wave == 1) ab.compute(L, R);
+            else if (wave == 2) cc.compute(L, R);
+        }
+        __syncthreads();
+        if (active) {
+            if (wave == 0) info.store(out);
+            else if (wave == 1) ab.store(out);
+            else if (wave == 2) cc.store(out);
+        }
+        __syncthreads();
+    }
+}
+
 // Element <-> its LDS slot (A | b | eta | C | Jm | kq kdm kde kmin kmag)
 template <int J>
 __device__ __forceinline__ void tp_store(const TpElem<J> &e, double *slot)
@@ -914,14 +1182,39 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     if (hi > N) hi = N;
     if (lo == 0) lo = 1;
 
-    // ---- pass 1: element of the chunk, with the chunk's likelihood given x_in = 0 -----------
-    TpElem<J> e;
-    tp_identity<J>(e);
-    tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
-    {
+    // filtered state after sample 0 (update of the stationary prior), identical on every lane; computed where
+    // it is used, not kept across the passes
+    auto head_state = [&](double *m, Sym<J> &C, double &D0, double &z0) {
+#pragma unroll
+        for (int i = 0; i < J * (J + 1) / 2; ++i) C.v[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) C(j, j) = M.ar[j];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int o = NR + 2 * k;
+            C(o, o) = M.ac[k]; C(o + 1, o) = -M.bc[k]; C(o + 1, o + 1) = M.pc[k];
+        }
+        double ch[J];
+        tp_C_h<NR, NC, J>(C, ch);
+        D0 = tp_h_dot<NR, NC>(ch) + yv[0].y + jitter;
+        z0 = yv[0].x - fma(slope, dxt[0].y, icpt);
+#pragma unroll
+        for (int i = 0; i < J; ++i) m[i] = ch[i] * z0 / D0;
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) C(i, j) -= ch[i] * ch[j] / D0;
+    };
+    int *flag = (int *)(red + 3 * (LANES / 64));
+    double *buf = elems;
+    // ---- pass 1: element of the chunk, with the chunk's likelihood given x_in = 0, into the lane's slot ----
+    auto compose_chunk = [&](int slot) {
+        TpElem<J> e;
+        tp_identity<J>(e);
+        tp_sub_pinf<NR, NC, J>(M, e.C);  // e.C holds C - P_inf inside the loop
         double kap[3] = {0.0, 1.0, INFINITY};
         int kexp = 0;
-        TpSamples q(yv, dxt, lo, N);
+        TpSamples<MTG_TP_AHEAD_OF(J)> q(yv, dxt, lo, N);
         for (int64_t n = lo; n < hi; ++n) {
             const double2 sy = q.y[0], sx = q.x[0];
             q.advance(yv, dxt, n, N);
@@ -933,13 +1226,50 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
             kap[1] = __builtin_amdgcn_frexp_mant(kap[1]);
         }
         e.kq = -0.5 * kap[0]; e.kdm = kap[1]; e.kde = (double)kexp; e.kmin = kap[2]; e.kmag = 0.5 * kap[0];
-    }
-    tp_add_pinf<NR, NC, J>(M, e.C);
+        tp_add_pinf<NR, NC, J>(M, e.C);
+        tp_store<J>(e, elems + slot * ELEM);
+        __syncthreads();
+    };
+    // The element of samples 1 .. N-1 (in `slot`) integrated against the state after sample 0 is the
+    // likelihood.  Anything suspicious sends the evaluation through pass 3.  Returns "done" (workgroup-uniform).
+    auto finish = [&](const double *slot, int owner) -> bool {
+        if (lane == owner) {
+            const TpSlot<J> tot{const_cast<double *>(slot)};
+            double m[J], D0, z0;
+            Sym<J> C;
+            head_state(m, C, D0, z0);
+            double eta[J];
+            Sym<J> Jm;
+#pragma unroll
+            for (int i = 0; i < J; ++i) eta[i] = tot.eta(i);
+#pragma unroll
+            for (int i = 0; i < J; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) Jm(i, j) = tot.Jm(i, j);
+            const double corr = tp_chunk_correction<J>(eta, Jm, m, C);
+            const double ld = log(tot.k(1)) + tot.k(2) * 0.69314718055994530942 + log(D0);
+            const double q0 = 0.5 * z0 * z0 / D0;
+            const double ll = tot.k(0) + corr - q0 - 0.5 * (ld + (double)N * MTG_LN_2PI);
+            const double mag = tot.k(4) + fabs(corr) + q0;
+            const bool good = direct && fmin(tot.k(3), D0) > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll);
+            if (good) { a.out[ev] = ll; a.status[ev] = MTG_ST_OK; }
+            *flag = good ? 0 : 1;
+        }
+        __syncthreads();
+        return *flag == 0;
+    };
 
-    // ---- pass 2: inclusive scan of the chunk elements (Hillis-Steele through LDS) -----------
-    double *buf = elems;
-    tp_store<J>(e, buf + lane * ELEM);
-    __syncthreads();
+    constexpr bool TREE = LANES == 256 && MTG_TP_TREE;
+    compose_chunk(TREE && direct ? tp_tree_slot(lane, LANES) : lane);
+    // ---- pass 2 ------------------------------------------------------------------------------------------
+    // Four waves: a tree reduces the chunk elements to the element of the whole series (tp_reduce_tree) -- no
+    // prefixes, so an evaluation that turns out to need pass 3 composes its chunks a second time and scans them.
+    if (TREE && direct) {
+        if constexpr (TREE) tp_reduce_tree<J>(buf);
+        if (finish(buf, 0)) return;
+        compose_chunk(lane);
+    }
+    // inclusive scan of the chunk elements (Hillis-Steele through LDS): lane l gets the element of chunks 0 .. l
     if (MTG_TP_PINGPONG(J)) {  // two buffers: read the round's inputs from one, write its outputs to the other
         double *nxt = elems + LANES * ELEM;
         for (int off = 1; off < LANES; off <<= 1) {
@@ -958,58 +1288,13 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
             __syncthreads();
         }
     }
-    // filtered state after sample 0 (update of the stationary prior), identical on every lane
-    double m[J];
-    Sym<J> C;
-#pragma unroll
-    for (int i = 0; i < J; ++i) m[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) C.v[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) C(j, j) = M.ar[j];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const int o = NR + 2 * k;
-        C(o, o) = M.ac[k]; C(o + 1, o) = -M.bc[k]; C(o + 1, o + 1) = M.pc[k];
-    }
-    double ch[J];
-    tp_C_h<NR, NC, J>(C, ch);
-    const double D0 = tp_h_dot<NR, NC>(ch) + yv[0].y + jitter;
-    const double z0 = yv[0].x - fma(slope, dxt[0].y, icpt);
-#pragma unroll
-    for (int i = 0; i < J; ++i) m[i] = ch[i] * z0 / D0;
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) C(i, j) -= ch[i] * ch[j] / D0;
-
-    // ---- the last lane holds the element of samples 1 .. N-1: integrated against the state after
-    // sample 0 it is the likelihood.  Anything suspicious sends the evaluation through pass 3.
-    int *flag = (int *)(red + 3 * (LANES / 64));
-    if (lane == LANES - 1) {
-        const TpSlot<J> tot{buf + lane * ELEM};
-        double eta[J];
-        Sym<J> Jm;
-#pragma unroll
-        for (int i = 0; i < J; ++i) eta[i] = tot.eta(i);
-#pragma unroll
-        for (int i = 0; i < J; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) Jm(i, j) = tot.Jm(i, j);
-        const double corr = tp_chunk_correction<J>(eta, Jm, m, C);
-        const double ld = log(tot.k(1)) + tot.k(2) * 0.69314718055994530942 + log(D0);
-        const double q0 = 0.5 * z0 * z0 / D0;
-        const double ll = tot.k(0) + corr - q0 - 0.5 * (ld + (double)N * MTG_LN_2PI);
-        const double mag = tot.k(4) + fabs(corr) + q0;
-        const bool good = direct && fmin(tot.k(3), D0) > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll);
-        if (good) { a.out[ev] = ll; a.status[ev] = MTG_ST_OK; }
-        *flag = good ? 0 : 1;
-    }
-    __syncthreads();
-    if (*flag == 0) return;  // (uniform over the workgroup: one evaluation)
+    if (!(TREE && direct) && finish(buf + (LANES - 1) * ELEM, LANES - 1)) return;
 
     // ---- pass 3: ordinary Kalman filter over the chunk from its start state -----------------
     // start state of this lane's chunk: the prefix of the earlier chunks applied to the state after sample 0
+    double m[J], D0, z0;
+    Sym<J> C;
+    head_state(m, C, D0, z0);
     if (lane > 0) {
         TpElem<J> pre;
         tp_load<J>(pre, buf + (lane - 1) * ELEM);
@@ -1020,7 +1305,7 @@ __device__ __forceinline__ void mtg_tp_body(const MtgSolveArgs &a, const TpModel
     double dprod = 1.0;
     int dexp = 0;
     tp_sub_pinf<NR, NC, J>(M, C);  // deviation form from here on
-    TpSamples q(yv, dxt, lo, N);
+    TpSamples<MTG_TP_AHEAD_OF(J)> q(yv, dxt, lo, N);
     for (int64_t n = lo; n < hi; ++n) {
         const double2 sy = q.y[0], sx = q.x[0];
         q.advance(yv, dxt, n, N);
