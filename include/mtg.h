@@ -226,6 +226,41 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
 
 /*
+ * Walker sharding of the resident ensembles across the GPUs of a job (one process per GPU; the
+ * reference's counterpart is the multiprocessing.Pool.map over the half-ensemble of
+ * mind_the_gaps/gpmodelling.py:245-248).  Every process calls mtg_ensemble_init with the SAME
+ * coordinates and seed, then one of the two calls below with its rank: from then on
+ * mtg_ensemble_run evaluates only rows [rank * chunk, (rank + 1) * chunk), chunk = ceil(E * W/2 /
+ * world), of every half-step's proposals and gets the others' log-probabilities (8 bytes per
+ * walker and a status word) before the accept step, which every rank then takes identically:
+ * all ranks hold the same chain.  A row is evaluated by the same kernel whatever the rank, but the
+ * kernel is chosen by the number of rows a rank evaluates: chains agree bit for bit with the
+ * one-process chain when that choice is the same (always with mtg_set_time_parallel(ctx, 0)).
+ *
+ *  mtg_ensemble_shard_rccl   one ncclAllGather of doubles and one of int32 per half-step, grouped,
+ *                            on the context's stream: no host synchronisation in the run.  id128:
+ *                            the 128-byte ncclUniqueId made by ONE process with
+ *                            mtg_rccl_unique_id and handed to the others by the caller (any
+ *                            channel: torch.distributed.broadcast, MPI, a file).  Collective:
+ *                            returns when every rank of `world` has called it.  librccl.so.1 is
+ *                            looked up at run time, the copy already loaded in the process first
+ *                            (mtg_rccl_load(path) names one explicitly before anything else loads it).
+ *  mtg_ensemble_shard_host   the exchange is a callback of the caller (another transport: gloo,
+ *                            MPI ...; or processes that share one GPU, which RCCL refuses): after
+ *                            each half-step's solve the library hands it host arrays lnp[count],
+ *                            status[count] with rows [lo, hi) filled in; it must fill in all others
+ *                            (the chunk layout above) and return 0.  Synchronises the stream twice per
+ *                            half-step.
+ *  mtg_ensemble_unshard      back to every row on this process.  mtg_ensemble_init also resets it.
+ */
+typedef int (*mtg_exchange_fn)(void *user, double *lnp, int32_t *status, int64_t count, int64_t lo, int64_t hi);
+MTG_API int mtg_rccl_load(const char *path);
+MTG_API int mtg_rccl_unique_id(void *id128);
+MTG_API int mtg_ensemble_shard_rccl(mtg_ctx *ctx, const void *id128, int rank, int world);
+MTG_API int mtg_ensemble_shard_host(mtg_ctx *ctx, int rank, int world, mtg_exchange_fn fn, void *user);
+MTG_API int mtg_ensemble_unshard(mtg_ctx *ctx);
+
+/*
  * Posterior-predictive light-curve simulation, the step before the hot path in the
  * Protassov loop: GPModelling.generate_from_posteriors (gpmodelling.py:478-539) ->
  * Simulator.generate_lightcurve + add_noise (simulator.py:300-420, get_fft :468-501),

@@ -4,6 +4,7 @@
 #include "mtg_tp_scan.h"
 #include "mtg_trace.h"
 
+#include <dlfcn.h>
 #include <hipfft/hipfft.h>
 
 #include <math.h>
@@ -84,6 +85,18 @@ struct mtg_ctx {
     int64_t ens_L = 0, ens_N = 0;  // shape of the resident set the ensembles index into
     DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
         ens_naccept, ens_best_lnp, ens_best_coords, ens_notpd, ens_chain, ens_lnp_chain;
+    // walker sharding (mtg_ensemble_shard_*): this rank evaluates rows [shard_lo, shard_hi) of every
+    // half-step's proposals; the exchange brings everybody's log-probabilities before the accept step
+    int shard_kind = 0;  // 0 none, 1 RCCL all-gather on the stream, 2 host callback
+    int shard_rank = 0, shard_world = 1;
+    int64_t shard_chunk = 0, shard_lo = 0, shard_hi = 0;
+    void *shard_comm = nullptr;         // ncclComm_t
+    mtg_exchange_fn shard_fn = nullptr;
+    void *shard_user = nullptr;
+    double *shard_h_lnp = nullptr;      // pinned staging of the host exchange
+    int32_t *shard_h_st = nullptr;
+    int64_t shard_h_rows = 0;
+    int64_t live_rows = 0;              // rows the next solve really evaluates (0: all) -- kernel choice only
 
     // side streams: the structures (signatures) of a small batch run next to each other
     hipStream_t side[MTG_MAX_J / 2] = {};
@@ -96,6 +109,9 @@ struct mtg_ctx {
 };
 
 namespace {
+
+void shard_release(mtg_ctx *ctx);
+int shard_exchange(mtg_ctx *ctx, int64_t EH, hipStream_t s);
 
 int fail(mtg_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -188,6 +204,8 @@ MtgPrepArgs make_prep_args(mtg_ctx *ctx, int64_t B, const double *d_theta, int a
     pa.out = d_out;
     pa.status = d_status;
     pa.sig = ctx->sig.as<int32_t>();  // structure of every evaluation: the rank-10 time-parallel path dispatches on it
+    pa.row_lo = 0;
+    pa.row_hi = INT64_MAX;
     return pa;
 }
 
@@ -287,9 +305,11 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // path costs ~3 x the serial sweep's work per sample, spread over every SIMD instead of B / 64 of
     // them, against ~1.05 us x N for the serial sweep whatever B <= 65 536 is.
     const int Jmodel = m.nr0 + 2 * m.nc0;
+    // rows that do work: a walker-sharded half-step skips the rows of the other ranks (MTG_ST_REMOTE)
+    const int64_t Bw = ctx->live_rows > 0 ? ctx->live_rows : B;
     bool pays;
-    if (Jmodel <= 6) pays = ctx->N >= 256 && B <= 1024;
-    else pays = ctx->N >= 1024 && B <= 8192;
+    if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= 1024;
+    else pays = ctx->N >= 1024 && Bw <= 8192;
     const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
@@ -301,8 +321,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     if (small && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
             if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
-        const int C = mtg_tp_big_chunks(ctx->N, B);
-        int g = mtg_tp_big_gsize(B, C);
+        const int C = mtg_tp_big_chunks(ctx->N, Bw);
+        int g = mtg_tp_big_gsize(Bw, C);
         if (const char *env = getenv("MTG_TP_GSIZE")) {  // measurements only
             const int v = atoi(env);
             if (v == 4 || v == 8 || v == 16) g = v;
@@ -316,7 +336,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             sa.tp_gsize = g;
         }
     }
-    const bool wide = B <= 256 && ctx->N >= 4096;  // four waves per evaluation
+    const bool wide = Bw <= 256 && ctx->N >= 4096;  // four waves per evaluation
     mtg_solve_launcher fused = nullptr;
     if (small_ok && nsig > 1) {
         if (wide) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256);
@@ -435,6 +455,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
                       &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,
                       &ctx->ens_lnp_chain};
     for (DevBuf *b : bufs) b->release();
+    shard_release(ctx);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipStream_t st : ctx->side) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
@@ -825,6 +846,188 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
     HIP_TRY(ctx, hipStreamSynchronize(s));  // lc_full / lc_half live on this stack frame
     ctx->ens_E = E; ctx->ens_W = W; ctx->ens_P = P; ctx->ens_seed = seed; ctx->ens_iteration = 0;
     ctx->ens_L = ctx->L; ctx->ens_N = ctx->N;
+    shard_release(ctx);  // a new set of ensembles starts unsharded (mtg_ensemble_shard_* after this call)
+    return MTG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Walker sharding of the device-resident ensembles (replaces the reference's
+// multiprocessing.Pool.map per half-step, gpmodelling.py:245-248)
+// ---------------------------------------------------------------------------
+// Every rank runs the whole sampler -- same Philox key, same proposals, same accept step -- but evaluates
+// only rows [rank * chunk, (rank + 1) * chunk) of each half-step's proposals; one all-gather of the
+// log-probabilities (8 bytes per walker, plus the status word) on the launch stream brings the rest
+// before the accept kernel.  RCCL is looked up at run time: a process that has PyTorch loaded must use
+// PyTorch's copy of librccl.so.1 (two copies in one process is asking for trouble), and a library
+// linked against /opt/rocm's would bring that one in first.
+namespace {
+
+struct Id128 { char b[128]; };  // ncclUniqueId
+struct Rccl {
+    void *lib = nullptr;
+    // (ncclComm_t, ncclUniqueId, ncclDataType_t of rccl.h, restated as plain types)
+    int (*GetUniqueId)(void *id128) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, Id128 id, int rank) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+} g_rccl;
+enum { RCCL_INT32 = 2, RCCL_FLOAT64 = 8 };  // ncclInt32, ncclFloat64
+
+bool rccl_load(const char *path)
+{
+    if (g_rccl.lib) return true;
+    void *h = nullptr;
+    if (path && *path) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the copy already in the process (PyTorch's)
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        g_rccl.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+        return false;
+    }
+    auto sym = [&](const char *n) { return dlsym(h, n); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GroupStart ||
+        !g_rccl.GroupEnd || !g_rccl.GetErrorString) {
+        g_rccl.why = "librccl.so.1 lacks one of the nccl* entry points";
+        return false;
+    }
+    g_rccl.lib = h;
+    return true;
+}
+
+#define RCCL_TRY(ctx, call)                                                                          \
+    do {                                                                                             \
+        int r__ = (call);                                                                            \
+        if (r__ != 0) return fail((ctx), MTG_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r__)); \
+    } while (0)
+
+void shard_release(mtg_ctx *ctx)
+{
+    if (ctx->shard_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->shard_comm);
+    if (ctx->shard_h_lnp) (void)hipHostFree(ctx->shard_h_lnp);
+    if (ctx->shard_h_st) (void)hipHostFree(ctx->shard_h_st);
+    ctx->shard_comm = nullptr; ctx->shard_h_lnp = nullptr; ctx->shard_h_st = nullptr; ctx->shard_h_rows = 0;
+    ctx->shard_kind = 0; ctx->shard_rank = 0; ctx->shard_world = 1;
+    ctx->shard_chunk = ctx->shard_lo = ctx->shard_hi = 0;
+    ctx->shard_fn = nullptr; ctx->shard_user = nullptr;
+}
+
+// rows of the half-step batch this rank evaluates, and buffers large enough for the padded all-gather
+int shard_layout(mtg_ctx *ctx, int rank, int world)
+{
+    if (ctx->ens_E <= 0) return fail(ctx, MTG_E_STATE, "mtg_ensemble_init has not been called");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, MTG_E_ARG, "mtg_ensemble_shard: rank %d of %d", rank, world);
+    const int64_t EH = ctx->ens_E * (ctx->ens_W / 2);
+    const int64_t chunk = (EH + world - 1) / world;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    shard_release(ctx);
+    // (DevBuf::reserve keeps the contents only when it does not grow: the buffers hold nothing between runs)
+    HIP_TRY(ctx, ctx->ens_new.reserve((size_t)std::max<int64_t>(ctx->ens_E * ctx->ens_W, chunk * world) * 8));
+    HIP_TRY(ctx, ctx->ens_st.reserve((size_t)std::max<int64_t>(ctx->ens_E * ctx->ens_W, chunk * world) * 4));
+    ctx->shard_rank = rank; ctx->shard_world = world; ctx->shard_chunk = chunk;
+    ctx->shard_lo = std::min<int64_t>((int64_t)rank * chunk, EH);
+    ctx->shard_hi = std::min<int64_t>(ctx->shard_lo + chunk, EH);
+    return MTG_OK;
+}
+
+// after the solve of a half-step: everybody's log-probabilities and status words into ens_new / ens_st
+int shard_exchange(mtg_ctx *ctx, int64_t EH, hipStream_t s)
+{
+    double *lnp = ctx->ens_new.as<double>();
+    int32_t *st = ctx->ens_st.as<int32_t>();
+    const int64_t chunk = ctx->shard_chunk, lo = ctx->shard_lo, hi = ctx->shard_hi;
+    if (ctx->shard_kind == 1) {
+        mtg_trace::Range range("mtg:all-gather of the half-step's log-probabilities (RCCL)");
+        // in place: this rank's block already sits at rank * chunk of the receive buffer
+        const int64_t at = (int64_t)ctx->shard_rank * chunk;
+        RCCL_TRY(ctx, g_rccl.GroupStart());
+        RCCL_TRY(ctx, g_rccl.AllGather(lnp + at, lnp, (size_t)chunk, RCCL_FLOAT64, ctx->shard_comm, s));
+        RCCL_TRY(ctx, g_rccl.AllGather(st + at, st, (size_t)chunk, RCCL_INT32, ctx->shard_comm, s));
+        RCCL_TRY(ctx, g_rccl.GroupEnd());
+        return MTG_OK;
+    }
+    // host callback: stage this rank's rows, let the caller fill in the others, upload everything
+    mtg_trace::Range range("mtg:exchange of the half-step's log-probabilities (host callback)");
+    if (ctx->shard_h_rows < EH) {
+        if (ctx->shard_h_lnp) (void)hipHostFree(ctx->shard_h_lnp);
+        if (ctx->shard_h_st) (void)hipHostFree(ctx->shard_h_st);
+        ctx->shard_h_lnp = nullptr; ctx->shard_h_st = nullptr; ctx->shard_h_rows = 0;
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->shard_h_lnp, (size_t)EH * 8));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->shard_h_st, (size_t)EH * 4));
+        ctx->shard_h_rows = EH;
+    }
+    if (hi > lo) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->shard_h_lnp + lo, lnp + lo, (size_t)(hi - lo) * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->shard_h_st + lo, st + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    const int rc = ctx->shard_fn(ctx->shard_user, ctx->shard_h_lnp, ctx->shard_h_st, EH, lo, hi);
+    if (rc) return fail(ctx, MTG_E_STATE, "the exchange callback of the walker-sharded ensemble returned %d", rc);
+    HIP_TRY(ctx, hipMemcpyAsync(lnp, ctx->shard_h_lnp, (size_t)EH * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(st, ctx->shard_h_st, (size_t)EH * 4, hipMemcpyHostToDevice, s));
+    return MTG_OK;
+}
+
+}  // namespace
+
+MTG_API int mtg_rccl_load(const char *path)
+{
+    return rccl_load(path) ? MTG_OK : MTG_E_UNSUPPORTED;
+}
+
+MTG_API int mtg_rccl_unique_id(void *id128)
+{
+    if (!id128) return MTG_E_ARG;
+    if (!rccl_load(nullptr)) return MTG_E_UNSUPPORTED;
+    return g_rccl.GetUniqueId(id128) == 0 ? MTG_OK : MTG_E_HIP;
+}
+
+MTG_API int mtg_ensemble_shard_rccl(mtg_ctx *ctx, const void *id128, int rank, int world)
+{
+    if (!ctx || !id128) return MTG_E_ARG;
+    if (!rccl_load(nullptr)) return fail(ctx, MTG_E_UNSUPPORTED, "%s", g_rccl.why.c_str());
+    int rc = shard_layout(ctx, rank, world);
+    if (rc) return rc;
+    Id128 id;
+    memcpy(id.b, id128, sizeof id.b);
+    void *comm = nullptr;
+    RCCL_TRY(ctx, g_rccl.CommInitRank(&comm, world, id, rank));
+    ctx->shard_comm = comm;
+    ctx->shard_kind = 1;
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_shard_host(mtg_ctx *ctx, int rank, int world, mtg_exchange_fn fn, void *user)
+{
+    if (!ctx || !fn) return MTG_E_ARG;
+    int rc = shard_layout(ctx, rank, world);
+    if (rc) return rc;
+    ctx->shard_fn = fn;
+    ctx->shard_user = user;
+    ctx->shard_kind = 2;
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_unshard(mtg_ctx *ctx)
+{
+    if (!ctx) return MTG_E_ARG;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    shard_release(ctx);
     return MTG_OK;
 }
 
@@ -849,8 +1052,18 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     if (rc) return rc;
     // the accept kernel leaves the structure counters cleared for the next expansion; clear them once here
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
-    const MtgPrepArgs pa = make_prep_args(ctx, EH, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(),
-                                          ctx->ens_st.as<int32_t>());
+    MtgPrepArgs pa = make_prep_args(ctx, EH, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(),
+                                    ctx->ens_st.as<int32_t>());
+    const bool sharded = ctx->shard_kind != 0;
+    if (sharded) {
+        pa.row_lo = ctx->shard_lo;
+        pa.row_hi = ctx->shard_hi;
+    }
+    struct LiveRows {  // the solver's kernel choice looks at the rows this rank evaluates
+        mtg_ctx *c;
+        LiveRows(mtg_ctx *ctx_, int64_t n) : c(ctx_) { c->live_rows = n; }
+        ~LiveRows() { c->live_rows = 0; }
+    } live_rows(ctx, sharded ? (ctx->shard_hi > ctx->shard_lo ? ctx->shard_hi - ctx->shard_lo : 1) : 0);
     for (int it = 0; it < steps; ++it) {
         const uint32_t iter = ctx->ens_iteration;
         for (int half = 0; half < 2; ++half) {
@@ -859,6 +1072,10 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
             rc = solve_prepared(ctx, EH, ctx->ens_lc_half.as<int32_t>(), ctx->ens_new.as<double>(),
                                 ctx->ens_st.as<int32_t>(), s);
             if (rc) return rc;
+            if (sharded) {
+                rc = shard_exchange(ctx, EH, s);
+                if (rc) return rc;
+            }
             const bool last = half == 1;
             mtg_launch_accept(E, W, P, half, iter, ctx->ens_seed, ctx->ens_perm.as<int32_t>(),
                               ctx->ens_q.as<double>(), ctx->ens_factor.as<double>(), ctx->ens_new.as<double>(),

@@ -57,7 +57,13 @@ struct MtgPrepArgs {
     double *out;    // [B]
     int32_t *status;  // [B]
     int32_t *sig;   // [B] number of over-damped SHO terms per evaluation, or NULL
+    // a walker-sharded ensemble expands and solves only rows [row_lo, row_hi); the others get MTG_ST_REMOTE
+    // (skipped by every solver like a prior rejection) until the all-gather brings the owner's result
+    int64_t row_lo, row_hi;
 };
+
+// status of a row another rank evaluates (internal: never visible after the exchange)
+#define MTG_ST_REMOTE 4
 
 struct MtgSolveArgs {
     const double *coef;

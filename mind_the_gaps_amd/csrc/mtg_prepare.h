@@ -18,8 +18,9 @@ __device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e,
         return s >= 0 ? th[s] : m.defaults[k];
     };
 
-    bool ok = live;
-    if (live && a.add_prior) {
+    const bool mine = e >= a.row_lo && e < a.row_hi;
+    bool ok = live && mine;
+    if (ok && a.add_prior) {
         // celerite Model.log_prior: every parameter, frozen ones included
         for (int k = 0; k < m.PF; ++k) {
             const double v = par(k);
@@ -35,8 +36,8 @@ __device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e,
         }
     }
     if (live) {
-        a.status[e] = ok ? MTG_ST_OK : MTG_ST_PRIOR;
-        if (!ok) a.out[e] = -INFINITY;
+        a.status[e] = ok ? MTG_ST_OK : mine ? MTG_ST_PRIOR : MTG_ST_REMOTE;
+        if (!ok && mine) a.out[e] = -INFINITY;
     }
 
     int nover = 0;

@@ -24,7 +24,7 @@ class DeviceEnsembleSampler:
     """
 
     def __init__(self, bind, nwalkers, ndim, n_ensembles=1, lc_of_ensemble=None, seed=None,
-                 store_chain=True):
+                 store_chain=True, shard_group=False, shard_transport=None):
         if nwalkers < 2 * ndim:
             raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than "
                                "twice the number of dimensions.")
@@ -36,6 +36,9 @@ class DeviceEnsembleSampler:
         # like emcee, reproducible from numpy's global state when no seed is given
         self.seed = int(np.random.randint(0, 2 ** 62)) if seed is None else int(seed)
         self.store_chain = store_chain
+        # walker sharding: False = none; None = the default process group; or a torch.distributed group.  Every
+        # rank then holds the same chain (distributed.shard_device_ensemble).
+        self.shard_group, self.shard_transport = shard_group, shard_transport
         self.iteration = 0
         self._chain = np.empty((0, self.E, self.nwalkers, self.ndim))
         self._log_prob = np.empty((0, self.E, self.nwalkers))
@@ -51,7 +54,12 @@ class DeviceEnsembleSampler:
                 raise ValueError("incompatible input dimensions {0}".format(p0.shape))
             if not np.all(np.isfinite(p0)):
                 raise ValueError("At least one parameter value was infinite or NaN")
+            if self.shard_group is not False:
+                from .distributed import broadcast_start, shard_device_ensemble
+                p0, self.seed = broadcast_start(p0, self.seed, self.shard_group)
             eng.ensemble_init(p0, seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
+            if self.shard_group is not False:
+                self.transport = shard_device_ensemble(eng, self.shard_group, self.shard_transport)
             self._started = True
             self.iteration = 0
             self._chain = np.empty((0, self.E, self.nwalkers, self.ndim))

@@ -14,7 +14,8 @@ ensemble.  Nothing here computes a likelihood: ``evaluate`` is the engine call.
 import numpy as np
 
 __all__ = ["block_bounds", "shard_rows", "shard_lightcurves", "all_gather_rows",
-           "sharded_log_prob", "LightcurveShard", "WalkerShardedLogProb", "lockstep"]
+           "sharded_log_prob", "LightcurveShard", "WalkerShardedLogProb", "lockstep", "shard_device_ensemble",
+           "broadcast_start"]
 
 
 def block_bounds(n_items, world_size):
@@ -172,3 +173,56 @@ def lockstep(sampler, p0, group=None):
     dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     sampler.random_state = objs[0]
     return objs[1]
+
+
+def broadcast_start(p0, seed, group=None):
+    """Rank 0's starting ensemble and Philox seed to every rank (the reference seeds nothing; each process
+    would draw its own).  Returns the common ``(p0, seed)``."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return np.asarray(p0, dtype=np.float64), int(seed)
+    objs = [np.asarray(p0, dtype=np.float64), int(seed)] if dist.get_rank(group) == 0 else [None, None]
+    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return objs[0], objs[1]
+
+
+def shard_device_ensemble(engine, group=None, transport=None):
+    """Shard the engine's resident ensembles (``mtg_ensemble_init`` done, same coordinates and seed on every
+    rank) across the ranks of ``group``: each evaluates its block of every half-step's proposals.
+
+    ``transport`` "rccl": one grouped ``ncclAllGather`` per half-step on the engine's stream, no host round trip
+    -- the library makes its own communicator from a ``ncclUniqueId`` that rank 0 creates and this function
+    broadcasts over ``group``.  "host": the library stages this rank's rows on the host and the exchange runs
+    over ``group``'s own backend (gloo in the CPU-side tests; also the way for processes that share one GPU,
+    which RCCL refuses).  Default: "rccl" when ``group``'s backend is nccl, else "host"."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return "none"
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if transport is None:
+        transport = "rccl" if dist.get_backend(group) == "nccl" else "host"
+    if transport == "rccl":
+        objs = [engine.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        engine.ensemble_shard_rccl(objs[0], rank, world)
+        return transport
+    if transport != "host":
+        raise ValueError("transport must be 'rccl' or 'host'")
+
+    def exchange(lnp, status, lo, hi):
+        # the library's layout: rank r owns rows [r * chunk, (r + 1) * chunk), chunk = ceil(count / world)
+        count = len(lnp)
+        chunk = -(-count // world)
+        mine = torch.zeros(2 * chunk, dtype=torch.float64)
+        mine[:hi - lo] = torch.from_numpy(lnp[lo:hi])
+        mine[chunk:chunk + hi - lo] = torch.from_numpy(status[lo:hi].astype(np.float64))
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        for r, part in enumerate(parts):
+            a, b = min(r * chunk, count), min((r + 1) * chunk, count)
+            lnp[a:b] = part[:b - a].numpy()
+            status[a:b] = part[chunk:chunk + b - a].numpy().astype(np.int32)
+
+    engine.ensemble_shard_host(rank, world, exchange)
+    return transport

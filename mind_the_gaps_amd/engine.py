@@ -30,8 +30,13 @@ EXPORTS = (
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
     "mtg_math_probe", "mtg_ensemble_init", "mtg_ensemble_run", "mtg_ensemble_get",
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
-    "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series",
+    "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
+    "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
 )
+
+# the exchange of a walker-sharded ensemble as a callback (include/mtg.h, mtg_exchange_fn)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64)
 
 
 class EngineUnavailable(RuntimeError):
@@ -124,6 +129,16 @@ def load_library():
     lib.mtg_ensemble_init.argtypes = [c_vp, c_i64, c_int, ctypes.c_uint64, _dp, _ip]
     lib.mtg_ensemble_run.restype = c_int
     lib.mtg_ensemble_run.argtypes = [c_vp, c_int, _dp, _dp]
+    lib.mtg_rccl_load.restype = c_int
+    lib.mtg_rccl_load.argtypes = [ctypes.c_char_p]
+    lib.mtg_rccl_unique_id.restype = c_int
+    lib.mtg_rccl_unique_id.argtypes = [c_vp]
+    lib.mtg_ensemble_shard_rccl.restype = c_int
+    lib.mtg_ensemble_shard_rccl.argtypes = [c_vp, c_vp, c_int, c_int]
+    lib.mtg_ensemble_shard_host.restype = c_int
+    lib.mtg_ensemble_shard_host.argtypes = [c_vp, c_int, c_int, EXCHANGE_FN, c_vp]
+    lib.mtg_ensemble_unshard.restype = c_int
+    lib.mtg_ensemble_unshard.argtypes = [c_vp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_simulate_tk95.restype = c_int
@@ -193,6 +208,9 @@ class Engine:
 
     def _check(self, rc):
         if rc != 0:
+            pending, self._exchange_error = getattr(self, "_exchange_error", None), None
+            if pending is not None:  # the exchange callback of a walker-sharded ensemble raised
+                raise pending
             raise EngineError(rc, self._lib.mtg_last_error(self._ctx).decode())
 
     # -- data ---------------------------------------------------------------
@@ -320,6 +338,40 @@ class Engine:
         self._check(self._lib.mtg_ensemble_init(self._ctx, coords.shape[0], coords.shape[1],
                                                 int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(coords), _iptr(lc)))
         self._ens_shape = coords.shape
+
+    # -- walker sharding of the resident ensembles (include/mtg.h, mtg_ensemble_shard_*) ------
+    def rccl_unique_id(self):
+        """A fresh ncclUniqueId (128 bytes): made by ONE rank, handed to the others by the caller."""
+        buf = ctypes.create_string_buffer(128)
+        rc = self._lib.mtg_rccl_unique_id(buf)
+        if rc:
+            raise EngineUnavailable("librccl.so.1 could not be loaded (mtg_rccl_unique_id -> %d)" % rc)
+        return buf.raw
+
+    def ensemble_shard_rccl(self, unique_id, rank, world):
+        """This process evaluates its block of every half-step's proposals; ncclAllGather on the
+        engine's stream brings the others' log-probabilities.  Collective over the ``world`` ranks."""
+        if len(unique_id) != 128:
+            raise ValueError("a ncclUniqueId is 128 bytes")
+        self._check(self._lib.mtg_ensemble_shard_rccl(self._ctx, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def ensemble_shard_host(self, rank, world, exchange):
+        """Same, with ``exchange(lnp[count], status[count], lo, hi)`` -- numpy views of the host staging
+        arrays, rows [lo, hi) filled in -- responsible for filling in every other row (any transport)."""
+        def trampoline(_user, lnp_p, st_p, count, lo, hi):
+            try:
+                exchange(np.ctypeslib.as_array(lnp_p, shape=(count,)), np.ctypeslib.as_array(st_p, shape=(count,)),
+                         int(lo), int(hi))
+                return 0
+            except Exception as exc:  # noqa: BLE001 -- reported through the C return code, re-raised by _check
+                self._exchange_error = exc
+                return 1
+        self._exchange_cb = EXCHANGE_FN(trampoline)  # keep the thunk alive as long as the engine uses it
+        self._check(self._lib.mtg_ensemble_shard_host(self._ctx, int(rank), int(world), self._exchange_cb, None))
+
+    def ensemble_unshard(self):
+        self._check(self._lib.mtg_ensemble_unshard(self._ctx))
+        self._exchange_cb = None
 
     def ensemble_run(self, steps, store_chain=False):
         """Advance every ensemble ``steps`` iterations; optionally return

@@ -186,10 +186,11 @@ class GPModelling:
         arguments) split every half-ensemble across the ranks: each GPU evaluates its rows,
         one all-gather of the log-probabilities per half-step (``group``: the process group,
         default the world), identical accept/reject everywhere -- every rank ends with the
-        same chain.  Uses the host-side sampler; rank 0's random state and starting ensemble
-        are broadcast first."""
-        if shard_walkers:
-            device_sampler = False
+        same chain.  With the device sampler the exchange is an ``ncclAllGather`` on the engine's
+        stream (``mtg_ensemble_shard_rccl``; a host-staged exchange over ``group`` when its backend
+        is not nccl); with the host-side sampler (``device_sampler=False``) it is
+        ``distributed.WalkerShardedLogProb``.  Rank 0's starting ensemble and random state / seed are
+        broadcast first."""
         if device_sampler is None:
             model = self.gp._device_model()
             device_sampler = walkers % 2 == 0 and bool(model.device_terms) and model.mean_kind is not None
@@ -206,7 +207,7 @@ class GPModelling:
         self.converged = False
         tau = None
         if device_sampler:
-            sampler = self._device_sampler(walkers)
+            sampler = self._device_sampler(walkers, shard_group=group if shard_walkers else False)
             first, done = initial_chain_params, 0
 
             def iterations():
@@ -265,13 +266,14 @@ class GPModelling:
         self._mcmc_samples = sampler.get_chain(discard=discard, thin=thin, flat=True)
         self._sampler = sampler
 
-    def _device_sampler(self, walkers):
+    def _device_sampler(self, walkers, shard_group=False):
         """One device-resident ensemble on this light curve (see device_sampler.py)."""
         ev = self.gp._ensure_evaluator(self._y)
         model = self.gp._device_model()
         if not model.device_terms or model.mean_kind is None:
             raise ValueError("the device sampler needs device-expandable terms and a constant or linear mean")
-        return DeviceEnsembleSampler(lambda: ev._bind(model), walkers, self._ndim, n_ensembles=1)
+        return DeviceEnsembleSampler(lambda: ev._bind(model), walkers, self._ndim, n_ensembles=1,
+                                     shard_group=shard_group)
 
     def spread_walkers(self, walkers: int, parameters, bounds: List[Tuple[float, float]],
                        percent: float = 0.1, max_attempts: int = 20):

@@ -269,3 +269,128 @@ def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
     assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
     assert np.allclose(single["chain"], r0["chain"], rtol=1e-9, atol=0) and np.allclose(single["lnp"], r0["lnp"], rtol=1e-9)
     assert np.isfinite(float(r0["best"]))
+
+
+# ---- the device-resident sampler, walker-sharded (mtg_ensemble_shard_*) -------------------------------------
+
+class _FakeShardEngine:
+    """Stands in for Engine in the CPU test of the host exchange: keeps the callback the way the library would."""
+
+    def ensemble_shard_host(self, rank, world, exchange):
+        self.rank, self.world, self.exchange = rank, world, exchange
+
+
+def _host_exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mind_the_gaps_amd.distributed import shard_device_ensemble, broadcast_start
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeShardEngine()
+    assert shard_device_ensemble(eng) == "host" and (eng.rank, eng.world) == (rank, world)
+    ok = True
+    for count in (7, 8, 1, 64):          # ragged last block, even split, fewer rows than ranks
+        chunk = -(-count // world)
+        lo, hi = min(rank * chunk, count), min((rank + 1) * chunk, count)
+        truth_lnp = -np.arange(count, dtype=np.float64) - 0.25
+        truth_st = (np.arange(count) % 4).astype(np.int32)
+        lnp, st = np.full(count, np.nan), np.full(count, -1, dtype=np.int32)
+        lnp[lo:hi], st[lo:hi] = truth_lnp[lo:hi], truth_st[lo:hi]
+        eng.exchange(lnp, st, lo, hi)
+        ok = ok and np.array_equal(lnp, truth_lnp) and np.array_equal(st, truth_st)
+    p0, seed = broadcast_start(np.full((4, 2), float(rank)), 100 + rank)
+    ok = ok and np.all(p0 == 0.0) and seed == 100
+    open(os.path.join(out_dir, "hx%d.txt" % rank), "w").write("ok" if ok else "bad")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_host_exchange_of_the_sharded_device_ensemble_two_ranks(tmp_path):
+    """distributed.shard_device_ensemble(transport 'host') on two gloo ranks: the callback the library would
+    call fills every other rank's rows (lnP and status) in the library's chunk layout; rank 0's start wins."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_host_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "hx0.txt").read() == "ok" and open(tmp_path / "hx1.txt").read() == "ok"
+
+
+def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, transport):
+    sys.path.insert(0, ROOT)
+    import warnings
+    import torch.distributed as dist
+    from mind_the_gaps_amd.gp import get_engine
+    from mind_the_gaps_amd.gpmodelling import GPModelling
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
+    from mind_the_gaps_amd import terms
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    th = synth.truth(synth.ALT_MODEL)
+    t, y, dy = synth.make_lightcurves(n, 1, seed=41)
+    amp, other = (-10, 50), (-10, 10)
+    kernel = DampedRandomWalk(th[0], th[1], bounds=[amp, other]) + terms.SHOTerm(
+        th[2], th[3], th[4], bounds=[amp, other, other]) + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other])
+    g = GPModelling(GappyLightcurve(t, y[0], dy[0]), kernel)
+    np.random.seed(7 if world == 1 else 7 + rank)
+    eng = get_engine(0)
+    eng.set_time_parallel(tp_mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if transport == "rccl1":   # the RCCL code path with a communicator of one rank
+            from mind_the_gaps_amd.device_sampler import DeviceEnsembleSampler
+            sampler = g._device_sampler(walkers)
+            p0 = g.spread_walkers(walkers, g.initial_params, np.array(g.gp.get_parameter_bounds()))
+            bound = sampler._bind()
+            bound.ensemble_init(p0[None], seed=sampler.seed)
+            bound.ensemble_shard_rccl(bound.rccl_unique_id(), 0, 1)
+            chain, lnp = bound.ensemble_run(20, store_chain=True)
+            np.savez(os.path.join(out_dir, "dev_%s_rccl.npz" % case), chain=chain[:, 0], lnp=lnp[:, 0])
+            bound.ensemble_unshard()
+            bound.ensemble_init(p0[None], seed=sampler.seed)
+            chain, lnp = bound.ensemble_run(20, store_chain=True)
+            np.savez(os.path.join(out_dir, "dev_%s_plain.npz" % case), chain=chain[:, 0], lnp=lnp[:, 0])
+            return
+        g.derive_posteriors(fit=False, max_steps=20, convergence_steps=20, walkers=walkers, progress=False,
+                            device_sampler=True, shard_walkers=world > 1)
+    np.savez(os.path.join(out_dir, "dev_%s_%d_%d.npz" % (case, world, rank)), chain=g.sampler.get_chain(),
+             lnp=g.sampler.get_log_prob(), best=g.max_loglikelihood)
+    if world > 1:
+        assert g.sampler.transport == "host"
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,tp_mode,n,walkers", [("sweep", 0, 300, 16), ("timeparallel", 1, 5000, 32),
+                                                    ("ragged", 2, 300, 18)])
+def test_device_sampler_walker_sharded_two_ranks_one_gpu(tmp_path, case, tp_mode, n, walkers):
+    """derive_posteriors(device_sampler=True, shard_walkers=True) on two processes (sharing the box's GPU, so
+    the exchange is the host callback over gloo: RCCL refuses two ranks on one device): both ranks hold the
+    same chain, and it is the one-process device chain BIT FOR BIT -- serial sweep, time-parallel kernels
+    (same kernel whatever the number of rows) and a half-ensemble that does not split evenly (9 rows)."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_device_chain_worker, args=(world, port, str(tmp_path), case, tp_mode, n, walkers, "host"), nprocs=world,
+             join=True)
+    mp.spawn(_device_chain_worker, args=(1, _free_port(), str(tmp_path), case, tp_mode, n, walkers, "host"), nprocs=1,
+             join=True)
+    r0, r1, single = (np.load(tmp_path / ("dev_%s_%s.npz" % (case, name))) for name in ("2_0", "2_1", "1_0"))
+    assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
+    assert np.array_equal(single["chain"], r0["chain"]) and np.array_equal(single["lnp"], r0["lnp"])
+    assert len(np.unique(r0["chain"][:, :, 0])) > walkers     # the walkers moved
+    assert np.isfinite(float(r0["best"]))
+
+
+@pytest.mark.gpu
+def test_device_sampler_rccl_exchange_one_rank(tmp_path):
+    """The RCCL transport end to end with a communicator of ONE rank (all a one-GPU box allows): library
+    look-up, ncclGetUniqueId, ncclCommInitRank, the grouped in-place ncclAllGather pair on the engine's
+    stream in every half-step, unshard -- and the chain equals the unsharded one bit for bit."""
+    import torch.multiprocessing as mp
+    mp.spawn(_device_chain_worker, args=(1, _free_port(), str(tmp_path), "one", 2, 300, 16, "rccl1"), nprocs=1, join=True)
+    a, b = np.load(tmp_path / "dev_one_rccl.npz"), np.load(tmp_path / "dev_one_plain.npz")
+    assert np.array_equal(a["chain"], b["chain"]) and np.array_equal(a["lnp"], b["lnp"])
+    assert len(np.unique(a["chain"][:, :, 0])) > 16
