@@ -367,7 +367,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         }
         for (int k = 0; k < nsig; ++k) {
             const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
-            mtg_solve_launcher fn = mtg_find_solver(nr, nc);
+            mtg_solve_launcher fn = mtg_find_solver(nr, nc, m.last_b0);
             if (!fn) continue;
             mtg_solve_launcher tp = small_ok ? mtg_find_tp_solver(nr, nc) : nullptr;
             if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
@@ -592,6 +592,14 @@ MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const 
         }
     }
     m.nk = off;
+    // the last complex slot: slots are handed out in term order, an over-damped SHOTerm takes none -- so it holds
+    // the last term that is complex whatever its parameters, if that term comes after every SHOTerm
+    for (int i = nterms - 1; i >= 0; --i) {
+        const int kd = kinds[i];
+        if (kd == MTG_TERM_REAL || kd == MTG_TERM_DRW || kd == MTG_TERM_JITTER) continue;
+        m.last_b0 = kd == MTG_TERM_LORENTZIAN || kd == MTG_TERM_COMPLEX3 || kd == MTG_TERM_COSINUS;
+        break;
+    }
     const int nmean = mean_kind == MTG_MEAN_LINEAR ? 2 : 1;
     if (PF != off + nmean)
         return fail(ctx, MTG_E_ARG, "mtg_set_model: PF = %d but the terms + mean hold %d parameters",

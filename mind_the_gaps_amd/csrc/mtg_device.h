@@ -17,6 +17,7 @@ struct MtgModel {
     int nsho;    // SHOTerm count: each may expand to 1 complex or 2 real terms
     int nr0, nc0;        // structure with every SHO under-damped (Q >= 1/2)
     int nr_max, nc_max;  // widest real / complex expansion (workspace layout)
+    int last_b0;         // the last complex slot always holds a term with b = 0 (Lorentzian, ComplexTerm3, Cosinus)
     int kinds[MTG_MAX_TERMS];
     int poff[MTG_MAX_TERMS];
     int src[MTG_MAX_PARAMS];  // theta column feeding full[k], or -1 = frozen
@@ -125,7 +126,7 @@ struct MtgPredictArgs {
 
 typedef void (*mtg_solve_launcher)(const MtgSolveArgs &, int64_t nlanes, hipStream_t);
 // Table lookup of the compiled <NR, NC> instantiations (mtg_kernels.hip).
-mtg_solve_launcher mtg_find_solver(int nr, int nc);
+mtg_solve_launcher mtg_find_solver(int nr, int nc, int last_b0 = 0);
 // Time-parallel (one wave per evaluation) instantiations, J <= 6 (mtg_timeparallel.hip); the
 // launcher's second argument is the number of evaluations.
 mtg_solve_launcher mtg_find_tp_solver(int nr, int nc);

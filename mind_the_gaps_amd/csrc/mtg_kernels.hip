@@ -122,7 +122,9 @@ struct MtgLane {
 //   MEAN: a mean function has to be subtracted or a jitter term added (false: the mean is
 //         identically zero, the frozen per-light-curve constant having been folded into y at
 //         upload, and the model has no JitterTerm).
-template <int NR, int NC, bool FAST, bool MEAN>
+//   NB0:  the last NB0 complex terms have b = 0 by construction (Lorentzian, three-parameter ComplexTerm,
+//         Cosinus): their U is a (cos, sin) -- a multiplication instead of a multiplication and a multiply-add.
+template <int NR, int NC, bool FAST, bool MEAN, int NB0 = 0>
 __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs &a, const double2 *yv_base,
                                           uint32_t yv_records, uint32_t yoff, const double2 *dxt_base,
                                           uint32_t dxt_records, uint32_t toff,
@@ -171,8 +173,13 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
                 // amplitude >> noise -- amplifies far beyond celerite's own error.)
                 sincos(L.dc[k] * (tc - t0), &sn, &cn);
             }
-            U[NR + 2 * k] = L.ac[k] * cn + L.bc[k] * sn;
-            U[NR + 2 * k + 1] = L.ac[k] * sn - L.bc[k] * cn;
+            if (k >= NC - NB0) {
+                U[NR + 2 * k] = L.ac[k] * cn;
+                U[NR + 2 * k + 1] = L.ac[k] * sn;
+            } else {
+                U[NR + 2 * k] = L.ac[k] * cn + L.bc[k] * sn;
+                U[NR + 2 * k + 1] = L.ac[k] * sn - L.bc[k] * cn;
+            }
             V[NR + 2 * k] = cn;
             V[NR + 2 * k + 1] = sn;
         }
@@ -244,7 +251,7 @@ __device__ __forceinline__ void mtg_sweep(MtgLane<NR, NC> &L, const MtgSolveArgs
 
 #define MTG_BLOCK 256
 
-template <int NR, int NC>
+template <int NR, int NC, int NB0 = 0>
 __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_solve_kernel(MtgSolveArgs a)
 {
     constexpr int J = NR + 2 * NC;  // celerite rank
@@ -329,10 +336,10 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     // table sincos is exact while d_k * dx < MTG_TRIG_FAST_MAX for every lane of the wave
     const bool fast = !__any(!(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
     if (fast) {
-        if (a.has_mean) mtg_sweep<NR, NC, true, true>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
-        else mtg_sweep<NR, NC, true, false>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
+        if (a.has_mean) mtg_sweep<NR, NC, true, true, NB0>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
+        else mtg_sweep<NR, NC, true, false, NB0>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
     } else {
-        mtg_sweep<NR, NC, false, true>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
+        mtg_sweep<NR, NC, false, true, NB0>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
     }
 
     const double logdet = log(L.dprod) + (double)L.dexp * 0.69314718055994530942;
@@ -379,12 +386,12 @@ void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, dou
                        n, x, e, s, c, rcp);
 }
 
-template <int NR, int NC>
+template <int NR, int NC, int NB0 = 0>
 static void mtg_launch_solve(const MtgSolveArgs &a, int64_t nlanes, hipStream_t stream)
 {
     const int64_t blocks = (nlanes + MTG_BLOCK - 1) / MTG_BLOCK;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL((mtg_solve_kernel<NR, NC>), dim3((unsigned)blocks), dim3(MTG_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((mtg_solve_kernel<NR, NC, NB0>), dim3((unsigned)blocks), dim3(MTG_BLOCK), 0, stream, a);
 }
 
 // Compiled structures: NR real + NC complex terms, J = NR + 2 NC <= MTG_MAX_J.
@@ -402,8 +409,19 @@ static const mtg_solve_launcher mtg_solver_table[MTG_MAX_NR + 1][MTG_MAX_NC + 1]
     MTG_ROW(0), MTG_ROW(1), MTG_ROW(2), MTG_ROW(3), MTG_ROW(4), MTG_ROW(5),
     MTG_ROW(6), MTG_ROW(7), MTG_ROW(8), MTG_ROW(9), MTG_ROW(10)};
 
-mtg_solve_launcher mtg_find_solver(int nr, int nc)
+// the same structures with the LAST complex term known to have b = 0, for the small ranks (J <= 6)
+template <int NR, int NC, bool OK = (NC > 0 && NR + 2 * NC <= 6)>
+struct MtgSelB0 { static constexpr mtg_solve_launcher fn = mtg_launch_solve<NR, NC, 1>; };
+template <int NR, int NC>
+struct MtgSelB0<NR, NC, false> { static constexpr mtg_solve_launcher fn = nullptr; };
+#define MTG_ROW_B0(nr) { nullptr, MtgSelB0<(nr), 1>::fn, MtgSelB0<(nr), 2>::fn, MtgSelB0<(nr), 3>::fn }
+static const mtg_solve_launcher mtg_solver_table_b0[5][4] = {MTG_ROW_B0(0), MTG_ROW_B0(1), MTG_ROW_B0(2), MTG_ROW_B0(3),
+                                                            MTG_ROW_B0(4)};
+
+// last_b0: the model's last complex term has b = 0 whatever its parameters (mtg_set_model works it out)
+mtg_solve_launcher mtg_find_solver(int nr, int nc, int last_b0)
 {
     if (nr < 0 || nc < 0 || nr > MTG_MAX_NR || nc > MTG_MAX_NC) return nullptr;
+    if (last_b0 && nr < 5 && nc < 4 && mtg_solver_table_b0[nr][nc]) return mtg_solver_table_b0[nr][nc];
     return mtg_solver_table[nr][nc];
 }
