@@ -2,13 +2,14 @@
 """Instruction mix of the inner sweep loop(s) of one solve instantiation (development aid)."""
 import collections, re, subprocess, sys, os
 nr, nc = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("1", "2")
-extra = sys.argv[3:]
+nb0 = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3].isdigit() else "0"   # last complex term known to have b = 0
+extra = [a for a in sys.argv[3:] if not a.isdigit()]
 os.makedirs("/tmp/isa", exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, "-c",
                 "/root/repo/mind_the_gaps_amd/csrc/mtg_kernels.hip", "-save-temps", "-o", "/tmp/isa/k.o"],
                cwd="/tmp/isa", stderr=subprocess.DEVNULL)
 s = open("/tmp/isa/mtg_kernels-hip-amdgcn-amd-amdhsa-gfx950.s").read()
-name = "_Z16mtg_solve_kernelILi%sELi%sEEv12MtgSolveArgs" % (nr, nc)
+name = "_Z16mtg_solve_kernelILi%sELi%sELi%sEEv12MtgSolveArgs" % (nr, nc, nb0)
 i = s.index(name + ":"); j = s.index(".Lfunc_end", i)
 lines = [l.strip() for l in s[i:j].split("\n")]
 heads = [k for k, l in enumerate(lines) if "Loop Header" in l]

@@ -11,7 +11,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $REPO/bench.py --steps $STEPS --warmup 1 --cpu-seconds 0"
+CMD="python3 $REPO/bench.py --steps $STEPS --warmup 1 --cpu-seconds 0 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/pmc_write.log" 2>&1

@@ -56,7 +56,8 @@ known_write = (L * N + N) * 16.0            # interleaved (y, var) and (dx, t) p
 solve = max((r for r in rows if "mtg_solve_kernel" in r["kernel"]),
             key=lambda r: r["hbm_read_bytes_corrected"])
 rec = {
-    "tag": tag, "N": N, "B": L * W, "kernel": solve["kernel"],
+    "tag": tag, "round": "round " + tag[1:3].lstrip("0") if tag[:1] == "r" and tag[1:3].isdigit() else tag,
+    "N": N, "B": L * W, "kernel": solve["kernel"],
     "hbm_bytes_per_launch": solve["hbm_read_bytes_corrected"] + solve["hbm_write_bytes"],
     "hbm_read_bytes_per_launch": solve["hbm_read_bytes_corrected"],
     "hbm_write_bytes_per_launch": solve["hbm_write_bytes"],
