@@ -35,19 +35,25 @@ def _next_pow_two(n):
     return i
 
 
-def _autocorr_functions(x):
-    """Normalised autocorrelation along axis 0 of x[n_t, ...] by zero-padded FFT (emcee's
-    ``function_1d`` for every series at once).  The convergence check runs on the whole chain
-    every ``convergence_steps`` iterations, so for long chains this is the host's hot spot:
-    real transforms over contiguous series on a few threads are ~20x the strided complex FFT."""
+def _mean_autocorr_function(x):
+    """Walker-averaged normalised autocorrelation function of x[n_t, n_walkers, n_dim] -> [n_t, n_dim] (emcee's
+    ``function_1d`` of every walker, each normalised by its own lag-0 value, then averaged) by zero-padded FFT.
+    The convergence check runs on the whole chain every ``convergence_steps`` iterations, so for long chains this
+    is the host's hot spot.  The inverse transform is linear, so the power spectra are normalised (lag 0 of a
+    series is the sum of its squares) and averaged over the walkers BEFORE it: one inverse transform per
+    dimension instead of one per walker and dimension; real transforms over contiguous series."""
     n_t = x.shape[0]
     n = _next_pow_two(n_t)
-    series = np.ascontiguousarray(np.moveaxis(x - np.mean(x, axis=0), 0, -1))     # time last
-    workers = max(1, min(8, os.cpu_count() or 1))
+    series = np.ascontiguousarray(np.moveaxis(x - np.mean(x, axis=0), 0, -1))     # [n_walkers, n_dim, n_t]
+    # (threads only where they pay: below a few million points the pool's start-up and hand-over cost more than
+    # the transforms -- 640 series of 1000 steps: 60 ms on 8 workers, 12 ms on one)
+    workers = max(1, min(8, os.cpu_count() or 1)) if series.size * 2 * n // max(n_t, 1) > (1 << 23) else 1
     f = _fft.rfft(series, n=2 * n, axis=-1, workers=workers)
-    acf = _fft.irfft(f.real ** 2 + f.imag ** 2, n=2 * n, axis=-1, workers=workers)[..., :n_t]
-    acf /= acf[..., :1]
-    return np.moveaxis(acf, -1, 0)
+    power = f.real ** 2 + f.imag ** 2
+    with np.errstate(invalid="ignore", divide="ignore"):   # a walker that never moved: 0 / 0 = nan, as emcee has it
+        power /= np.sum(series * series, axis=-1)[..., None]
+    acf = _fft.irfft(np.mean(power, axis=0), n=2 * n, axis=-1)[..., :n_t]          # [n_dim, n_t]
+    return np.ascontiguousarray(acf.T)
 
 
 def integrated_time(x, c=5, tol=50, quiet=False):
@@ -62,7 +68,7 @@ def integrated_time(x, c=5, tol=50, quiet=False):
     if x.ndim != 3:
         raise ValueError("invalid dimensions")
     n_t, n_w, n_d = x.shape
-    rho = np.mean(_autocorr_functions(x), axis=1)          # [n_t, n_d]
+    rho = _mean_autocorr_function(x)                       # [n_t, n_d]
     taus = 2.0 * np.cumsum(rho, axis=0) - 1.0
     tau_est = np.empty(n_d)
     lags = np.arange(n_t)
