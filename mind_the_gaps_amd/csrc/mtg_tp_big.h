@@ -10,14 +10,15 @@
 //   compose  mtg_tpb_compose2_kernel<NR, NC>: the element of every chunk by the filter-from-zero
 //            recursion, TWO waves per 64 chunks (one keeps A, the other Dv, b, eta, Jm; see below); also
 //            the chunk's likelihood given x_in = 0 (kappa);
-//   scan     mtg_tp_scan.h: up-sweep of combinations, down-sweep of applications, each J x J
-//            operation spread over 16 lanes with the operands in LDS -- no lane holds a matrix; the last
-//            level of the down-sweep also yields every chunk's likelihood correction;
-//   finish   mtg_tpb_finish_direct_kernel: lnL = sum of (kappa + correction) -- no further pass over the
-//            data.  Evaluations whose terms cancel badly, or that met a pivot that is not positive, go
-//            through
-//   filter   mtg_tpb_filter_kernel<NR, NC>: lane = chunk; the ordinary Kalman filter over the chunk
-//            from its start state: celerite's own pivots and residuals (mtg_tpb_finish_kernel sums them).
+//   up-sweep mtg_tp_scan.h: combinations level by level down to four elements per evaluation, each J x J
+//            operation spread over 16 lanes with the operands in LDS -- no lane holds a matrix; the
+//            likelihood records (kappa and the combinations' contributions) travel along;
+//   top      mtg_tpb_top_direct_kernel: those four elements applied to the state after sample 0 give lnL --
+//            no further pass over the data.  Evaluations whose terms cancel badly, or that met a pivot that
+//            is not positive, go through
+//   down-sweep + filter   mtg_tpb_down_kernel: every chunk's start state; mtg_tpb_filter_kernel<NR, NC>:
+//            lane = chunk, the ordinary Kalman filter over the chunk from its start state: celerite's own
+//            pivots and residuals (mtg_tpb_finish_kernel sums them).
 // The light curve is cut into C chunks of `per` samples after sample 0, whose update of the
 // stationary prior is the scan's initial state (mtg_tpb_down_kernel).
 #pragma once
@@ -507,8 +508,6 @@ __device__ __forceinline__ int tpb_nr(const MtgSolveArgs &a, int64_t ev) { retur
 // one wave per evaluation: the chunks' partial sums in a fixed order, plus the head (sample 0)
 void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
                            hipStream_t stream);
-void mtg_launch_tpb_finish_direct(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
-                                  int *redo_list, int *redo_count, hipStream_t stream);
 // mtg_tp_big_compose.hip / mtg_tp_big_filter.hip: the two kernels that hold all six structures
 void mtg_launch_tpb_compose(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
 void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *parts, int C, int64_t nevals, hipStream_t stream);

@@ -26,9 +26,10 @@ void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *
 }
 
 // Every prepared evaluation of a rank-10 model (status OK; its structure in a.sig) in one sequence of
-// launches.  a.tp_direct: the likelihood from the composition pass and the scan alone (see
-// mtg_tpb_finish_direct_kernel); the filter pass then runs for the evaluations on the redo list only -- as
-// a rule none, and its workgroups leave at once.  Otherwise the filter pass runs for everybody.
+// launches.  a.tp_direct: the likelihood from the composition pass and the up-sweep alone (mtg_tp_scan.h:
+// the elements carry their likelihood records); the down-sweep and the filter pass then run for the
+// evaluations on the redo list only -- as a rule none, and their workgroups leave at once.  Otherwise the filter
+// pass runs for everybody.
 void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
 {
     constexpr int J = 10;
@@ -37,15 +38,16 @@ void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
     const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C, a.tp_gsize);
     double *ws = a.tp_ws;
     mtg_launch_tpb_compose(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
-    mtg_launch_tpb_scan(J, a, plan, nevals, a.tp_direct, s);
+    mtg_launch_tpb_up(J, a, plan, nevals, a.tp_direct, s);
     MtgSolveArgs f = a;
     if (a.tp_direct) {
         int *redo_list = (int *)(ws + plan.redo_off), *redo_count = redo_list + a.B;
         (void)hipMemsetAsync(redo_count, 0, sizeof(int), s);
-        mtg_launch_tpb_finish_direct(a, ws + plan.part_off, ws + plan.head_off, C, nevals, redo_list, redo_count, s);
+        mtg_launch_tpb_top_direct(J, a, plan, nevals, redo_list, redo_count, s);
         f.list = redo_list;
         f.count_ptr = redo_count;
     }
+    mtg_launch_tpb_down(J, f, plan, nevals, s);
     mtg_launch_tpb_filter(f, ws + plan.state_off[0], ws + plan.part_off, C, nevals, s);
     mtg_launch_tpb_finish(f, ws + plan.part_off, ws + plan.head_off, C, nevals, s);
 }

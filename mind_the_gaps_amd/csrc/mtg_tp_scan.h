@@ -10,13 +10,21 @@
 //
 // Structure of the scan (per evaluation, C chunk elements e_0 .. e_{C-1} in global memory):
 //   up-sweep    mtg_tpb_reduce_kernel: groups of g (mtg_tp_big_gsize) consecutive elements are composed into
-//               one (g - 1 sequential combinations per lane group), level after level while more than g
-//               elements remain;
-//   down-sweep  mtg_tpb_down_kernel: from the state after sample 0 the start state of every top-level
-//               element by sequential application, then level by level down to the chunks: the
-//               start state of element g k + i follows from that of group k by applying i elements.
-// Work: ~C g/(g-1) combinations + as many applications per evaluation (a Hillis-Steele scan needs
-// C log2 C combinations); depth: g - 1 combinations + g - 1 applications per level.
+//               one (g - 1 sequential combinations per lane group), level after level until four
+//               elements remain.  With the likelihood record (below) carried along, those four applied to
+//               the state after sample 0 give lnL (mtg_tpb_top_direct_kernel): no down-sweep, no filter pass;
+//   down-sweep  mtg_tpb_down_kernel (only for evaluations that need the filter pass): from the state after
+//               sample 0 the start state of every top-level element by sequential application, then level
+//               by level down to the chunks: the start state of element g k + i follows from that of group
+//               k by applying i elements.
+// Work: ~C g/(g-1) combinations (+ as many applications for the down-sweep) per evaluation (a
+// Hillis-Steele scan needs C log2 C combinations); depth: g - 1 combinations per level.
+//
+// Likelihood record of an element, 4 doubles (dot, ld, dmin, mag): ln p(y_element | x_in = 0) =
+// -1/2 (dot + ld) without the 2 pi terms.  For a chunk the composition pass leaves its filter's sum z^2/D,
+// ln prod D and min D (parts[chunk][0..2]); a combination e1 o e2 adds (mtg_timeparallel.h has the derivation)
+//   dot += -2 (lin + quad),  ld += ln det G,   lin = 1/2 b1^T (eta2 + t),  quad = 1/2 t^T G^-1 C1 t,
+// G = I + C1 J2, t = eta2 - J2 b1; dmin becomes -1 (and ld NaN) when det G is not positive; mag sums the magnitudes.
 //
 // Global layouts (full matrices, so that loading is a plain copy):
 //   element: A[J][J] | b[J] | eta[J] | C[J][J] | Jm[J][J]     MTG_TPB_ELEM(J) doubles
@@ -31,12 +39,15 @@
 
 // Workspace of the big-J path, in doubles from a.tp_ws: element and state arrays per scan level,
 // per-chunk partial sums of the final filter pass, per-evaluation head (sample 0).
+#define MTG_TPB_TOP 4        /* elements per evaluation at the top level */
 struct MtgTpBigPlan {
     int C;                         // chunks per evaluation (a power of two >= 64)
-    int g;                         // elements per scan group (4, 8 or 16)
-    int nlev;                      // scan levels; level 0 = the chunks
+    int g;                         // elements per scan group (4 or 16), fewer where a level has less than 4 g
+    int nlev;                      // scan levels; level 0 = the chunks, level nlev - 1 has MTG_TPB_TOP elements
     int n[MTG_TPB_MAX_LEVELS];     // elements per evaluation at each level
+    int gl[MTG_TPB_MAX_LEVELS];    // group size that takes level l to level l + 1
     int64_t elem_off[MTG_TPB_MAX_LEVELS], state_off[MTG_TPB_MAX_LEVELS];
+    int64_t rec_off[MTG_TPB_MAX_LEVELS];   // likelihood records of the levels >= 1 (level 0: the parts array)
     int64_t part_off, head_off, redo_off, total;
 };
 
@@ -47,12 +58,16 @@ static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C, int g)
     p.g = g;
     p.nlev = 0;
     int64_t off = 0;
-    for (int n = C;; n /= g) {
-        p.n[p.nlev] = n;
-        p.elem_off[p.nlev] = off; off += B * n * MTG_TPB_ELEM(J);
-        p.state_off[p.nlev] = off; off += B * n * MTG_TPB_STATE(J);
-        ++p.nlev;
-        if (n <= g || p.nlev == MTG_TPB_MAX_LEVELS) break;
+    for (int n = C;;) {
+        const int l = p.nlev++;
+        p.n[l] = n;
+        p.elem_off[l] = off; off += B * n * MTG_TPB_ELEM(J);
+        p.state_off[l] = off; off += B * n * MTG_TPB_STATE(J);
+        p.rec_off[l] = off; off += l > 0 ? B * n * 4 : 0;
+        p.gl[l] = 0;
+        if (n <= MTG_TPB_TOP || p.nlev == MTG_TPB_MAX_LEVELS) break;
+        p.gl[l] = g < n / MTG_TPB_TOP ? g : n / MTG_TPB_TOP;   // (C is a power of two >= 64: ends on exactly four)
+        n /= p.gl[l];
     }
     p.part_off = off; off += B * C * 4;
     p.head_off = off; off += B * 4;
@@ -79,8 +94,13 @@ static inline int mtg_tp_big_gsize(int64_t B, int C)
     return B * C >= 65536 ? 16 : 4;
 }
 
-// corr != 0: the level-0 down-sweep also leaves every chunk's likelihood correction in parts[..][3]
-void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int corr, hipStream_t stream);
+// up-sweep; kappa != 0: every group (the last one's total too) and the likelihood records
+void mtg_launch_tpb_up(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int kappa, hipStream_t stream);
+// lnL from the top-level elements and their records; suspects are appended to the redo list
+void mtg_launch_tpb_top_direct(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int *redo_list,
+                               int *redo_count, hipStream_t stream);
+// down-sweep: the start state of every chunk (for the filter pass)
+void mtg_launch_tpb_down(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, hipStream_t stream);
 // the whole path (mtg_tp_big_filter.hip): every prepared evaluation of a rank-10 model, whatever its structure
 void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t stream);
 
@@ -194,10 +214,12 @@ __device__ __forceinline__ void inv_ipxy(Lds<J> &L, const double *X, const doubl
 // time:  G = I + C1 J2;  A = A2 G^-1 A1;  b = A2 G^-1 (b1 + C1 eta2) + b2;  C = A2 G^-1 C1 A2^T + C2;
 //        eta = A1^T G^-T (eta2 - J2 b1) + eta1;  J = A1^T G^-T J2 A1 + J1,
 // with G^-T J2 = J2 G^-1 (push-through identity).
-template <int J> __device__ __forceinline__ void combine(Lds<J> &L, int r)
+// KAPPA: kap = (lin, quad) of the likelihood record's update and 1 / det G = dm 2^de (same on every lane of
+// the group; the caller takes the logarithm of the product of a whole group's determinants once).
+template <int J, bool KAPPA = false>
+__device__ __forceinline__ void combine(Lds<J> &L, int r, double (&kap)[2], double &dm, int &de)
 {
-    double gi[J], dm;
-    int de;
+    double gi[J];
     inv_ipxy<J>(L, L.C1, L.J2, r, gi, dm, de);
     // w = b1 + C1 eta2 -> v1 ; t = eta2 - J2 b1 -> v2 ; Gi -> T1
     {
@@ -221,6 +243,11 @@ template <int J> __device__ __forceinline__ void combine(Lds<J> &L, int r)
         put<J>(L.T2, r, xa);
         put<J>(L.T3, r, xc);
         L.v3[r] = xb;
+        if (KAPPA) {  // this row's share of lin and of quad (t in v2; piv is free after the inverse)
+            const double tr = L.v2[r];
+            L.piv[r] = 0.5 * L.b1[r] * (L.eta2[r] + tr);
+            L.piv[J + r] = 0.5 * tr * dot<J>(xc, L.v2);
+        }
     }
     // yeta = G^-T t (column r of Gi; stays in this lane until A1's columns are read);
     // YJ = G^-T J2 = J2 Gi ; Z = YJ A1
@@ -236,6 +263,12 @@ template <int J> __device__ __forceinline__ void combine(Lds<J> &L, int r)
         mm<J>(yj, L.A1, z);
     }
     wsync();                       // everybody has read Gi (T1) and v2
+    if (KAPPA) {
+        double lin = 0.0, quad = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) { lin += L.piv[k]; quad += L.piv[J + k]; }
+        kap[0] = lin; kap[1] = quad;
+    }
     put<J>(L.T1, r, z);       // Z -> T1
     L.v2[r] = yeta;
     wsync();

@@ -24,43 +24,173 @@ __device__ __forceinline__ bool tpb_group(const MtgSolveArgs &a, int groups_per_
     return true;
 }
 
-// out[ev][k] = in[ev][g k] o in[ev][g k + 1] o ... o in[ev][g k + g - 1],  
-template <int J>
+// out[ev][k] = in[ev][g k] o in[ev][g k + 1] o ... o in[ev][g k + g - 1].
+// KAPPA: the likelihood records travel along (rec_in -> rec_out; level0: rec_in is the composition pass's parts
+// array, whose fourth entry is not a magnitude) and every group is reduced; otherwise only prefixes are ever
+// applied and the last group's total is not needed.
+template <int J, bool KAPPA>
 __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_LANES */, 1) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
-                                                                                           double *out, int n_in, int g)
+                                                                                           double *out, int n_in, int g,
+                                                                                           const double *rec_in, double *rec_out,
+                                                                                           int level0)
 {
     __shared__ tpg::Lds<J> lds[GROUPS];
     const int gpe = n_in / g;
     int64_t ev;
     int k;
     if (!tpb_group(a, gpe, ev, k)) return;
-    if (k == gpe - 1) return;  // only prefixes are ever applied: the last group's total is not needed
+    if (!KAPPA && k == gpe - 1) return;
     tpg::Lds<J> &L = lds[threadIdx.x >> 4];
     const int l16 = threadIdx.x & 15;
     const int r = l16 < J ? l16 : J - 1;
-    const double *e = in + (ev * n_in + (int64_t)k * g) * MTG_TPB_ELEM(J);
+    const int64_t first = ev * n_in + (int64_t)k * g;
+    const double *e = in + first * MTG_TPB_ELEM(J);
     tpg::load_first<J>(L, e, l16);
     tpg::Pre<J> pre;
     tpg::fetch<J>(pre, e + MTG_TPB_ELEM(J), l16);
+    // the group's record: (dot, mag) as they come; the determinants as a product (pm 2^pe = prod 1 / det G)
+    double dot = 0.0, mag = 0.0, pm = 1.0;
+    int pe = 0;
+    bool positive = true;
 #pragma unroll 1
     for (int i = 1; i < g; ++i) {
         tpg::put_second<J>(L, pre, l16);
         if (i + 1 < g) tpg::fetch<J>(pre, e + (int64_t)(i + 1) * MTG_TPB_ELEM(J), l16);
         tpg::wsync();
-        tpg::combine<J>(L, r);
+        double kap[2], dm;
+        int de;
+        tpg::combine<J, KAPPA>(L, r, kap, dm, de);
+        if (KAPPA) {
+            dot -= 2.0 * (kap[0] + kap[1]);
+            mag += fabs(kap[0]) + fabs(kap[1]);
+            positive = positive && dm > 0.0;
+            const double pr = pm * dm;
+            pm = __builtin_amdgcn_frexp_mant(pr);
+            pe += de + __builtin_amdgcn_frexp_exp(pr);
+        }
     }
     tpg::store_first<J>(L, out + (ev * gpe + k) * MTG_TPB_ELEM(J), l16);
+    if (KAPPA && l16 == 0) {
+        double ld = positive ? -(log(pm) + (double)pe * 0.69314718055994530942) : __builtin_nan("");
+        double dmin = positive ? INFINITY : -1.0;
+        for (int i = 0; i < g; ++i) {
+            const double *q = rec_in + (first + i) * 4;
+            dot += q[0]; ld += q[1]; dmin = fmin(dmin, q[2]); mag += level0 ? 0.5 * q[0] : q[3];
+        }
+        double *q = rec_out + (ev * gpe + k) * 4;
+        q[0] = dot; q[1] = ld; q[2] = dmin; q[3] = mag;
+    }
+}
+
+// The filtered state after sample 0 (update of the stationary prior) into (b1 | C1) of the group's LDS region, that
+// sample's terms of the likelihood into head[ev]; false: the evaluation's light curve index is out of range.
+template <int J>
+__device__ __forceinline__ bool tpb_head_state(const MtgSolveArgs &a, int64_t ev, tpg::Lds<J> &L, int l16, int r, double *head)
+{
+    constexpr int M = J * J;
+    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
+    if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) return false;
+    const int nover = a.sig ? a.sig[ev] : 0, nr = a.tp_nr0 + 2 * nover, nc = a.tp_nc0 - nover;  // structure of this evaluation
+    if (l16 == 0) {  // stationary covariance P_inf and P_inf h, rank by rank
+        const double *cf = a.coef + ev;
+        const int64_t cs = a.cstride;
+        for (int i = 0; i < M; ++i) L.C1[i] = 0.0;
+        double D0 = 0.0;
+        for (int j = 0; j < nr; ++j) {
+            const double aj = cf[a.lay.ar(j) * cs];
+            L.C1[j * J + j] = aj; L.v1[j] = aj; D0 += aj;
+        }
+        for (int q = 0; q < nc; ++q) {
+            const double aa = cf[a.lay.ac(q) * cs], bb = cf[a.lay.bc(q) * cs], c = cf[a.lay.cc(q) * cs], d = cf[a.lay.dc(q) * cs];
+            const double p = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
+            const int o = nr + 2 * q;
+            L.C1[o * J + o] = aa; L.C1[o * J + o + 1] = -bb; L.C1[(o + 1) * J + o] = -bb; L.C1[(o + 1) * J + o + 1] = p;
+            L.v1[o] = aa; L.v1[o + 1] = -bb; D0 += aa;
+        }
+        const double2 y0 = a.yv[lc * a.N], t0 = a.dxt[lc * a.t_stride];
+        D0 += y0.y + cf[a.lay.jit() * cs];
+        const double z0 = y0.x - fma(cf[a.lay.mean(0) * cs], t0.y, cf[a.lay.mean(1) * cs]);
+        L.v2[0] = z0 / D0; L.v2[1] = 1.0 / D0;
+        double *h = head + ev * 4;
+        h[0] = z0 * z0 / D0; h[1] = log(D0); h[2] = D0;
+    }
+    tpg::wsync();
+    {
+        const double chr = L.v1[r];
+        double prow[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) prow[j] = L.C1[r * J + j] - chr * L.v1[j] * L.v2[1];
+        tpg::wsync();   // lanes J .. 15 duplicate row J - 1: everybody reads before anybody writes
+        L.b1[r] = chr * L.v2[0];
+        tpg::put<J>(L.C1, r, prow);
+    }
+    tpg::wsync();
+    return true;
+}
+
+// lnL of an evaluation from its n top-level elements and their likelihood records: the elements applied one after
+// the other to the state after sample 0, each leaving its correction (tpg::apply) -- the samples were read once,
+// by the composition pass.  The records are computed under a wrong hypothesis (x_in = 0), so the terms can be far
+// larger than the result and cancel; an evaluation whose terms exceed 1e3 x the result, with anything not positive or
+// not finite on the way, or with a complex term whose power spectrum can go negative (b d > a c: the matrix need not
+// be positive definite and only the filter pass sees every pivot's sign, mtg_timeparallel.h) is appended to the redo
+// list and goes through the down-sweep and the filter pass, whose pivots are celerite's own.
+template <int J>
+__global__ void __launch_bounds__(64, 2) mtg_tpb_top_direct_kernel(MtgSolveArgs a, const double *elems, const double *recs,
+                                                                double *head, int n, int *redo_list, int *redo_count)
+{
+    __shared__ tpg::Lds<J> lds[GROUPS];
+    int64_t ev;
+    int k;
+    if (!tpb_group(a, 1, ev, k)) return;
+    tpg::Lds<J> &L = lds[threadIdx.x >> 4];
+    const int l16 = threadIdx.x & 15;
+    const int r = l16 < J ? l16 : J - 1;
+    if (!tpb_head_state<J>(a, ev, L, l16, r, head)) {
+        if (l16 == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
+        return;
+    }
+    const int64_t first = ev * n;
+    tpg::Pre<J> pre;
+    tpg::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l16);
+    double corr = 0.0, mag = 0.0, dot = 0.0, ld = 0.0, dmin = INFINITY;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        tpg::put_second<J>(L, pre, l16);
+        if (i + 1 < n) tpg::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l16);
+        tpg::wsync();
+        const double c = i + 1 < n ? tpg::apply<J, true, true>(L, r) : tpg::apply<J, true, false>(L, r);
+        const double *q = recs + (first + i) * 4;
+        corr += c; mag += fabs(c) + q[3];
+        dot += q[0]; ld += q[1]; dmin = fmin(dmin, q[2]);
+    }
+    if (l16 == 0) {
+        const double *h = head + ev * 4;
+        mag += 0.5 * h[0];
+        dot += h[0]; ld += h[1]; dmin = fmin(dmin, h[2]);
+        const double ll = corr - 0.5 * (dot + ld + (double)a.N * MTG_LN_2PI);
+        bool psd = true;
+        const int nc = a.tp_nc0 - (a.sig ? a.sig[ev] : 0);
+        const double *cf = a.coef + ev;
+        for (int q = 0; q < nc; ++q)
+            if (!(fabs(cf[a.lay.bc(q) * a.cstride] * cf[a.lay.dc(q) * a.cstride])
+                  <= cf[a.lay.ac(q) * a.cstride] * cf[a.lay.cc(q) * a.cstride] * (1.0 + 1.0e-12)))
+                psd = false;
+        if (a.tp_direct >= 2 || (psd && dmin > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll))) {  // 2: diagnostic, never redo
+            a.out[ev] = a.tp_direct == 3 ? dot : a.tp_direct == 4 ? ld : a.tp_direct == 5 ? corr : a.tp_direct == 6 ? mag : ll;
+            a.status[ev] = MTG_ST_OK;
+        } else {
+            redo_list[atomicAdd(redo_count, 1)] = (int)ev;
+        }
+    }
 }
 
 // states[ev][k gsize + i] = start state of element k gsize + i, i = 0 .. gsize - 1, from the start state
 // of the group: up[ev][k] (the level above), or -- at the top, up == NULL, one group per evaluation --
-// the filtered state after sample 0 (update of the stationary prior; also leaves that sample's terms of
-// the likelihood in head[ev]).
-// CORR (level 0 only): every element of the group is applied -- the last one for its number only -- and the
-// chunk likelihood correction of tpg::apply goes to parts[chunk][3].
-template <int J, bool CORR>
+// the filtered state after sample 0 (which also leaves that sample's terms of the likelihood in head[ev]).
+template <int J>
 __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, const double *elems, const double *up,
-                                                          double *states, double *head, double *parts, int n, int gsize)
+                                                          double *states, double *head, int n, int gsize)
 {
     constexpr int M = J * J;
     __shared__ tpg::Lds<J> lds[GROUPS];
@@ -73,61 +203,21 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, con
     const int r = l16 < J ? l16 : J - 1;
     if (up) {
         tpg::gcopy(L.b1, up + (ev * gpe + k) * MTG_TPB_STATE(J), J + M, l16);  // b1 | C1 are contiguous
-    } else {
-        const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
-        if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) return;
-        const int nover = a.sig ? a.sig[ev] : 0, nr = a.tp_nr0 + 2 * nover, nc = a.tp_nc0 - nover;  // structure of this evaluation
-        if (l16 == 0) {  // stationary covariance P_inf and P_inf h, rank by rank
-            const double *cf = a.coef + ev;
-            const int64_t cs = a.cstride;
-            for (int i = 0; i < M; ++i) L.C1[i] = 0.0;
-            double D0 = 0.0;
-            for (int j = 0; j < nr; ++j) {
-                const double aj = cf[a.lay.ar(j) * cs];
-                L.C1[j * J + j] = aj; L.v1[j] = aj; D0 += aj;
-            }
-            for (int q = 0; q < nc; ++q) {
-                const double aa = cf[a.lay.ac(q) * cs], bb = cf[a.lay.bc(q) * cs], c = cf[a.lay.cc(q) * cs], d = cf[a.lay.dc(q) * cs];
-                const double p = d != 0.0 ? (2.0 * d * (2.0 * c * bb + d * aa) + 4.0 * c * (c * aa - d * bb)) / (2.0 * d * d) : aa;
-                const int o = nr + 2 * q;
-                L.C1[o * J + o] = aa; L.C1[o * J + o + 1] = -bb; L.C1[(o + 1) * J + o] = -bb; L.C1[(o + 1) * J + o + 1] = p;
-                L.v1[o] = aa; L.v1[o + 1] = -bb; D0 += aa;
-            }
-            const double2 y0 = a.yv[lc * a.N], t0 = a.dxt[lc * a.t_stride];
-            D0 += y0.y + cf[a.lay.jit() * cs];
-            const double z0 = y0.x - fma(cf[a.lay.mean(0) * cs], t0.y, cf[a.lay.mean(1) * cs]);
-            L.v2[0] = z0 / D0; L.v2[1] = 1.0 / D0;
-            double *h = head + ev * 4;
-            h[0] = z0 * z0 / D0; h[1] = log(D0); h[2] = D0;
-        }
         tpg::wsync();
-        {
-            const double chr = L.v1[r];
-            double prow[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) prow[j] = L.C1[r * J + j] - chr * L.v1[j] * L.v2[1];
-            tpg::wsync();   // lanes J .. 15 duplicate row J - 1: everybody reads before anybody writes
-            L.b1[r] = chr * L.v2[0];
-            tpg::put<J>(L.C1, r, prow);
-        }
+    } else if (!tpb_head_state<J>(a, ev, L, l16, r, head)) {
+        return;
     }
-    tpg::wsync();
     const int64_t first = ev * n + (int64_t)k * gsize;
     tpg::Pre<J> pre;
     tpg::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l16);
 #pragma unroll 1
     for (int i = 0; i < gsize; ++i) {
         tpg::gcopy(states + (first + i) * MTG_TPB_STATE(J), L.b1, J + M, l16);
-        if (!CORR && i + 1 == gsize) break;
+        if (i + 1 == gsize) break;
         tpg::put_second<J>(L, pre, l16);
         if (i + 1 < gsize) tpg::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l16);
         tpg::wsync();
-        if (CORR) {
-            const double corr = i + 1 < gsize ? tpg::apply<J, true, true>(L, r) : tpg::apply<J, true, false>(L, r);
-            if (l16 == 0) parts[(first + i) * 4 + 3] = corr;
-        } else {
-            tpg::apply<J>(L, r);
-        }
+        tpg::apply<J>(L, r);
     }
 }
 
@@ -165,95 +255,60 @@ __global__ void __launch_bounds__(64) mtg_tpb_finish_kernel(MtgSolveArgs a, cons
     }
 }
 
-// Direct mode: lnL = sum over the chunks of [kappa_c (composition pass: the chunk's likelihood given
-// x_in = 0) + correction_c (down-sweep)] -- no filter pass.  kappa is computed under a wrong hypothesis, so
-// its residuals can be far larger than the true ones and the correction then cancels most of it; an
-// evaluation whose terms exceed 1e3 x the result (or with anything not positive / not finite on the way)
-// is appended to the redo list and goes through the filter pass, whose pivots are celerite's own.
-__global__ void __launch_bounds__(64) mtg_tpb_finish_direct_kernel(MtgSolveArgs a, const double *parts, const double *head, int C,
-                                                                   int *redo_list, int *redo_count)
+template <int J>
+void launch_up(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int kappa, hipStream_t s)
 {
-    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
-    if ((int64_t)blockIdx.x >= count) return;
-    const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
-    if (!a.list && a.status[ev] != MTG_ST_OK) return;
-    const int lane = threadIdx.x;
-    const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
-    if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) {
-        if (lane == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
-        return;
-    }
-    double dot = 0.0, ld = 0.0, dmin = INFINITY, corr = 0.0, mag = 0.0;
-    for (int c = lane; c < C; c += 64) {
-        const double *p = parts + (ev * C + c) * 4;
-        dot += p[0]; ld += p[1]; dmin = fmin(dmin, p[2]); corr += p[3]; mag += fabs(p[3]);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        dot += __shfl_down(dot, off);
-        ld += __shfl_down(ld, off);
-        dmin = fmin(dmin, __shfl_down(dmin, off));
-        corr += __shfl_down(corr, off);
-        mag += __shfl_down(mag, off);
-    }
-    if (lane == 0) {
-        const double *h = head + ev * 4;
-        mag += 0.5 * dot;
-        dot += h[0]; ld += h[1]; dmin = fmin(dmin, h[2]);
-        const double ll = corr - 0.5 * (dot + ld + (double)a.N * MTG_LN_2PI);
-        // a complex term with b d > a c has a power spectrum that goes negative: the matrix need not be positive
-        // definite and only the filter pass sees every pivot's sign (mtg_timeparallel.h, mtg_tp_eval)
-        bool psd = true;
-        const int nc = a.tp_nc0 - (a.sig ? a.sig[ev] : 0);
-        const double *cf = a.coef + ev;
-        for (int k = 0; k < nc; ++k)
-            if (!(fabs(cf[a.lay.bc(k) * a.cstride] * cf[a.lay.dc(k) * a.cstride])
-                  <= cf[a.lay.ac(k) * a.cstride] * cf[a.lay.cc(k) * a.cstride] * (1.0 + 1.0e-12)))
-                psd = false;
-        if (a.tp_direct >= 2 || (psd && dmin > 0.0 && isfinite(ll) && mag <= 1.0e3 * fabs(ll))) {  // 2: diagnostic, never redo
-            a.out[ev] = a.tp_direct == 3 ? dot : a.tp_direct == 4 ? ld : a.tp_direct == 5 ? corr : a.tp_direct == 6 ? mag : ll;
-            a.status[ev] = MTG_ST_OK;
-        } else {
-            redo_list[atomicAdd(redo_count, 1)] = (int)ev;
-        }
+    double *ws = a.tp_ws;
+    auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
+    for (int l = 0; l + 1 < p.nlev; ++l) {
+        const double *rec_in = ws + (l == 0 ? p.part_off : p.rec_off[l]);
+        if (kappa)
+            hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J, true>), blocks(p.n[l] / p.gl[l]), dim3(64), 0, s, a, ws + p.elem_off[l],
+                               ws + p.elem_off[l + 1], p.n[l], p.gl[l], rec_in, ws + p.rec_off[l + 1], l == 0 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J, false>), blocks(p.n[l] / p.gl[l]), dim3(64), 0, s, a, ws + p.elem_off[l],
+                               ws + p.elem_off[l + 1], p.n[l], p.gl[l], (const double *)nullptr, (double *)nullptr, 0);
     }
 }
 
 template <int J>
-void launch_scan(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int corr, hipStream_t s)
+void launch_top_direct(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int *redo_list, int *redo_count, hipStream_t s)
+{
+    double *ws = a.tp_ws;
+    const int top = p.nlev - 1;  // (the chunk count is at least 64, so the top level is never level 0)
+    hipLaunchKernelGGL((mtg_tpb_top_direct_kernel<J>), dim3((unsigned)((nevals + GROUPS - 1) / GROUPS)), dim3(64), 0, s, a,
+                       ws + p.elem_off[top], ws + p.rec_off[top], ws + p.head_off, p.n[top], redo_list, redo_count);
+}
+
+template <int J>
+void launch_down(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, hipStream_t s)
 {
     double *ws = a.tp_ws;
     auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
-    for (int l = 0; l + 1 < p.nlev; ++l)
-        hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
-                           ws + p.elem_off[l], ws + p.elem_off[l + 1], p.n[l], p.g);
     const int top = p.nlev - 1;
-    // (the chunk count is at least 64, so the top level is never level 0)
-    hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top],
-                       (const double *)nullptr, ws + p.state_off[top], ws + p.head_off, (double *)nullptr, p.n[top], p.n[top]);
-    for (int l = top - 1; l >= 0; --l) {
-        if (l == 0 && corr)
-            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, true>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
-                               ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
-                               ws + p.part_off, p.n[l], p.g);
-        else
-            hipLaunchKernelGGL((mtg_tpb_down_kernel<J, false>), blocks(p.n[l] / p.g), dim3(64), 0, s, a,
-                               ws + p.elem_off[l], ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off,
-                               (double *)nullptr, p.n[l], p.g);
-    }
+    hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top], (const double *)nullptr,
+                       ws + p.state_off[top], ws + p.head_off, p.n[top], p.n[top]);
+    for (int l = top - 1; l >= 0; --l)
+        hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(p.n[l] / p.gl[l]), dim3(64), 0, s, a, ws + p.elem_off[l],
+                           ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off, p.n[l], p.gl[l]);
 }
 
 }  // namespace
 
-void mtg_launch_tpb_scan(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int corr, hipStream_t stream)
+void mtg_launch_tpb_up(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int kappa, hipStream_t stream)
 {
-    if (J == 10) launch_scan<10>(a, plan, nevals, corr, stream);
+    if (J == 10) launch_up<10>(a, plan, nevals, kappa, stream);
 }
 
-void mtg_launch_tpb_finish_direct(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
-                                  int *redo_list, int *redo_count, hipStream_t stream)
+void mtg_launch_tpb_top_direct(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int *redo_list,
+                               int *redo_count, hipStream_t stream)
 {
-    hipLaunchKernelGGL(mtg_tpb_finish_direct_kernel, dim3((unsigned)nevals), dim3(64), 0, stream, a, parts, head, C, redo_list,
-                       redo_count);
+    if (J == 10) launch_top_direct<10>(a, plan, nevals, redo_list, redo_count, stream);
+}
+
+void mtg_launch_tpb_down(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, hipStream_t stream)
+{
+    if (J == 10) launch_down<10>(a, plan, nevals, stream);
 }
 
 void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
