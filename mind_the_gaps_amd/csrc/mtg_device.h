@@ -60,7 +60,7 @@ struct MtgPrepArgs {
     int32_t *sig;   // [B] number of over-damped SHO terms per evaluation, or NULL
     // a walker-sharded ensemble expands and solves only rows [row_lo, row_hi); the others get MTG_ST_REMOTE
     // (skipped by every solver like a prior rejection) until the all-gather brings the owner's result
-    int64_t row_lo, row_hi;
+    int64_t row_lo = 0, row_hi = INT64_MAX;
 };
 
 // status of a row another rank evaluates (internal: never visible after the exchange)

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+    # pytest-timeout registers this one itself; declared here too so that the suite runs without the plugin
+    config.addinivalue_line("markers", "timeout(seconds): fail a multi-process test that waits forever")
 
 
 @pytest.fixture(scope="session")

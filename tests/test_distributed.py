@@ -228,8 +228,29 @@ def test_failure_on_one_rank_reaches_every_rank(tmp_path):
     assert open(tmp_path / "fail0.txt").read() == "peer error" and open(tmp_path / "fail1.txt").read() == "own error"
 
 
+def _watchdog(out_dir, tag, seconds=240):
+    """A worker that is still running after `seconds` writes every thread's stack to out_dir and exits: a
+    deadlock between the ranks then fails the test with the place where each rank waited instead of hanging
+    the suite."""
+    import faulthandler
+    fh = open(os.path.join(out_dir, "hang_%s.txt" % tag), "w")
+    faulthandler.dump_traceback_later(seconds, exit=True, file=fh)
+    return fh
+
+
+def _spawn(fn, args, nprocs, out_dir):
+    import glob
+    import torch.multiprocessing as mp
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+    except Exception as exc:
+        dumps = "".join("\n--- %s ---\n%s" % (f, open(f).read()) for f in sorted(glob.glob(os.path.join(str(out_dir), "hang_*.txt"))))
+        raise AssertionError("worker failed: %s%s" % (exc, dumps))
+
+
 def _gpu_chain_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
+    guard = _watchdog(out_dir, "host%d_%d" % (world, rank))
     import warnings
     import torch.distributed as dist
     from mind_the_gaps_amd.gpmodelling import GPModelling
@@ -255,16 +276,19 @@ def _gpu_chain_worker(rank, world, port, out_dir):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+    guard.close()
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(330)
 def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
     """GPModelling.derive_posteriors(shard_walkers=True) on two ranks (sharing the box's GPU, gloo
     for the gather): identical chains on both, equal to the single-process host-sampler chain."""
-    import torch.multiprocessing as mp
     world, port = 2, _free_port()
-    mp.spawn(_gpu_chain_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    mp.spawn(_gpu_chain_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _spawn(_gpu_chain_worker, (world, port, str(tmp_path)), world, tmp_path)
+    _spawn(_gpu_chain_worker, (1, _free_port(), str(tmp_path)), 1, tmp_path)
     r0, r1, single = (np.load(tmp_path / name) for name in ("gpu2_0.npz", "gpu2_1.npz", "gpu1_0.npz"))
     assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
     assert np.allclose(single["chain"], r0["chain"], rtol=1e-9, atol=0) and np.allclose(single["lnp"], r0["lnp"], rtol=1e-9)
@@ -317,6 +341,8 @@ def test_host_exchange_of_the_sharded_device_ensemble_two_ranks(tmp_path):
 
 def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, transport):
     sys.path.insert(0, ROOT)
+    guard = _watchdog(out_dir, "dev_%s_%d_%d" % (case, world, rank))
+    import faulthandler
     import warnings
     import torch.distributed as dist
     from mind_the_gaps_amd.gp import get_engine
@@ -352,6 +378,8 @@ def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, 
             bound.ensemble_init(p0[None], seed=sampler.seed)
             chain, lnp = bound.ensemble_run(20, store_chain=True)
             np.savez(os.path.join(out_dir, "dev_%s_plain.npz" % case), chain=chain[:, 0], lnp=lnp[:, 0])
+            faulthandler.cancel_dump_traceback_later()
+            guard.close()
             return
         g.derive_posteriors(fit=False, max_steps=20, convergence_steps=20, walkers=walkers, progress=False,
                             device_sampler=True, shard_walkers=world > 1)
@@ -361,9 +389,12 @@ def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, 
         assert g.sampler.transport == "host"
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+    guard.close()
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(330)
 @pytest.mark.parametrize("case,tp_mode,n,walkers", [("sweep", 0, 300, 16), ("timeparallel", 1, 5000, 32),
                                                     ("ragged", 2, 300, 18)])
 def test_device_sampler_walker_sharded_two_ranks_one_gpu(tmp_path, case, tp_mode, n, walkers):
@@ -371,12 +402,9 @@ def test_device_sampler_walker_sharded_two_ranks_one_gpu(tmp_path, case, tp_mode
     the exchange is the host callback over gloo: RCCL refuses two ranks on one device): both ranks hold the
     same chain, and it is the one-process device chain BIT FOR BIT -- serial sweep, time-parallel kernels
     (same kernel whatever the number of rows) and a half-ensemble that does not split evenly (9 rows)."""
-    import torch.multiprocessing as mp
     world, port = 2, _free_port()
-    mp.spawn(_device_chain_worker, args=(world, port, str(tmp_path), case, tp_mode, n, walkers, "host"), nprocs=world,
-             join=True)
-    mp.spawn(_device_chain_worker, args=(1, _free_port(), str(tmp_path), case, tp_mode, n, walkers, "host"), nprocs=1,
-             join=True)
+    _spawn(_device_chain_worker, (world, port, str(tmp_path), case, tp_mode, n, walkers, "host"), world, tmp_path)
+    _spawn(_device_chain_worker, (1, _free_port(), str(tmp_path), case, tp_mode, n, walkers, "host"), 1, tmp_path)
     r0, r1, single = (np.load(tmp_path / ("dev_%s_%s.npz" % (case, name))) for name in ("2_0", "2_1", "1_0"))
     assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
     assert np.array_equal(single["chain"], r0["chain"]) and np.array_equal(single["lnp"], r0["lnp"])
@@ -385,12 +413,12 @@ def test_device_sampler_walker_sharded_two_ranks_one_gpu(tmp_path, case, tp_mode
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(330)
 def test_device_sampler_rccl_exchange_one_rank(tmp_path):
     """The RCCL transport end to end with a communicator of ONE rank (all a one-GPU box allows): library
     look-up, ncclGetUniqueId, ncclCommInitRank, the grouped in-place ncclAllGather pair on the engine's
     stream in every half-step, unshard -- and the chain equals the unsharded one bit for bit."""
-    import torch.multiprocessing as mp
-    mp.spawn(_device_chain_worker, args=(1, _free_port(), str(tmp_path), "one", 2, 300, 16, "rccl1"), nprocs=1, join=True)
+    _spawn(_device_chain_worker, (1, _free_port(), str(tmp_path), "one", 2, 300, 16, "rccl1"), 1, tmp_path)
     a, b = np.load(tmp_path / "dev_one_rccl.npz"), np.load(tmp_path / "dev_one_plain.npz")
     assert np.array_equal(a["chain"], b["chain"]) and np.array_equal(a["lnp"], b["lnp"])
     assert len(np.unique(a["chain"][:, :, 0])) > 16
