@@ -228,7 +228,7 @@ def test_failure_on_one_rank_reaches_every_rank(tmp_path):
     assert open(tmp_path / "fail0.txt").read() == "peer error" and open(tmp_path / "fail1.txt").read() == "own error"
 
 
-def _watchdog(out_dir, tag, seconds=240):
+def _watchdog(out_dir, tag, seconds=360):
     """A worker that is still running after `seconds` writes every thread's stack to out_dir and exits: a
     deadlock between the ranks then fails the test with the place where each rank waited instead of hanging
     the suite."""
@@ -282,7 +282,7 @@ def _gpu_chain_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(330)
+@pytest.mark.timeout(400)
 def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
     """GPModelling.derive_posteriors(shard_walkers=True) on two ranks (sharing the box's GPU, gloo
     for the gather): identical chains on both, equal to the single-process host-sampler chain."""
@@ -394,7 +394,7 @@ def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, 
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(330)
+@pytest.mark.timeout(400)
 @pytest.mark.parametrize("case,tp_mode,n,walkers", [("sweep", 0, 300, 16), ("timeparallel", 1, 5000, 32),
                                                     ("ragged", 2, 300, 18)])
 def test_device_sampler_walker_sharded_two_ranks_one_gpu(tmp_path, case, tp_mode, n, walkers):
@@ -413,7 +413,7 @@ def test_device_sampler_walker_sharded_two_ranks_one_gpu(tmp_path, case, tp_mode
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(330)
+@pytest.mark.timeout(400)
 def test_device_sampler_rccl_exchange_one_rank(tmp_path):
     """The RCCL transport end to end with a communicator of ONE rank (all a one-GPU box allows): library
     look-up, ncclGetUniqueId, ncclCommInitRank, the grouped in-place ncclAllGather pair on the engine's
