@@ -61,30 +61,42 @@ enum { PURPOSE_SPLIT = 1, PURPOSE_PROPOSE = 2, PURPOSE_ACCEPT = 3 };
 //     walker index); perm[e][0..W/2) is the first half.  Keys in LDS, W broadcast reads per walker.
 //   proposal: z = ((a - 1) u + 1)^2 / a,  q = c_partner - (c_partner - s) z,  factor = (P - 1) ln z.
 //   expansion: mtg_prepare_one on the proposal (prior verdict, coefficient columns, structure lists).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 mtg_propose_kernel(int W, int P, int half, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi, double a,
                    int32_t *__restrict__ perm, const double *__restrict__ coords, double *__restrict__ factor,
                    MtgPrepArgs pa)
 {
-    extern __shared__ uint64_t s_key[];
+    extern __shared__ uint64_t s_key[];   // W keys, then W ranks (int)
     const int H = W / 2;
     const int e = blockIdx.x;
     int32_t *p = perm + (int64_t)e * W;
     if (half == 0) {
+        int *s_rank = (int *)(s_key + W);
         for (int w = threadIdx.x; w < W; w += blockDim.x) {
             const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, seed_lo, seed_hi);
             s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
+            s_rank[w] = 0;
         }
         __syncthreads();
-        for (int w = threadIdx.x; w < W; w += blockDim.x) {
+        // rank of every key: W^2 comparisons spread over all the threads of the workgroup -- `parts` threads per
+        // walker, each counting over its share of the keys (one thread per walker and 512 serial comparisons were
+        // 12 us of the 25 us this kernel took at W = 256)
+        const int parts = blockDim.x >= (unsigned)W ? (int)blockDim.x / W : 1;
+        const int span = (W + parts - 1) / parts;
+        for (int i = threadIdx.x; i < W * parts; i += blockDim.x) {
+            const int w = i % W, part = i / W;
             const uint64_t mine = s_key[w];
+            const int j0 = part * span, j1 = j0 + span < W ? j0 + span : W;
             int rank = 0;
-            for (int j = 0; j < W; ++j) {
+            for (int j = j0; j < j1; ++j) {
                 const uint64_t other = s_key[j];
                 rank += (other < mine) || (other == mine && j < w);
             }
-            p[rank] = w;
+            if (parts > 1) atomicAdd(&s_rank[w], rank);
+            else s_rank[w] = rank;
         }
+        __syncthreads();
+        for (int w = threadIdx.x; w < W; w += blockDim.x) p[s_rank[w]] = w;
         __syncthreads();  // the permutation is read back below (same workgroup: visible after the barrier)
     }
     double *q = const_cast<double *>(pa.theta);  // the proposals ARE the batch the expansion reads
@@ -187,8 +199,11 @@ mtg_initial_best_kernel(int E, int W, int P, const double *__restrict__ coords, 
 void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a, int32_t *perm,
                         const double *coords, double *factor, const MtgPrepArgs &pa, hipStream_t s)
 {
-    const int threads = W / 2 >= 256 ? 256 : (W / 2 + 63) / 64 * 64;
-    hipLaunchKernelGGL(mtg_propose_kernel, dim3(E), dim3(threads), (size_t)W * sizeof(uint64_t), s, W, P, half, iteration,
+    // the proposals need W / 2 threads; the split of the first half-step ranks W keys against each other and
+    // takes as many threads as a workgroup of a few ensembles can have (many ensembles: the GPU is full anyway)
+    int threads = W / 2 >= 256 ? 256 : (W / 2 + 63) / 64 * 64;
+    if (half == 0 && E <= 64) threads = 1024;
+    hipLaunchKernelGGL(mtg_propose_kernel, dim3(E), dim3(threads), (size_t)W * (sizeof(uint64_t) + sizeof(int)), s, W, P, half, iteration,
                        (uint32_t)seed, (uint32_t)(seed >> 32), a, perm, coords, factor, pa);
 }
 
