@@ -365,7 +365,7 @@ def main():
                 # what binds the kernel is FP64 vector issue (fp64_valu below, profiles/): 256 walkers share a
                 # light curve through L2 / MALL and the real HBM traffic is ~1 % of the algorithmic bytes
                 "bound": "fp64_valu",
-                "kernel": "mtg_solve_kernel<1,2>",
+                "kernel": "mtg_solve_kernel<1,2,1>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
