@@ -19,7 +19,7 @@ region.  "weak" gives every rank its own 2000 light curves instead.
 
 The JSON line also carries
   roofline        : algorithmic bytes (24 N + 8 P + 12 per evaluation) / mean
-                    duration of the dominant kernel (mtg_solve_kernel<1,2>), HIP events on the launch
+                    duration of the dominant kernel (mtg_solve_kernel<1,2,1>), HIP events on the launch
                     stream; the binding resource is FP64 vector issue (bound: "fp64_valu");
   end_to_end      : the same sweep through the host-pointer entry point (H2D theta, kernels, D2H);
   strong_shard_8  : one GPU on the share it gets of the 2000 light curves at 8 GPUs (250);
@@ -39,9 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# FP64 operations per sample and lane of mtg_solve_kernel<1,2> (93 fma + 53 mul/add in kernel v7;
-# scripts/loop_stats.py counts the compiled loop)
-FLOP_PER_SAMPLE = 2 * 93 + 53
+# FP64 operations per sample and lane of mtg_solve_kernel<1,2,1> (91 fma + 53 mul/add in kernel v8;
+# `scripts/loop_stats.py 1 2 1` counts the compiled loop: 182 fma + 106 mul/add per two steps)
+FLOP_PER_SAMPLE = 2 * 91 + 53
 
 
 def parse():
