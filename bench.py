@@ -176,6 +176,24 @@ def single_lightcurve_configs():
         evals = steps * walkers / el
         out[name] = {"iterations_per_s": steps / el, "evals_per_s": evals, "iterations_timed": steps,
                      "algorithmic_hbm_frac": evals * (24 * n + 8 * (P - 6) + 12) / (HBM_PEAK_GBS * 1e9)}
+        if n == 200000:
+            # what walker sharding over 8 GPUs can gain on this chain: device time of one half-step's likelihoods for
+            # the whole half-ensemble (256 rows) and for one rank's share of it (32 rows), same engine, same model
+            from mind_the_gaps_amd.gp import get_engine
+            eng = get_engine(0)
+            theta = np.asarray(g.sampler.get_chain()[-1], dtype=np.float64)
+            ms = {}
+            for rows in (256, 32):
+                best = np.inf
+                for _ in range(3):
+                    eng.loglike(theta[:rows])
+                    best = min(best, eng.last_kernel_ms)
+                ms[rows] = best
+            out[name]["walker_shard_8"] = {
+                "half_step_ms_256_rows": ms[256], "half_step_ms_32_rows": ms[32], "speedup": ms[256] / ms[32],
+                "what": "likelihoods of one half-step on one MI355X: the whole half-ensemble against the 32 rows a rank "
+                        "evaluates when the walkers are sharded over 8 GPUs (mtg_ensemble_shard_rccl); the exchange is one "
+                        "all-gather of 256 doubles + status words per half-step"}
     return out
 
 

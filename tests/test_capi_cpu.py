@@ -53,3 +53,14 @@ def test_pure_queries_need_no_gpu():
 def test_fails_loudly_without_gpu():
     with pytest.raises(engine.EngineUnavailable):
         engine.Engine(0)
+
+
+def test_sharding_entry_points_check_their_arguments_without_a_gpu():
+    """mtg_ensemble_shard_* / mtg_rccl_unique_id with no context or no buffer: MTG_E_ARG, nothing touched."""
+    import ctypes
+    lib = engine.load_library()
+    noop = engine.EXCHANGE_FN(lambda user, lnp, status, count, lo, hi: 0)
+    assert lib.mtg_ensemble_shard_host(None, 0, 1, noop, None) == engine.E_ARG
+    assert lib.mtg_ensemble_shard_rccl(None, ctypes.create_string_buffer(128), 0, 1) == engine.E_ARG
+    assert lib.mtg_ensemble_unshard(None) == engine.E_ARG
+    assert lib.mtg_rccl_unique_id(None) == engine.E_ARG
