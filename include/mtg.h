@@ -226,6 +226,16 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
 
 /*
+ * Walker-averaged, normalised autocorrelation function of a chain -- the inner loop of the convergence
+ * check of mind_the_gaps/gpmodelling.py:260-272 (emcee.autocorr.integrated_time: function_1d of every
+ * walker and dimension by zero-padded FFT, each normalised by its lag-0 value, averaged over the walkers).
+ * chain: host [n_t][W][P]; rho: host out [n_t][P].  On the device: S = W * P batched forward transforms,
+ * power spectra normalised and averaged over the walkers, P inverse transforms (hipFFT, the only library
+ * call).  A walker that never moved yields NaN in its dimension, as emcee does.
+ */
+MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int W, int P, const double *chain, double *rho);
+
+/*
  * Walker sharding of the resident ensembles across the GPUs of a job (one process per GPU; the
  * reference's counterpart is the multiprocessing.Pool.map over the half-ensemble of
  * mind_the_gaps/gpmodelling.py:245-248).  Every process calls mtg_ensemble_init with the SAME

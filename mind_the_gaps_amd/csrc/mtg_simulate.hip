@@ -260,3 +260,97 @@ void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int
                        seg_len, dt, scale, mean_rate, series, win_lo, win_hi, noise_kind, sigma_noise, exposures,
                        fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), clean, rates, dy);
 }
+
+
+// ---------------------------------------------------------------------------
+// Walker-averaged autocorrelation function of a chain (the convergence check of derive_posteriors,
+// gpmodelling.py:260-272 -> emcee.autocorr.integrated_time -> function_1d per walker and dimension)
+// ---------------------------------------------------------------------------
+// chain[n_t][S] with S = W * P series (walker-major, dimension fastest).  emcee computes, per series, the
+// autocorrelation by zero-padded FFT, normalises it by its lag-0 value and averages over the walkers.  The
+// inverse transform is linear, so the power spectra are normalised (lag 0 of a series = the sum of its squares)
+// and averaged BEFORE it: S forward transforms, P inverse ones.  The transforms read and write the [time][series]
+// layout directly (stride S), so every kernel here is coalesced over the series.
+
+// Sums over time in two deterministic steps (a chain can be 10^5 steps of only a few dozen series, so the time
+// axis has to be spread over workgroups): partial[tile][s] = sum over the tile's steps of v or (v - mean)^2, then
+// the tiles added in order.  MTG_ACF_TILE steps per tile.
+#define MTG_ACF_TILE 256
+// SQUARES = false: partial sums of the chain;  true: x[t][s] = chain - mean (zero for t >= n_t) written and the
+// partial sums of its squares
+template <bool SQUARES>
+__global__ void __launch_bounds__(256) mtg_acf_tile_kernel(int64_t n_t, int64_t n2, int64_t S, const double *chain, const double *mean,
+                                                         double *x, double *partial)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int64_t t0 = (int64_t)blockIdx.y * MTG_ACF_TILE, t1 = t0 + MTG_ACF_TILE < n2 ? t0 + MTG_ACF_TILE : n2;
+    const double m = SQUARES ? mean[s] : 0.0;
+    double acc = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        if (SQUARES) {
+            const double v = t < n_t ? chain[t * S + s] - m : 0.0;
+            x[t * S + s] = v;
+            acc = fma(v, v, acc);
+        } else if (t < n_t) {
+            acc += chain[t * S + s];
+        }
+    }
+    partial[(int64_t)blockIdx.y * S + s] = acc;
+}
+
+// out[s] = scale * sum over the tiles (in order) of partial[tile][s]
+__global__ void __launch_bounds__(256) mtg_acf_fold_kernel(int64_t tiles, int64_t S, double scale, const double *partial, double *out)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    double acc = 0.0;
+    for (int64_t k = 0; k < tiles; ++k) acc += partial[k * S + s];
+    out[s] = acc * scale;
+}
+
+// g[k][p] = mean over the walkers of |f[k][w][p]|^2 / sumsq[w][p]   (a real spectrum: imaginary part 0)
+__global__ void __launch_bounds__(256) mtg_acf_power_kernel(int64_t nk, int W, int P, const double2 *f, const double *sumsq, double2 *g)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nk * P) return;
+    const int64_t k = i / P;
+    const int p = (int)(i % P);
+    const double2 *row = f + k * (int64_t)W * P;
+    double acc = 0.0;
+    for (int w = 0; w < W; ++w) {
+        const double2 v = row[(int64_t)w * P + p];
+        acc += (v.x * v.x + v.y * v.y) / sumsq[(int64_t)w * P + p];   // 0 / 0 = NaN for a walker that never moved, as emcee has it
+    }
+    g[i] = make_double2(acc / (double)W, 0.0);
+}
+
+__global__ void __launch_bounds__(256) mtg_acf_scale_kernel(int64_t n, double scale, double *r)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] *= scale;
+}
+
+// x[t][s] (t < n2) = centred, zero-padded chain; sumsq[s]; `scratch`: (n2 / MTG_ACF_TILE + 1) * S + S doubles
+void mtg_launch_acf_center(int64_t n_t, int64_t n2, int64_t S, const double *chain, double *x, double *sumsq, double *scratch,
+                           hipStream_t s)
+{
+    const int64_t tiles = (n2 + MTG_ACF_TILE - 1) / MTG_ACF_TILE, tiles_in = (n_t + MTG_ACF_TILE - 1) / MTG_ACF_TILE;
+    double *partial = scratch, *mean = scratch + tiles * S;
+    const dim3 block(64), cols((unsigned)((S + 63) / 64));
+    hipLaunchKernelGGL((mtg_acf_tile_kernel<false>), dim3(cols.x, (unsigned)tiles_in), block, 0, s, n_t, n2, S, chain,
+                       (const double *)nullptr, (double *)nullptr, partial);
+    hipLaunchKernelGGL(mtg_acf_fold_kernel, cols, block, 0, s, tiles_in, S, 1.0 / (double)n_t, partial, mean);
+    hipLaunchKernelGGL((mtg_acf_tile_kernel<true>), dim3(cols.x, (unsigned)tiles), block, 0, s, n_t, n2, S, chain, mean, x, partial);
+    hipLaunchKernelGGL(mtg_acf_fold_kernel, cols, block, 0, s, tiles, S, 1.0, partial, sumsq);
+}
+
+void mtg_launch_acf_power(int64_t nk, int W, int P, const double2 *f, const double *sumsq, double2 *g, hipStream_t s)
+{
+    hipLaunchKernelGGL(mtg_acf_power_kernel, dim3((unsigned)((nk * P + 255) / 256)), dim3(256), 0, s, nk, W, P, f, sumsq, g);
+}
+
+void mtg_launch_acf_scale(int64_t n, double scale, double *r, hipStream_t s)
+{
+    hipLaunchKernelGGL(mtg_acf_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, scale, r);
+}

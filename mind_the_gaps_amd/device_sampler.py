@@ -14,6 +14,36 @@ from .sampler import integrated_time
 
 __all__ = ["DeviceEnsembleSampler"]
 
+# The convergence check runs on the whole chain every time it is made.  On the device (Engine.chain_autocorr) it
+# costs ~1 ms where the host's FFTs take 10-200 ms (1000 x 256 x 8: 0.7 against 30 ms; 50 000 x 12 x 5: 1.2 against
+# 54 ms) -- once hipFFT is up (~1.3 s the first time in a process) and a plan for the padded length exists (~13 ms
+# each).  So: rent before buying.  The host does the checks until it has spent as long as the start-up costs (or a
+# single check would), and a new plan is made only where the host would take longer than making it.
+HOST_SECONDS_PER_POINT = 1.1e-8      # measured: 7 ms for 6.4e5 points, 30 ms for 2e6, 220 ms for 2e7
+FFT_STARTUP_SECONDS, FFT_PLAN_SECONDS = 1.3, 0.013
+
+
+def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
+    import time
+    n_t = chain.shape[0]
+    key = (1 << max(n_t - 1, 1).bit_length(),) + chain.shape[1:]
+    state = engine.__dict__.setdefault("_acf_state", {"ready": False, "key": None, "host_seconds": 0.0})
+    estimate = HOST_SECONDS_PER_POINT * chain.size
+    if getattr(engine, "fft_ready", False):      # the simulator has started hipFFT already
+        state["ready"] = True
+    if state["ready"]:
+        on_device = key == state["key"] or estimate > FFT_PLAN_SECONDS
+    else:
+        on_device = state["host_seconds"] > FFT_STARTUP_SECONDS or estimate > FFT_STARTUP_SECONDS
+    if on_device and chain.ndim == 3 and n_t >= 2:
+        state["ready"], state["key"] = True, key
+        return integrated_time(chain, acf=engine.chain_autocorr, **kwargs)
+    t0 = time.perf_counter()
+    try:
+        return integrated_time(chain, **kwargs)
+    finally:
+        state["host_seconds"] += time.perf_counter() - t0
+
 
 class DeviceEnsembleSampler:
     """E lock-step ensembles of ``nwalkers`` walkers on one engine (E = 1 mirrors emcee).
@@ -86,7 +116,10 @@ class DeviceEnsembleSampler:
         return self._get(self._log_prob, flat, thin, discard, ensemble)
 
     def get_autocorr_time(self, discard=0, thin=1, ensemble=0, **kwargs):
-        return thin * integrated_time(self.get_chain(discard=discard, thin=thin, ensemble=ensemble), **kwargs)
+        chain = self.get_chain(discard=discard, thin=thin, ensemble=ensemble)
+        if "acf" not in kwargs:
+            return thin * _autocorr_time_where_it_is_cheapest(self._bind(), chain, kwargs)
+        return thin * integrated_time(chain, **kwargs)
 
     @property
     def acceptance_fraction(self):

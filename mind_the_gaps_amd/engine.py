@@ -32,6 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
+    "mtg_chain_autocorr",
 )
 
 # the exchange of a walker-sharded ensemble as a callback (include/mtg.h, mtg_exchange_fn)
@@ -139,6 +140,8 @@ def load_library():
     lib.mtg_ensemble_shard_host.argtypes = [c_vp, c_int, c_int, EXCHANGE_FN, c_vp]
     lib.mtg_ensemble_unshard.restype = c_int
     lib.mtg_ensemble_unshard.argtypes = [c_vp]
+    lib.mtg_chain_autocorr.restype = c_int
+    lib.mtg_chain_autocorr.argtypes = [c_vp, c_i64, c_int, c_int, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_simulate_tk95.restype = c_int
@@ -382,6 +385,18 @@ class Engine:
         self._check(self._lib.mtg_ensemble_run(self._ctx, int(steps), _ptr(chain), _ptr(lnp)))
         return chain, lnp
 
+    def chain_autocorr(self, chain):
+        """chain [n_t][W][P] -> walker-averaged normalised autocorrelation function [n_t][P] (emcee's
+        ``function_1d`` per walker and dimension, averaged), computed on the device."""
+        chain = _f64(chain)
+        if chain.ndim != 3:
+            raise ValueError("chain must be [n_t][W][P]")
+        n_t, W, P = chain.shape
+        rho = np.empty((n_t, P))
+        self._check(self._lib.mtg_chain_autocorr(self._ctx, n_t, W, P, _ptr(chain), _ptr(rho)))
+        self.fft_ready = True
+        return rho
+
     def ensemble_state(self):
         """dict(coords, log_prob, best_log_prob, best_coords, naccept, iteration, n_not_pd)."""
         E, W, P = self._ens_shape
@@ -425,6 +440,7 @@ class Engine:
             int(seed) & 0xFFFFFFFFFFFFFFFF, int(nfft), float(sim_dt), float(mean_rate),
             int(seg_len), _iptr(lo), _iptr(hi), int(noise_kind), float(sigma_noise), _ptr(expo), _ptr(clean),
             _ptr(rates), _ptr(dy), _ptr(means), _ptr(segments), int(bool(make_resident))))
+        self.fft_ready = True   # hipFFT is up from here on (device_sampler: the convergence check may use it at once)
         if make_resident:
             self.L = S
         return dict(rates=rates, dy=dy, means=means, clean=clean, segments=segments)

@@ -56,10 +56,11 @@ def _mean_autocorr_function(x):
     return np.ascontiguousarray(acf.T)
 
 
-def integrated_time(x, c=5, tol=50, quiet=False):
+def integrated_time(x, c=5, tol=50, quiet=False, acf=None):
     """Integrated autocorrelation time of x[n_t, n_walkers, n_dim] per dimension:
     walker-averaged autocorrelation function, tau(M) = 2 sum_{k<=M} rho_k - 1, window
-    M = first index with M >= c tau(M) (Sokal)."""
+    M = first index with M >= c tau(M) (Sokal).  ``acf``: a callable chain[n_t, W, P] -> rho[n_t, P] to use
+    instead of the host FFTs (``Engine.chain_autocorr``: the same numbers from the device)."""
     x = np.atleast_1d(x)
     if x.ndim == 1:
         x = x[:, None, None]
@@ -68,7 +69,7 @@ def integrated_time(x, c=5, tol=50, quiet=False):
     if x.ndim != 3:
         raise ValueError("invalid dimensions")
     n_t, n_w, n_d = x.shape
-    rho = _mean_autocorr_function(x)                       # [n_t, n_d]
+    rho = _mean_autocorr_function(x) if acf is None else acf(x)   # [n_t, n_d]
     taus = 2.0 * np.cumsum(rho, axis=0) - 1.0
     tau_est = np.empty(n_d)
     lags = np.arange(n_t)

@@ -75,3 +75,26 @@ def test_device_sampler_statistics_and_prior_box(engine):
     assert not np.array_equal(chain2, chain[:5])
     with pytest.raises(Exception):
         engine.ensemble_init(p0[:, :3], seed=1)          # fewer walkers than 2 * ndim (and odd)
+
+
+def test_chain_autocorr_on_the_device_matches_the_host(engine):
+    """mtg_chain_autocorr against sampler._mean_autocorr_function (emcee's function_1d per walker and dimension,
+    averaged): correlated chains of several shapes, lengths on both sides of a power of two, and through
+    integrated_time(acf=...)."""
+    from mind_the_gaps_amd.sampler import _mean_autocorr_function, integrated_time
+    rng = np.random.default_rng(3)
+    for n_t, W, P in ((2, 2, 1), (37, 6, 3), (512, 32, 5), (1000, 128, 5), (1025, 12, 15)):
+        x = rng.standard_normal((n_t, W, P))
+        for t in range(1, n_t):                       # AR(1) with a different memory per dimension
+            x[t] += (0.5 + 0.45 * np.arange(P) / max(P - 1, 1)) * x[t - 1]
+        ref = _mean_autocorr_function(x)
+        got = engine.chain_autocorr(x)
+        assert got.shape == ref.shape == (n_t, P)
+        assert np.max(np.abs(got - ref)) < 1e-11, (n_t, W, P, np.max(np.abs(got - ref)))
+        if n_t >= 500:
+            assert np.allclose(integrated_time(x, tol=0, acf=engine.chain_autocorr), integrated_time(x, tol=0),
+                               rtol=1e-9, atol=0)
+    still = rng.standard_normal((64, 4, 2))
+    still[:, 1, 0] = 1.25                              # a walker that never moved: NaN in its dimension, as emcee
+    got = engine.chain_autocorr(still)
+    assert np.all(np.isnan(got[:, 0])) and np.all(np.isfinite(got[:, 1]))
