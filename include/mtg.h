@@ -229,11 +229,12 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
  * Walker-averaged, normalised autocorrelation function of a chain -- the inner loop of the convergence
  * check of mind_the_gaps/gpmodelling.py:260-272 (emcee.autocorr.integrated_time: function_1d of every
  * walker and dimension by zero-padded FFT, each normalised by its lag-0 value, averaged over the walkers).
- * chain: host [n_t][W][P]; rho: host out [n_t][P].  On the device: S = W * P batched forward transforms,
- * power spectra normalised and averaged over the walkers, P inverse transforms (hipFFT, the only library
- * call).  A walker that never moved yields NaN in its dimension, as emcee does.
+ * chain: host [n_t][E][W][P] for E independent ensembles (E = 1: one chain); rho: host out [n_t][E][P].  On
+ * the device: E * W * P batched forward transforms, power spectra normalised and averaged over each ensemble's
+ * walkers, E * P inverse transforms (hipFFT, the only library call).  A walker that never moved yields NaN in
+ * its dimension, as emcee does.
  */
-MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int W, int P, const double *chain, double *rho);
+MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int P, const double *chain, double *rho);
 
 /*
  * Walker sharding of the resident ensembles across the GPUs of a job (one process per GPU; the

@@ -103,7 +103,7 @@ struct mtg_ctx {
     hipfftHandle acf_fwd = 0, acf_inv = 0;
     bool acf_plans = false;
     int64_t acf_n2 = 0, acf_S = 0;
-    int acf_P = 0;
+    int64_t acf_P = 0;
     DevBuf acf_chain, acf_x, acf_f, acf_g, acf_r, acf_ss, acf_tmp;
 
     // side streams: the structures (signatures) of a small batch run next to each other
@@ -1136,14 +1136,15 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     return MTG_OK;
 }
 
-MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int W, int P, const double *chain, double *rho)
+MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int P, const double *chain, double *rho)
 {
     if (!ctx) return MTG_E_ARG;
-    if (n_t < 2 || W < 1 || P < 1 || !chain || !rho) return fail(ctx, MTG_E_ARG, "mtg_chain_autocorr: bad arguments");
+    if (n_t < 2 || E < 1 || W < 1 || P < 1 || !chain || !rho) return fail(ctx, MTG_E_ARG, "mtg_chain_autocorr: bad arguments");
     int64_t n = 1;
     while (n < n_t) n *= 2;
-    const int64_t n2 = 2 * n, nk = n + 1, S = (int64_t)W * P;
-    if (n2 > ((int64_t)1 << 30) || S > ((int64_t)1 << 24)) return fail(ctx, MTG_E_ARG, "mtg_chain_autocorr: chain too large");
+    const int64_t n2 = 2 * n, nk = n + 1, S = E * (int64_t)W * P, EP = E * P;
+    if (n2 > ((int64_t)1 << 30) || S > ((int64_t)1 << 24) || n2 * S > ((int64_t)1 << 32))
+        return fail(ctx, MTG_E_ARG, "mtg_chain_autocorr: chain too large");
     int rc = use_device(ctx);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
@@ -1152,35 +1153,35 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int W, int P, const do
     HIP_TRY(ctx, d_chain.reserve((size_t)n_t * S * 8));
     HIP_TRY(ctx, d_x.reserve((size_t)n2 * S * 8));
     HIP_TRY(ctx, d_f.reserve((size_t)nk * S * 16));
-    HIP_TRY(ctx, d_g.reserve((size_t)nk * P * 16));
-    HIP_TRY(ctx, d_r.reserve((size_t)n2 * P * 8));
+    HIP_TRY(ctx, d_g.reserve((size_t)nk * EP * 16));
+    HIP_TRY(ctx, d_r.reserve((size_t)n2 * EP * 8));
     HIP_TRY(ctx, d_ss.reserve((size_t)S * 8));
     HIP_TRY(ctx, ctx->acf_tmp.reserve((size_t)((n2 / 256 + 2) * S) * 8));
     HIP_TRY(ctx, hipMemcpyAsync(d_chain.p, chain, (size_t)n_t * S * 8, hipMemcpyHostToDevice, s));
     mtg_launch_acf_center(n_t, n2, S, d_chain.as<double>(), d_x.as<double>(), d_ss.as<double>(), ctx->acf_tmp.as<double>(), s);
     // transforms over the [time][series] layout: element stride = number of series, consecutive series 1 apart
-    if (!ctx->acf_plans || ctx->acf_n2 != n2 || ctx->acf_S != S || ctx->acf_P != P) {
+    if (!ctx->acf_plans || ctx->acf_n2 != n2 || ctx->acf_S != S || ctx->acf_P != EP) {
         if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); ctx->acf_plans = false; }
         int len = (int)n2, emb = (int)n2, embk = (int)nk;
         if (hipfftPlanMany(&ctx->acf_fwd, 1, &len, &emb, (int)S, 1, &embk, (int)S, 1, HIPFFT_D2Z, (int)S) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (forward) failed");
-        if (hipfftPlanMany(&ctx->acf_inv, 1, &len, &embk, P, 1, &emb, P, 1, HIPFFT_Z2D, P) != HIPFFT_SUCCESS) {
+        if (hipfftPlanMany(&ctx->acf_inv, 1, &len, &embk, (int)EP, 1, &emb, (int)EP, 1, HIPFFT_Z2D, (int)EP) != HIPFFT_SUCCESS) {
             (void)hipfftDestroy(ctx->acf_fwd);
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (inverse) failed");
         }
-        ctx->acf_plans = true; ctx->acf_n2 = n2; ctx->acf_S = S; ctx->acf_P = P;
+        ctx->acf_plans = true; ctx->acf_n2 = n2; ctx->acf_S = S; ctx->acf_P = EP;
         if (hipfftSetStream(ctx->acf_fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(ctx->acf_inv, s) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftSetStream failed");
     }
     struct { hipfftHandle h; } fwd{ctx->acf_fwd}, inv{ctx->acf_inv};
     if (hipfftExecD2Z(fwd.h, d_x.as<double>(), (hipfftDoubleComplex *)d_f.p) != HIPFFT_SUCCESS)
         return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftExecD2Z failed");
-    mtg_launch_acf_power(nk, W, P, d_f.as<double2>(), d_ss.as<double>(), d_g.as<double2>(), s);
+    mtg_launch_acf_power(nk, E, W, P, d_f.as<double2>(), d_ss.as<double>(), d_g.as<double2>(), s);
     if (hipfftExecZ2D(inv.h, (hipfftDoubleComplex *)d_g.p, d_r.as<double>()) != HIPFFT_SUCCESS)
         return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftExecZ2D failed");
-    mtg_launch_acf_scale(n_t * P, 1.0 / (double)n2, d_r.as<double>(), s);   // hipFFT does not normalise
+    mtg_launch_acf_scale(n_t * EP, 1.0 / (double)n2, d_r.as<double>(), s);   // hipFFT does not normalise
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(rho, d_r.p, (size_t)n_t * P * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(rho, d_r.p, (size_t)n_t * EP * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return MTG_OK;
 }

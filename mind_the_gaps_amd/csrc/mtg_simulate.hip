@@ -266,7 +266,7 @@ void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int
 // Walker-averaged autocorrelation function of a chain (the convergence check of derive_posteriors,
 // gpmodelling.py:260-272 -> emcee.autocorr.integrated_time -> function_1d per walker and dimension)
 // ---------------------------------------------------------------------------
-// chain[n_t][S] with S = W * P series (walker-major, dimension fastest).  emcee computes, per series, the
+// chain[n_t][S] with S = E * W * P series (ensemble, walker, dimension fastest).  emcee computes, per series, the
 // autocorrelation by zero-padded FFT, normalises it by its lag-0 value and averages over the walkers.  The
 // inverse transform is linear, so the power spectra are normalised (lag 0 of a series = the sum of its squares)
 // and averaged BEFORE it: S forward transforms, P inverse ones.  The transforms read and write the [time][series]
@@ -309,18 +309,20 @@ __global__ void __launch_bounds__(256) mtg_acf_fold_kernel(int64_t tiles, int64_
     out[s] = acc * scale;
 }
 
-// g[k][p] = mean over the walkers of |f[k][w][p]|^2 / sumsq[w][p]   (a real spectrum: imaginary part 0)
-__global__ void __launch_bounds__(256) mtg_acf_power_kernel(int64_t nk, int W, int P, const double2 *f, const double *sumsq, double2 *g)
+// g[k][e][p] = mean over the walkers of ensemble e of |f[k][e][w][p]|^2 / sumsq[e][w][p]   (a real spectrum)
+__global__ void __launch_bounds__(256) mtg_acf_power_kernel(int64_t nk, int64_t E, int W, int P, const double2 *f, const double *sumsq,
+                                                          double2 *g)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nk * P) return;
-    const int64_t k = i / P;
-    const int p = (int)(i % P);
-    const double2 *row = f + k * (int64_t)W * P;
+    if (i >= nk * E * P) return;
+    const int64_t k = i / (E * P), ep = i % (E * P), e = ep / P;
+    const int p = (int)(ep % P);
+    const int64_t first = e * (int64_t)W * P + p;
+    const double2 *row = f + k * E * (int64_t)W * P + first;
     double acc = 0.0;
     for (int w = 0; w < W; ++w) {
-        const double2 v = row[(int64_t)w * P + p];
-        acc += (v.x * v.x + v.y * v.y) / sumsq[(int64_t)w * P + p];   // 0 / 0 = NaN for a walker that never moved, as emcee has it
+        const double2 v = row[(int64_t)w * P];
+        acc += (v.x * v.x + v.y * v.y) / sumsq[first + (int64_t)w * P];   // 0 / 0 = NaN for a walker that never moved, as emcee has it
     }
     g[i] = make_double2(acc / (double)W, 0.0);
 }
@@ -345,9 +347,9 @@ void mtg_launch_acf_center(int64_t n_t, int64_t n2, int64_t S, const double *cha
     hipLaunchKernelGGL(mtg_acf_fold_kernel, cols, block, 0, s, tiles, S, 1.0, partial, sumsq);
 }
 
-void mtg_launch_acf_power(int64_t nk, int W, int P, const double2 *f, const double *sumsq, double2 *g, hipStream_t s)
+void mtg_launch_acf_power(int64_t nk, int64_t E, int W, int P, const double2 *f, const double *sumsq, double2 *g, hipStream_t s)
 {
-    hipLaunchKernelGGL(mtg_acf_power_kernel, dim3((unsigned)((nk * P + 255) / 256)), dim3(256), 0, s, nk, W, P, f, sumsq, g);
+    hipLaunchKernelGGL(mtg_acf_power_kernel, dim3((unsigned)((nk * E * P + 255) / 256)), dim3(256), 0, s, nk, E, W, P, f, sumsq, g);
 }
 
 void mtg_launch_acf_scale(int64_t n, double scale, double *r, hipStream_t s)

@@ -24,8 +24,17 @@ FFT_STARTUP_SECONDS, FFT_PLAN_SECONDS = 1.3, 0.013
 
 
 def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
+    """chain[n_t, W, P] -> tau[P]; or chain[n_t, E, W, P] (independent ensembles) -> tau[E, P]."""
     import time
     n_t = chain.shape[0]
+    many = chain.ndim == 4
+
+    def taus(rho):
+        if not many:
+            return integrated_time(chain, acf=None if rho is None else (lambda _x: rho), **kwargs)
+        return np.array([integrated_time(chain[:, e], acf=None if rho is None else (lambda _x, e=e: rho[:, e]), **kwargs)
+                         for e in range(chain.shape[1])])
+
     key = (1 << max(n_t - 1, 1).bit_length(),) + chain.shape[1:]
     state = engine.__dict__.setdefault("_acf_state", {"ready": False, "key": None, "host_seconds": 0.0})
     estimate = HOST_SECONDS_PER_POINT * chain.size
@@ -35,12 +44,12 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
         on_device = key == state["key"] or estimate > FFT_PLAN_SECONDS
     else:
         on_device = state["host_seconds"] > FFT_STARTUP_SECONDS or estimate > FFT_STARTUP_SECONDS
-    if on_device and chain.ndim == 3 and n_t >= 2:
+    if on_device and n_t >= 2:
         state["ready"], state["key"] = True, key
-        return integrated_time(chain, acf=engine.chain_autocorr, **kwargs)
+        return taus(engine.chain_autocorr(chain))
     t0 = time.perf_counter()
     try:
-        return integrated_time(chain, **kwargs)
+        return taus(None)
     finally:
         state["host_seconds"] += time.perf_counter() - t0
 

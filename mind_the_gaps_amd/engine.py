@@ -141,7 +141,7 @@ def load_library():
     lib.mtg_ensemble_unshard.restype = c_int
     lib.mtg_ensemble_unshard.argtypes = [c_vp]
     lib.mtg_chain_autocorr.restype = c_int
-    lib.mtg_chain_autocorr.argtypes = [c_vp, c_i64, c_int, c_int, _dp, _dp]
+    lib.mtg_chain_autocorr.argtypes = [c_vp, c_i64, c_i64, c_int, c_int, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_simulate_tk95.restype = c_int
@@ -387,15 +387,17 @@ class Engine:
 
     def chain_autocorr(self, chain):
         """chain [n_t][W][P] -> walker-averaged normalised autocorrelation function [n_t][P] (emcee's
-        ``function_1d`` per walker and dimension, averaged), computed on the device."""
+        ``function_1d`` per walker and dimension, averaged), computed on the device; or, for E independent
+        ensembles at once, [n_t][E][W][P] -> [n_t][E][P]."""
         chain = _f64(chain)
-        if chain.ndim != 3:
-            raise ValueError("chain must be [n_t][W][P]")
-        n_t, W, P = chain.shape
-        rho = np.empty((n_t, P))
-        self._check(self._lib.mtg_chain_autocorr(self._ctx, n_t, W, P, _ptr(chain), _ptr(rho)))
+        if chain.ndim not in (3, 4):
+            raise ValueError("chain must be [n_t][W][P] or [n_t][E][W][P]")
+        n_t, (W, P) = chain.shape[0], chain.shape[-2:]
+        E = chain.shape[1] if chain.ndim == 4 else 1
+        rho = np.empty((n_t, E, P))
+        self._check(self._lib.mtg_chain_autocorr(self._ctx, n_t, E, W, P, _ptr(chain), _ptr(rho)))
         self.fft_ready = True
-        return rho
+        return rho if chain.ndim == 4 else rho[:, 0]
 
     def ensemble_state(self):
         """dict(coords, log_prob, best_log_prob, best_coords, naccept, iteration, n_not_pd)."""

@@ -270,7 +270,8 @@ class _DeviceBatch:
         return self.dev._log_prob if lc is None else self.dev._log_prob[:, lc]
 
     def get_autocorr_time(self, tol=0):
-        return np.array([integrated_time(self.dev._chain[:, l], tol=tol, quiet=True) for l in range(self.L)])
+        from .device_sampler import _autocorr_time_where_it_is_cheapest
+        return _autocorr_time_where_it_is_cheapest(self.dev._bind(), self.dev._chain, dict(tol=tol, quiet=True))
 
     @property
     def acceptance_fraction(self):

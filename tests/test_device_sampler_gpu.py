@@ -94,6 +94,15 @@ def test_chain_autocorr_on_the_device_matches_the_host(engine):
         if n_t >= 500:
             assert np.allclose(integrated_time(x, tol=0, acf=engine.chain_autocorr), integrated_time(x, tol=0),
                                rtol=1e-9, atol=0)
+    many = rng.standard_normal((300, 7, 10, 3)).cumsum(axis=0)           # seven independent ensembles in one call
+    got = engine.chain_autocorr(many)
+    assert got.shape == (300, 7, 3)
+    for e in range(7):
+        assert np.max(np.abs(got[:, e] - _mean_autocorr_function(many[:, e]))) < 1e-11
+    from mind_the_gaps_amd.device_sampler import _autocorr_time_where_it_is_cheapest
+    engine.fft_ready = True
+    tau = _autocorr_time_where_it_is_cheapest(engine, many, dict(tol=0, quiet=True))
+    assert tau.shape == (7, 3) and np.allclose(tau, [integrated_time(many[:, e], tol=0) for e in range(7)], rtol=1e-9)
     still = rng.standard_normal((64, 4, 2))
     still[:, 1, 0] = 1.25                              # a walker that never moved: NaN in its dimension, as emcee
     got = engine.chain_autocorr(still)
