@@ -156,10 +156,10 @@ def single_lightcurve_configs():
         return k
 
     out = {}
-    cases = (("configs[0] DRW N=1e3 32 walkers", drw, 1000, 32, 2000, 8),
-             ("configs[1] DRW+SHO N=1e4 128 walkers", null_kernel, 10000, 128, 1000, 11),
+    cases = (("configs[0] DRW N=1e3 32 walkers", drw, 1000, 32, 8000, 8),
+             ("configs[1] DRW+SHO N=1e4 128 walkers", null_kernel, 10000, 128, 4000, 11),
              ("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers",
-              lambda: null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other]), 10000, 256, 1000, 14),
+              lambda: null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other]), 10000, 256, 4000, 14),
              ("configs[4] 5 x SHO (J=10) N=2e5 512 walkers", five_sho, 200000, 512, 40, 21))
     for name, make_kernel, n, walkers, steps, P in cases:
         t, y, dy = synth.make_lightcurves(n, 1, seed=20250704 + 2)

@@ -235,6 +235,9 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
  * its dimension, as emcee does.
  */
 MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int P, const double *chain, double *rho);
+/* hipFFT's one-time start-up (~1.4 s: the first plan of a process) paid now; safe to call from a helper thread,
+ * with a device already selected by an mtg_create in this process. */
+MTG_API int mtg_fft_warmup(void);
 
 /*
  * Walker sharding of the resident ensembles across the GPUs of a job (one process per GPU; the

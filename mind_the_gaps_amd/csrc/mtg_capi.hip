@@ -1136,6 +1136,16 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     return MTG_OK;
 }
 
+MTG_API int mtg_fft_warmup(void)
+{
+    // hipFFT needs ~1.4 s the first time a plan is made in a process (rocFFT loads its kernels): callers that will
+    // need mtg_chain_autocorr or mtg_simulate_tk95 later can pay that early, from another thread
+    hipfftHandle plan = 0;
+    if (hipfftPlan1d(&plan, 64, HIPFFT_D2Z, 1) != HIPFFT_SUCCESS) return MTG_E_HIP;
+    (void)hipfftDestroy(plan);
+    return MTG_OK;
+}
+
 MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int P, const double *chain, double *rho)
 {
     if (!ctx) return MTG_E_ARG;
@@ -1150,22 +1160,23 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
     hipStream_t s = ctx->stream;
     mtg_trace::Range range("mtg:chain_autocorr (convergence check)");
     DevBuf &d_chain = ctx->acf_chain, &d_x = ctx->acf_x, &d_f = ctx->acf_f, &d_g = ctx->acf_g, &d_r = ctx->acf_r, &d_ss = ctx->acf_ss;
-    HIP_TRY(ctx, d_chain.reserve((size_t)n_t * S * 8));
-    HIP_TRY(ctx, d_x.reserve((size_t)n2 * S * 8));
+    HIP_TRY(ctx, d_chain.reserve((size_t)n2 * S * 8));        // the chain, then the transposed series [S][n2]
+    HIP_TRY(ctx, d_x.reserve((size_t)n2 * S * 8));            // centred and padded, [n2][S]
     HIP_TRY(ctx, d_f.reserve((size_t)nk * S * 16));
     HIP_TRY(ctx, d_g.reserve((size_t)nk * EP * 16));
-    HIP_TRY(ctx, d_r.reserve((size_t)n2 * EP * 8));
+    HIP_TRY(ctx, d_r.reserve((size_t)(n2 + n_t) * EP * 8));   // inverse transforms [EP][n2], then rho [n_t][EP]
     HIP_TRY(ctx, d_ss.reserve((size_t)S * 8));
     HIP_TRY(ctx, ctx->acf_tmp.reserve((size_t)((n2 / 256 + 2) * S) * 8));
     HIP_TRY(ctx, hipMemcpyAsync(d_chain.p, chain, (size_t)n_t * S * 8, hipMemcpyHostToDevice, s));
     mtg_launch_acf_center(n_t, n2, S, d_chain.as<double>(), d_x.as<double>(), d_ss.as<double>(), ctx->acf_tmp.as<double>(), s);
-    // transforms over the [time][series] layout: element stride = number of series, consecutive series 1 apart
+    mtg_launch_acf_transpose(n2, S, d_x.as<double>(), d_chain.as<double>(), s);
+    // contiguous batched transforms (stock kernels: no run-time compilation inside rocFFT)
     if (!ctx->acf_plans || ctx->acf_n2 != n2 || ctx->acf_S != S || ctx->acf_P != EP) {
         if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); ctx->acf_plans = false; }
-        int len = (int)n2, emb = (int)n2, embk = (int)nk;
-        if (hipfftPlanMany(&ctx->acf_fwd, 1, &len, &emb, (int)S, 1, &embk, (int)S, 1, HIPFFT_D2Z, (int)S) != HIPFFT_SUCCESS)
+        int len = (int)n2;
+        if (hipfftPlanMany(&ctx->acf_fwd, 1, &len, nullptr, 1, (int)n2, nullptr, 1, (int)nk, HIPFFT_D2Z, (int)S) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (forward) failed");
-        if (hipfftPlanMany(&ctx->acf_inv, 1, &len, &embk, (int)EP, 1, &emb, (int)EP, 1, HIPFFT_Z2D, (int)EP) != HIPFFT_SUCCESS) {
+        if (hipfftPlanMany(&ctx->acf_inv, 1, &len, nullptr, 1, (int)nk, nullptr, 1, (int)n2, HIPFFT_Z2D, (int)EP) != HIPFFT_SUCCESS) {
             (void)hipfftDestroy(ctx->acf_fwd);
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (inverse) failed");
         }
@@ -1173,15 +1184,15 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
         if (hipfftSetStream(ctx->acf_fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(ctx->acf_inv, s) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftSetStream failed");
     }
-    struct { hipfftHandle h; } fwd{ctx->acf_fwd}, inv{ctx->acf_inv};
-    if (hipfftExecD2Z(fwd.h, d_x.as<double>(), (hipfftDoubleComplex *)d_f.p) != HIPFFT_SUCCESS)
+    if (hipfftExecD2Z(ctx->acf_fwd, d_chain.as<double>(), (hipfftDoubleComplex *)d_f.p) != HIPFFT_SUCCESS)
         return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftExecD2Z failed");
     mtg_launch_acf_power(nk, E, W, P, d_f.as<double2>(), d_ss.as<double>(), d_g.as<double2>(), s);
-    if (hipfftExecZ2D(inv.h, (hipfftDoubleComplex *)d_g.p, d_r.as<double>()) != HIPFFT_SUCCESS)
+    if (hipfftExecZ2D(ctx->acf_inv, (hipfftDoubleComplex *)d_g.p, d_r.as<double>()) != HIPFFT_SUCCESS)
         return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftExecZ2D failed");
-    mtg_launch_acf_scale(n_t * EP, 1.0 / (double)n2, d_r.as<double>(), s);   // hipFFT does not normalise
+    double *d_rho = d_r.as<double>() + n2 * EP;
+    mtg_launch_acf_out(n_t, n2, EP, 1.0 / (double)n2, d_r.as<double>(), d_rho, s);   // hipFFT does not normalise
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(rho, d_r.p, (size_t)n_t * EP * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(rho, d_rho, (size_t)n_t * EP * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return MTG_OK;
 }

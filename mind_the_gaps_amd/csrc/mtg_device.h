@@ -169,4 +169,5 @@ void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, dou
 void mtg_launch_acf_center(int64_t n_t, int64_t n2, int64_t S, const double *chain, double *x, double *sumsq, double *scratch,
                            hipStream_t s);
 void mtg_launch_acf_power(int64_t nk, int64_t E, int W, int P, const double2 *f, const double *sumsq, double2 *g, hipStream_t s);
-void mtg_launch_acf_scale(int64_t n, double scale, double *r, hipStream_t s);
+void mtg_launch_acf_transpose(int64_t rows, int64_t cols, const double *in, double *out, hipStream_t s);
+void mtg_launch_acf_out(int64_t n_t, int64_t n2, int64_t EP, double scale, const double *r, double *rho, hipStream_t s);

@@ -269,8 +269,10 @@ void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int
 // chain[n_t][S] with S = E * W * P series (ensemble, walker, dimension fastest).  emcee computes, per series, the
 // autocorrelation by zero-padded FFT, normalises it by its lag-0 value and averages over the walkers.  The
 // inverse transform is linear, so the power spectra are normalised (lag 0 of a series = the sum of its squares)
-// and averaged BEFORE it: S forward transforms, P inverse ones.  The transforms read and write the [time][series]
-// layout directly (stride S), so every kernel here is coalesced over the series.
+// and averaged BEFORE it: S forward transforms, E * P inverse ones.  The chain is centred in its own
+// [time][series] layout (coalesced over the series), transposed once to [series][time], and the transforms run
+// over contiguous series: hipFFT's stock kernels.  (Strided plans over the chain's own layout worked too, but
+// every new length cost a run-time compilation of ~1.4 s inside rocFFT.)
 
 // Sums over time in two deterministic steps (a chain can be 10^5 steps of only a few dozen series, so the time
 // axis has to be spread over workgroups): partial[tile][s] = sum over the tile's steps of v or (v - mean)^2, then
@@ -309,28 +311,61 @@ __global__ void __launch_bounds__(256) mtg_acf_fold_kernel(int64_t tiles, int64_
     out[s] = acc * scale;
 }
 
-// g[k][e][p] = mean over the walkers of ensemble e of |f[k][e][w][p]|^2 / sumsq[e][w][p]   (a real spectrum)
+// [rows][cols] -> [cols][rows] through a 32 x 33 LDS tile (both sides coalesced)
+__global__ void __launch_bounds__(256) mtg_acf_transpose_kernel(int64_t rows, int64_t cols, const double *in, double *out)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads, four rows each
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) out[(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+// g[e][p][k] = mean over the walkers of ensemble e of |f[e][w][p][k]|^2 / sumsq[e][w][p]   (a real spectrum);
+// f: one row of nk coefficients per series, the series in (ensemble, walker, dimension) order
 __global__ void __launch_bounds__(256) mtg_acf_power_kernel(int64_t nk, int64_t E, int W, int P, const double2 *f, const double *sumsq,
                                                           double2 *g)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nk * E * P) return;
-    const int64_t k = i / (E * P), ep = i % (E * P), e = ep / P;
+    const int64_t ep = i / nk, k = i % nk, e = ep / P;
     const int p = (int)(ep % P);
     const int64_t first = e * (int64_t)W * P + p;
-    const double2 *row = f + k * E * (int64_t)W * P + first;
     double acc = 0.0;
     for (int w = 0; w < W; ++w) {
-        const double2 v = row[(int64_t)w * P];
-        acc += (v.x * v.x + v.y * v.y) / sumsq[first + (int64_t)w * P];   // 0 / 0 = NaN for a walker that never moved, as emcee has it
+        const int64_t sidx = first + (int64_t)w * P;
+        const double2 v = f[sidx * nk + k];
+        acc += (v.x * v.x + v.y * v.y) / sumsq[sidx];   // 0 / 0 = NaN for a walker that never moved, as emcee has it
     }
     g[i] = make_double2(acc / (double)W, 0.0);
 }
 
-__global__ void __launch_bounds__(256) mtg_acf_scale_kernel(int64_t n, double scale, double *r)
+// rho[t][ep] = scale * r[ep][t]   (t < n_t; r has n2 values per row)
+__global__ void __launch_bounds__(256) mtg_acf_out_kernel(int64_t n_t, int64_t n2, int64_t EP, double scale, const double *r, double *rho)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) r[i] *= scale;
+    if (i >= n_t * EP) return;
+    const int64_t t = i / EP, ep = i % EP;
+    rho[i] = scale * r[ep * n2 + t];
+}
+
+void mtg_launch_acf_transpose(int64_t rows, int64_t cols, const double *in, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(mtg_acf_transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, s, rows,
+                       cols, in, out);
+}
+
+void mtg_launch_acf_power(int64_t nk, int64_t E, int W, int P, const double2 *f, const double *sumsq, double2 *g, hipStream_t s)
+{
+    hipLaunchKernelGGL(mtg_acf_power_kernel, dim3((unsigned)((nk * E * P + 255) / 256)), dim3(256), 0, s, nk, E, W, P, f, sumsq, g);
+}
+
+void mtg_launch_acf_out(int64_t n_t, int64_t n2, int64_t EP, double scale, const double *r, double *rho, hipStream_t s)
+{
+    hipLaunchKernelGGL(mtg_acf_out_kernel, dim3((unsigned)((n_t * EP + 255) / 256)), dim3(256), 0, s, n_t, n2, EP, scale, r, rho);
 }
 
 // x[t][s] (t < n2) = centred, zero-padded chain; sumsq[s]; `scratch`: (n2 / MTG_ACF_TILE + 1) * S + S doubles
@@ -345,14 +380,4 @@ void mtg_launch_acf_center(int64_t n_t, int64_t n2, int64_t S, const double *cha
     hipLaunchKernelGGL(mtg_acf_fold_kernel, cols, block, 0, s, tiles_in, S, 1.0 / (double)n_t, partial, mean);
     hipLaunchKernelGGL((mtg_acf_tile_kernel<true>), dim3(cols.x, (unsigned)tiles), block, 0, s, n_t, n2, S, chain, mean, x, partial);
     hipLaunchKernelGGL(mtg_acf_fold_kernel, cols, block, 0, s, tiles, S, 1.0, partial, sumsq);
-}
-
-void mtg_launch_acf_power(int64_t nk, int64_t E, int W, int P, const double2 *f, const double *sumsq, double2 *g, hipStream_t s)
-{
-    hipLaunchKernelGGL(mtg_acf_power_kernel, dim3((unsigned)((nk * E * P + 255) / 256)), dim3(256), 0, s, nk, E, W, P, f, sumsq, g);
-}
-
-void mtg_launch_acf_scale(int64_t n, double scale, double *r, hipStream_t s)
-{
-    hipLaunchKernelGGL(mtg_acf_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, scale, r);
 }

@@ -15,12 +15,14 @@ from .sampler import integrated_time
 __all__ = ["DeviceEnsembleSampler"]
 
 # The convergence check runs on the whole chain every time it is made.  On the device (Engine.chain_autocorr) it
-# costs ~1 ms where the host's FFTs take 10-200 ms (1000 x 256 x 8: 0.7 against 30 ms; 50 000 x 12 x 5: 1.2 against
-# 54 ms) -- once hipFFT is up (~1.3 s the first time in a process) and a plan for the padded length exists (~13 ms
-# each).  So: rent before buying.  The host does the checks until it has spent as long as the start-up costs (or a
-# single check would), and a new plan is made only where the host would take longer than making it.
+# costs ~1 ms where the host's FFTs take 10-200 ms (1000 x 256 x 8: 0.8 against 35 ms; 50 000 x 12 x 5: 1.1 against
+# 53 ms) -- once hipFFT is up (~0.8 s the first time in a process; the sampler starts that on a helper thread when it
+# starts sampling) and has a plan for the padded length: on this ROCm build rocFFT compiles the kernels of every new
+# length at run time, ~1.2 s each (measured on fresh MI355X boxes; nothing to do with the layout).  So every padded
+# length is rented before it is bought: the host does the checks of a length until it has spent as long on them as
+# the plan would cost (or a single check would) -- at most twice the cost of always choosing right.
 HOST_SECONDS_PER_POINT = 1.1e-8      # measured: 7 ms for 6.4e5 points, 30 ms for 2e6, 220 ms for 2e7
-FFT_STARTUP_SECONDS, FFT_PLAN_SECONDS = 1.3, 0.013
+FFT_PLAN_SECONDS = 1.2
 
 
 def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
@@ -36,22 +38,19 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
                          for e in range(chain.shape[1])])
 
     key = (1 << max(n_t - 1, 1).bit_length(),) + chain.shape[1:]
-    state = engine.__dict__.setdefault("_acf_state", {"ready": False, "key": None, "host_seconds": 0.0})
+    state = engine.__dict__.setdefault("_acf_state", {"planned": None, "rented": {}})
     estimate = HOST_SECONDS_PER_POINT * chain.size
-    if getattr(engine, "fft_ready", False):      # the simulator has started hipFFT already
-        state["ready"] = True
-    if state["ready"]:
-        on_device = key == state["key"] or estimate > FFT_PLAN_SECONDS
-    else:
-        on_device = state["host_seconds"] > FFT_STARTUP_SECONDS or estimate > FFT_STARTUP_SECONDS
-    if on_device and n_t >= 2:
-        state["ready"], state["key"] = True, key
+    rented = state["rented"].get(key, 0.0)
+    on_device = getattr(engine, "fft_ready", False) and n_t >= 2 and (
+        key == state["planned"] or estimate > FFT_PLAN_SECONDS or rented > FFT_PLAN_SECONDS)
+    if on_device:
+        state["planned"] = key
         return taus(engine.chain_autocorr(chain))
     t0 = time.perf_counter()
     try:
         return taus(None)
     finally:
-        state["host_seconds"] += time.perf_counter() - t0
+        state["rented"][key] = rented + time.perf_counter() - t0
 
 
 class DeviceEnsembleSampler:
@@ -85,6 +84,7 @@ class DeviceEnsembleSampler:
 
     def run_mcmc(self, initial_state, nsteps):
         eng = self._bind()
+        eng.start_fft_warmup()   # the convergence checks may want the device (see _autocorr_time_where_it_is_cheapest)
         if initial_state is not None:
             p0 = np.asarray(initial_state, dtype=np.float64)
             if p0.ndim == 2:

@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr",
+    "mtg_chain_autocorr", "mtg_fft_warmup",
 )
 
 # the exchange of a walker-sharded ensemble as a callback (include/mtg.h, mtg_exchange_fn)
@@ -140,6 +140,8 @@ def load_library():
     lib.mtg_ensemble_shard_host.argtypes = [c_vp, c_int, c_int, EXCHANGE_FN, c_vp]
     lib.mtg_ensemble_unshard.restype = c_int
     lib.mtg_ensemble_unshard.argtypes = [c_vp]
+    lib.mtg_fft_warmup.restype = c_int
+    lib.mtg_fft_warmup.argtypes = []
     lib.mtg_chain_autocorr.restype = c_int
     lib.mtg_chain_autocorr.argtypes = [c_vp, c_i64, c_i64, c_int, c_int, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
@@ -385,6 +387,24 @@ class Engine:
         self._check(self._lib.mtg_ensemble_run(self._ctx, int(steps), _ptr(chain), _ptr(lnp)))
         return chain, lnp
 
+    def start_fft_warmup(self):
+        """hipFFT's one-time start-up (~1.4 s) on a helper thread, so that the first convergence check or simulation
+        that wants the device does not wait for it; ``fft_ready`` turns True when it is done."""
+        import threading
+        if getattr(self, "fft_ready", False) or getattr(self, "_fft_thread", None) is not None:
+            return
+
+        def work():
+            if self._lib.mtg_fft_warmup() == 0:
+                self.fft_ready = True
+        self._fft_thread = threading.Thread(target=work, name="mtg-fft-warmup", daemon=True)
+        self._fft_thread.start()
+
+    def _join_fft_warmup(self):
+        thread = getattr(self, "_fft_thread", None)
+        if thread is not None and thread.is_alive():
+            thread.join()
+
     def chain_autocorr(self, chain):
         """chain [n_t][W][P] -> walker-averaged normalised autocorrelation function [n_t][P] (emcee's
         ``function_1d`` per walker and dimension, averaged), computed on the device; or, for E independent
@@ -395,6 +415,7 @@ class Engine:
         n_t, (W, P) = chain.shape[0], chain.shape[-2:]
         E = chain.shape[1] if chain.ndim == 4 else 1
         rho = np.empty((n_t, E, P))
+        self._join_fft_warmup()   # (two threads inside hipFFT's first plan is not something to find out about)
         self._check(self._lib.mtg_chain_autocorr(self._ctx, n_t, E, W, P, _ptr(chain), _ptr(rho)))
         self.fft_ready = True
         return rho if chain.ndim == 4 else rho[:, 0]
@@ -437,6 +458,7 @@ class Engine:
         rates, dy, means = np.empty((S, self.N)), np.empty((S, self.N)), np.empty(S)
         clean = np.empty((S, self.N)) if want_clean else None
         segments = np.empty((S, int(seg_len))) if want_segments else None
+        self._join_fft_warmup()
         self._check(self._lib.mtg_simulate_tk95(
             self._ctx, S, _ptr(theta), _ptr(table), 0 if table is None else table.shape[0],
             int(seed) & 0xFFFFFFFFFFFFFFFF, int(nfft), float(sim_dt), float(mean_rate),

@@ -101,7 +101,11 @@ def test_chain_autocorr_on_the_device_matches_the_host(engine):
         assert np.max(np.abs(got[:, e] - _mean_autocorr_function(many[:, e]))) < 1e-11
     from mind_the_gaps_amd.device_sampler import _autocorr_time_where_it_is_cheapest
     engine.fft_ready = True
-    tau = _autocorr_time_where_it_is_cheapest(engine, many, dict(tol=0, quiet=True))
+    engine.__dict__.pop("_acf_state", None)
+    tau_host = _autocorr_time_where_it_is_cheapest(engine, many, dict(tol=0, quiet=True))        # rented: the host
+    engine._acf_state["rented"][(512, 7, 10, 3)] = 10.0                                          # ... long enough
+    tau = _autocorr_time_where_it_is_cheapest(engine, many, dict(tol=0, quiet=True))             # bought: the device
+    assert engine._acf_state["planned"] == (512, 7, 10, 3) and np.allclose(tau, tau_host, rtol=1e-9)
     assert tau.shape == (7, 3) and np.allclose(tau, [integrated_time(many[:, e], tol=0) for e in range(7)], rtol=1e-9)
     still = rng.standard_normal((64, 4, 2))
     still[:, 1, 0] = 1.25                              # a walker that never moved: NaN in its dimension, as emcee
