@@ -17,12 +17,17 @@ __all__ = ["DeviceEnsembleSampler"]
 # The convergence check runs on the whole chain every time it is made.  On the device (Engine.chain_autocorr) it
 # costs ~1 ms where the host's FFTs take 10-200 ms (1000 x 256 x 8: 0.8 against 35 ms; 50 000 x 12 x 5: 1.1 against
 # 53 ms) -- once hipFFT is up (~0.8 s the first time in a process; the sampler starts that on a helper thread when it
-# starts sampling) and has a plan for the padded length: on this ROCm build rocFFT compiles the kernels of every new
-# length at run time, ~1.2 s each (measured on fresh MI355X boxes; nothing to do with the layout).  So every padded
-# length is rented before it is bought: the host does the checks of a length until it has spent as long on them as
-# the plan would cost (or a single check would) -- at most twice the cost of always choosing right.
+# starts sampling) and has a plan for the padded length: ~15 ms with the kernels in rocFFT's cache, ~1.2 s when
+# rocFFT has to compile them first (it does that at run time for every new length on this ROCm build; the package
+# ships a cache file with the power-of-two lengths, engine._seed_rocfft_cache).  So every padded length is rented
+# before it is bought: the host does the checks of a length until it has spent as long on them as the plan would
+# cost (or a single check would) -- at most twice the cost of always choosing right.
 HOST_SECONDS_PER_POINT = 1.1e-8      # measured: 7 ms for 6.4e5 points, 30 ms for 2e6, 220 ms for 2e7
-FFT_PLAN_SECONDS = 1.2
+
+
+def _plan_seconds():
+    from . import engine as _engine
+    return 0.015 if _engine.rocfft_cache_seeded else 1.2
 
 
 def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
@@ -41,8 +46,9 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
     state = engine.__dict__.setdefault("_acf_state", {"planned": None, "rented": {}})
     estimate = HOST_SECONDS_PER_POINT * chain.size
     rented = state["rented"].get(key, 0.0)
+    plan = _plan_seconds()
     on_device = getattr(engine, "fft_ready", False) and n_t >= 2 and (
-        key == state["planned"] or estimate > FFT_PLAN_SECONDS or rented > FFT_PLAN_SECONDS)
+        key == state["planned"] or estimate > plan or rented > plan)
     if on_device:
         state["planned"] = key
         return taus(engine.chain_autocorr(chain))

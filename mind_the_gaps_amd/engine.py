@@ -80,12 +80,31 @@ def _adopt_pytorch_hip_runtime():
                 return  # a broken wheel is torch's problem; fall back to /opt/rocm
 
 
+ROCFFT_CACHE_SEED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rocfft_cache_gfx950.db")
+rocfft_cache_seeded = False
+
+
+def _seed_rocfft_cache():
+    """rocFFT compiles the kernels of every new transform length at run time (~1.2 s each on this ROCm build) and
+    keeps them in the file ROCFFT_RTC_CACHE_PATH names -- by default under ~/.cache, which a fresh machine or an
+    ephemeral box does not have.  The package ships that file filled with the power-of-two lengths
+    mtg_chain_autocorr uses (scripts/make_rocfft_cache.py); rocFFT is pointed at it unless the user chose a file."""
+    global rocfft_cache_seeded
+    if "ROCFFT_RTC_CACHE_PATH" in os.environ:
+        rocfft_cache_seeded = os.path.abspath(os.environ["ROCFFT_RTC_CACHE_PATH"]) == ROCFFT_CACHE_SEED
+        return
+    if os.path.exists(ROCFFT_CACHE_SEED) and os.access(ROCFFT_CACHE_SEED, os.W_OK):
+        os.environ["ROCFFT_RTC_CACHE_PATH"] = ROCFFT_CACHE_SEED
+        rocfft_cache_seeded = True
+
+
 def load_library():
     """dlopen libmtg_hip.so and declare the prototypes (no GPU needed)."""
     global _lib
     if _lib is not None:
         return _lib
     _adopt_pytorch_hip_runtime()
+    _seed_rocfft_cache()
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
