@@ -182,8 +182,16 @@ def broadcast_start(p0, seed, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return np.asarray(p0, dtype=np.float64), int(seed)
     objs = [np.asarray(p0, dtype=np.float64), int(seed)] if dist.get_rank(group) == 0 else [None, None]
-    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                               device=_object_device(group))
     return objs[0], objs[1]
+
+
+def _object_device(group):
+    """Where broadcast_object_list stages its pickles: RCCL moves device buffers only."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else None
 
 
 def shard_device_ensemble(engine, group=None, transport=None):
@@ -204,7 +212,8 @@ def shard_device_ensemble(engine, group=None, transport=None):
         transport = "rccl" if dist.get_backend(group) == "nccl" else "host"
     if transport == "rccl":
         objs = [engine.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                   device=_object_device(group))
         engine.ensemble_shard_rccl(objs[0], rank, world)
         return transport
     if transport != "host":
