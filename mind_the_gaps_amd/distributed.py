@@ -170,7 +170,8 @@ def lockstep(sampler, p0, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return np.asarray(p0, dtype=np.float64)
     objs = [sampler.random_state, np.asarray(p0, dtype=np.float64)] if dist.get_rank(group) == 0 else [None, None]
-    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                               device=_object_device(group))
     sampler.random_state = objs[0]
     return objs[1]
 
