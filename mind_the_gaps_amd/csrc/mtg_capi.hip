@@ -70,6 +70,8 @@ struct mtg_ctx {
     DevBuf coef, lists, counts, tp_ws, sig;
     int64_t cstride = 0;
     int nsig_ws = 1;  // signature lists the workspace was laid out for
+    int bank = 0;     // which of the two banks of structure lists / counters the next expansion and solve use (the device
+                      // sampler alternates: the proposals of a half-step are expanded while the other bank is cleared)
     // staging for the host-pointer entry points
     DevBuf theta, lc, out, status;
 
@@ -117,6 +119,10 @@ struct mtg_ctx {
 };
 
 namespace {
+
+// the current bank of structure lists ([nsig] signature lists, then [nsig] left-over lists) and counters (64)
+inline int *bank_lists(const mtg_ctx *ctx) { return ctx->lists.as<int>() + (int64_t)ctx->bank * 2 * ctx->nsig_ws * ctx->cstride; }
+inline int *bank_counts(const mtg_ctx *ctx) { return ctx->counts.as<int>() + ctx->bank * 64; }
 
 void shard_release(mtg_ctx *ctx);
 int shard_exchange(mtg_ctx *ctx, int64_t EH, hipStream_t s);
@@ -169,9 +175,9 @@ int reserve_workspace(mtg_ctx *ctx, int64_t B, int nslots, int nsig)
     if (stride < 64) stride = 64;
     HIP_TRY(ctx, ctx->coef.reserve((size_t)stride * nslots * sizeof(double)));
     // [nsig] signature lists, then [nsig] left-over lists of the windowed sweep (sweep_launch)
-    HIP_TRY(ctx, ctx->lists.reserve((size_t)stride * (nsig > 1 ? nsig : 1) * 2 * sizeof(int)));
+    HIP_TRY(ctx, ctx->lists.reserve((size_t)stride * (nsig > 1 ? nsig : 1) * 2 * 2 * sizeof(int)));   // two banks
     ctx->nsig_ws = nsig > 1 ? nsig : 1;
-    HIP_TRY(ctx, ctx->counts.reserve(64 * sizeof(int)));
+    HIP_TRY(ctx, ctx->counts.reserve(2 * 64 * sizeof(int)));
     HIP_TRY(ctx, ctx->sig.reserve((size_t)stride * sizeof(int32_t)));
     ctx->cstride = stride;
     return MTG_OK;
@@ -207,8 +213,8 @@ MtgPrepArgs make_prep_args(mtg_ctx *ctx, int64_t B, const double *d_theta, int a
     pa.coef = ctx->coef.as<double>();
     pa.cstride = ctx->cstride;
     pa.nsig = ctx->model.nsho + 1;
-    pa.lists = ctx->lists.as<int>();
-    pa.counts = ctx->counts.as<int>();
+    pa.lists = bank_lists(ctx);
+    pa.counts = bank_counts(ctx);
     pa.out = d_out;
     pa.status = d_status;
     pa.sig = ctx->sig.as<int32_t>();  // structure of every evaluation: the rank-10 time-parallel path dispatches on it
@@ -230,8 +236,8 @@ int sweep_launch(mtg_ctx *ctx, mtg_solve_launcher fn, MtgSolveArgs sa, int64_t B
         fn(sa, B, s);
         return MTG_OK;
     }
-    int *left_list = ctx->lists.as<int>() + ((int64_t)ctx->nsig_ws + k) * ctx->cstride;
-    int *left_count = ctx->counts.as<int>() + 32 + k;
+    int *left_list = bank_lists(ctx) + ((int64_t)ctx->nsig_ws + k) * ctx->cstride;
+    int *left_count = bank_counts(ctx) + 32 + k;
     HIP_TRY(ctx, hipMemsetAsync(left_count, 0, sizeof(int), s));
     sa.left_list = left_list;
     sa.left_count = left_count;
@@ -260,7 +266,7 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[0], s));
     {
         mtg_trace::Range range("mtg:prepare (theta -> prior, coefficients)");
-        if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
+        if (nsig > 1) HIP_TRY(ctx, hipMemsetAsync(bank_counts(ctx), 0, 64 * sizeof(int), s));
         mtg_launch_prepare(make_prep_args(ctx, B, d_theta, add_prior, d_out, d_status), s);
     }
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
@@ -356,8 +362,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         sa.count_ptr = nullptr;
         mtg_launch_tp_big(sa, B, s);
     } else if (fused) {  // every signature in one launch
-        sa.list = ctx->lists.as<int>();
-        sa.count_ptr = ctx->counts.as<int>();
+        sa.list = bank_lists(ctx);
+        sa.count_ptr = bank_counts(ctx);
         fused(sa, B, s);
     } else {
         // A time-parallel launch is latency bound: a structure holding three evaluations takes as long
@@ -379,8 +385,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             if (!fn) continue;
             mtg_solve_launcher tp = small_ok ? mtg_find_tp_solver(nr, nc) : nullptr;
             if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
-            sa.list = nsig > 1 ? ctx->lists.as<int>() + (int64_t)k * ctx->cstride : nullptr;
-            sa.count_ptr = nsig > 1 ? ctx->counts.as<int>() + k : nullptr;
+            sa.list = nsig > 1 ? bank_lists(ctx) + (int64_t)k * ctx->cstride : nullptr;
+            sa.count_ptr = nsig > 1 ? bank_counts(ctx) + k : nullptr;
             hipStream_t sk = fan_out && k > 0 ? ctx->side[k - 1] : s;
             if (sk != s) HIP_TRY(ctx, hipStreamWaitEvent(sk, ctx->fork, 0));
             if (tp) {
@@ -1068,25 +1074,49 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     if (lnp_chain) HIP_TRY(ctx, ctx->ens_lnp_chain.reserve((size_t)steps * EW * 8));
     rc = check_model_workspace(ctx, EH);
     if (rc) return rc;
-    // the accept kernel leaves the structure counters cleared for the next expansion; clear them once here
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 64 * sizeof(int), s));
-    MtgPrepArgs pa = make_prep_args(ctx, EH, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(),
-                                    ctx->ens_st.as<int32_t>());
+    // Between two solves ONE launch does the accept step of the half-step just evaluated and the proposals (with
+    // their expansion) of the next: mtg_sampler_step_kernel.  The structure lists have two banks: the proposals of
+    // half-step h + 1 are appended to one while workgroup 0 clears the counters of the other, which the solver of
+    // half-step h has just used.
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, 2 * 64 * sizeof(int), s));
+    struct BankGuard {  // everybody else uses bank 0
+        mtg_ctx *c;
+        ~BankGuard() { c->bank = 0; }
+    } bank_guard{ctx};
     const bool sharded = ctx->shard_kind != 0;
-    if (sharded) {
-        pa.row_lo = ctx->shard_lo;
-        pa.row_hi = ctx->shard_hi;
-    }
     struct LiveRows {  // the solver's kernel choice looks at the rows this rank evaluates
         mtg_ctx *c;
         LiveRows(mtg_ctx *ctx_, int64_t n) : c(ctx_) { c->live_rows = n; }
         ~LiveRows() { c->live_rows = 0; }
     } live_rows(ctx, sharded ? (ctx->shard_hi > ctx->shard_lo ? ctx->shard_hi - ctx->shard_lo : 1) : 0);
+    auto prep_args = [&](int bank) {
+        ctx->bank = bank;
+        MtgPrepArgs pa = make_prep_args(ctx, EH, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>());
+        if (sharded) {
+            pa.row_lo = ctx->shard_lo;
+            pa.row_hi = ctx->shard_hi;
+        }
+        return pa;
+    };
+    MtgEnsembleArgs g;
+    g.E = E; g.W = W; g.P = P;
+    g.seed_lo = (uint32_t)ctx->ens_seed; g.seed_hi = (uint32_t)(ctx->ens_seed >> 32);
+    g.a = 2.0;
+    g.perm = ctx->ens_perm.as<int32_t>();
+    g.coords = ctx->ens_coords.as<double>();
+    g.lnp = ctx->ens_lnp.as<double>();
+    g.factor = ctx->ens_factor.as<double>();
+    g.naccept = ctx->ens_naccept.as<int32_t>();
+    g.best_lnp = ctx->ens_best_lnp.as<double>();
+    g.best_coords = ctx->ens_best_coords.as<double>();
+    g.n_notpd = ctx->ens_notpd.as<int32_t>();
+    int bank = 0;
+    if (steps > 0)  // the first proposals of the run
+        mtg_launch_sampler_step(g, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, ctx->ens_iteration, prep_args(bank), s);
     for (int it = 0; it < steps; ++it) {
         const uint32_t iter = ctx->ens_iteration;
         for (int half = 0; half < 2; ++half) {
-            mtg_launch_propose(E, W, P, half, iter, ctx->ens_seed, 2.0, ctx->ens_perm.as<int32_t>(),
-                               ctx->ens_coords.as<double>(), ctx->ens_factor.as<double>(), pa, s);
+            ctx->bank = bank;
             rc = solve_prepared(ctx, EH, ctx->ens_lc_half.as<int32_t>(), ctx->ens_new.as<double>(),
                                 ctx->ens_st.as<int32_t>(), s);
             if (rc) return rc;
@@ -1095,13 +1125,13 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
                 if (rc) return rc;
             }
             const bool last = half == 1;
-            mtg_launch_accept(E, W, P, half, iter, ctx->ens_seed, ctx->ens_perm.as<int32_t>(),
-                              ctx->ens_q.as<double>(), ctx->ens_factor.as<double>(), ctx->ens_new.as<double>(),
-                              ctx->ens_st.as<int32_t>(), ctx->ens_coords.as<double>(), ctx->ens_lnp.as<double>(),
-                              ctx->ens_naccept.as<int32_t>(), ctx->ens_best_lnp.as<double>(),
-                              ctx->ens_best_coords.as<double>(), ctx->ens_notpd.as<int32_t>(), ctx->counts.as<int>(),
-                              last && chain ? ctx->ens_chain.as<double>() + (size_t)it * EW * P : nullptr,
-                              last && lnp_chain ? ctx->ens_lnp_chain.as<double>() + (size_t)it * EW : nullptr, s);
+            const bool more = !(last && it + 1 == steps);   // another half-step follows in this call
+            int *used_counts = bank_counts(ctx);
+            mtg_launch_sampler_step(g, 1, half, iter, ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>(), used_counts,
+                                    last && chain ? ctx->ens_chain.as<double>() + (size_t)it * EW * P : nullptr,
+                                    last && lnp_chain ? ctx->ens_lnp_chain.as<double>() + (size_t)it * EW : nullptr,
+                                    more ? 1 : 0, last ? 0 : 1, last ? iter + 1 : iter, prep_args(bank ^ 1), s);
+            bank ^= 1;
         }
         ctx->ens_iteration += 1;
     }

@@ -140,12 +140,24 @@ void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, 
                          const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,
                          double *dxmax, hipStream_t);
 // device-resident ensemble sampler (mtg_sampler.hip)
-void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a, int32_t *perm,
-                        const double *coords, double *factor, const MtgPrepArgs &pa, hipStream_t);
-void mtg_launch_accept(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, const int32_t *perm,
-                       const double *q, const double *factor, const double *new_lnp, const int32_t *status,
-                       double *coords, double *lnp, int32_t *naccept, double *best_lnp, double *best_coords,
-                       int32_t *n_notpd, int *counts, double *chain_row, double *lnp_chain_row, hipStream_t);
+struct MtgEnsembleArgs {
+    int E, W, P;
+    uint32_t seed_lo, seed_hi;
+    double a;             // stretch scale
+    int32_t *perm;        // [E][W] red/blue split of the current iteration
+    double *coords;       // [E][W][P]
+    double *lnp;          // [E][W]
+    double *factor;       // [E][W/2] (P - 1) ln z of the current proposals
+    int32_t *naccept;     // [E][W]
+    double *best_lnp;     // [E]
+    double *best_coords;  // [E][P]
+    int32_t *n_notpd;
+};
+// One launch between two solves: accept of half-step (iteration, half) -- proposals in pa.theta, results in
+// new_lnp / status -- then the proposals of (next_iteration, next_half) expanded through pa (either part optional).
+void mtg_launch_sampler_step(const MtgEnsembleArgs &g, int do_accept, int half, uint32_t iteration, const double *new_lnp,
+                             const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
+                             int next_half, uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t);
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
                              double *best_coords, hipStream_t);
 // TK95 light-curve simulation (mtg_simulate.hip)

@@ -61,19 +61,17 @@ enum { PURPOSE_SPLIT = 1, PURPOSE_PROPOSE = 2, PURPOSE_ACCEPT = 3 };
 //     walker index); perm[e][0..W/2) is the first half.  Keys in LDS, W broadcast reads per walker.
 //   proposal: z = ((a - 1) u + 1)^2 / a,  q = c_partner - (c_partner - s) z,  factor = (P - 1) ln z.
 //   expansion: mtg_prepare_one on the proposal (prior verdict, coefficient columns, structure lists).
-__global__ void __launch_bounds__(1024)
-mtg_propose_kernel(int W, int P, int half, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi, double a,
-                   int32_t *__restrict__ perm, const double *__restrict__ coords, double *__restrict__ factor,
-                   MtgPrepArgs pa)
+// s_key: W 64-bit keys, then W ranks (int), in LDS.
+__device__ __forceinline__ void mtg_propose_part(const MtgEnsembleArgs &g, int half, uint32_t iteration, const MtgPrepArgs &pa,
+                                                 uint64_t *s_key)
 {
-    extern __shared__ uint64_t s_key[];   // W keys, then W ranks (int)
-    const int H = W / 2;
+    const int W = g.W, P = g.P, H = W / 2;
     const int e = blockIdx.x;
-    int32_t *p = perm + (int64_t)e * W;
+    int32_t *p = g.perm + (int64_t)e * W;
     if (half == 0) {
         int *s_rank = (int *)(s_key + W);
         for (int w = threadIdx.x; w < W; w += blockDim.x) {
-            const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, seed_lo, seed_hi);
+            const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, g.seed_lo, g.seed_hi);
             s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
             s_rank[w] = 0;
         }
@@ -105,78 +103,92 @@ mtg_propose_kernel(int W, int P, int half, uint32_t iteration, uint32_t seed_lo,
         const bool live = k < H;
         const int64_t i = (int64_t)e * H + (live ? k : 0);
         if (live) {
-            const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16 * half, (uint32_t)e, (uint32_t)k, seed_lo, seed_hi);
+            const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16 * half, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
             const double u = u01(r.c[0], r.c[1]);
-            const double zr = (a - 1.0) * u + 1.0;
-            const double z = zr * zr / a;
+            const double zr = (g.a - 1.0) * u + 1.0;
+            const double z = zr * zr / g.a;
             const int w = p[half * H + k];
             const int partner = p[(1 - half) * H + (int)(u01(r.c[2], r.c[3]) * (double)H)];
-            const double *s = coords + ((int64_t)e * W + w) * P;
-            const double *c = coords + ((int64_t)e * W + partner) * P;
+            const double *s = g.coords + ((int64_t)e * W + w) * P;
+            const double *c = g.coords + ((int64_t)e * W + partner) * P;
             double *qo = q + i * P;
             for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
-            factor[i] = (double)(P - 1) * log(z);
+            g.factor[i] = (double)(P - 1) * log(z);
         }
         mtg_prepare_one(pa, i, live);
     }
 }
 
-// Accept / reject, state update, per-ensemble running best; then the housekeeping of the
-// half-step: clear the structure lists' counters for the next expansion and, after the second
-// half, append the ensemble's state to the chain.  One workgroup per ensemble.
-__global__ void __launch_bounds__(256)
-mtg_accept_kernel(int E, int W, int P, int half, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi,
-                  const int32_t *__restrict__ perm, const double *__restrict__ q,
-                  const double *__restrict__ factor, const double *__restrict__ new_lnp,
-                  const int32_t *__restrict__ status, double *__restrict__ coords, double *__restrict__ lnp,
-                  int32_t *__restrict__ naccept, double *__restrict__ best_lnp,
-                  double *__restrict__ best_coords, int32_t *__restrict__ n_notpd, int *__restrict__ counts,
-                  double *__restrict__ chain_row, double *__restrict__ lnp_chain_row)
+// Accept / reject of the half-step whose proposals are q[], with log-probabilities new_lnp[] / status[]: state
+// update, per-ensemble running best; clears `clear_counts` (structure counters the solver of this half-step is done
+// with) and, after the second half, appends the ensemble's state to the chain.  One workgroup per ensemble; its first
+// 256 threads do the work, every thread takes part in the barriers.
+__device__ __forceinline__ void mtg_accept_part(const MtgEnsembleArgs &g, int half, uint32_t iteration, const double *q,
+                                                const double *new_lnp, const int32_t *status, int *clear_counts,
+                                                double *chain_row, double *lnp_chain_row, double *s_best, int *s_idx)
 {
-    const int H = W / 2;
+    const int W = g.W, P = g.P, H = W / 2;
     const int e = blockIdx.x;
-    __shared__ double s_best[256];
-    __shared__ int s_idx[256];
-    if (e == 0 && threadIdx.x < 64) counts[threadIdx.x] = 0;  // the solver of this half-step is done with them
+    const bool worker = threadIdx.x < 256;
+    if (e == 0 && threadIdx.x < 64 && clear_counts) clear_counts[threadIdx.x] = 0;
     double my_best = -INFINITY;
     int my_idx = -1;
-    for (int k = threadIdx.x; k < H; k += blockDim.x) {
-        const int64_t i = (int64_t)e * H + k;
-        const int w = perm[(int64_t)e * W + half * H + k];
-        const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e, (uint32_t)k, seed_lo, seed_hi);
-        const double lu = log(u01(r.c[0], r.c[1]));
-        const double cand = new_lnp[i];
-        if (status[i] == MTG_ST_NOTPD) atomicAdd(n_notpd, 1);
-        const int64_t wi = (int64_t)e * W + w;
-        const double diff = factor[i] + cand - lnp[wi];
-        if (diff > lu) {  // false for NaN and for cand = -inf
-            for (int d = 0; d < P; ++d) coords[wi * P + d] = q[i * P + d];
-            lnp[wi] = cand;
-            naccept[wi] += 1;
-            if (cand > my_best) { my_best = cand; my_idx = (int)i; }
+    if (worker)
+        for (int k = threadIdx.x; k < H; k += 256) {
+            const int64_t i = (int64_t)e * H + k;
+            const int w = g.perm[(int64_t)e * W + half * H + k];
+            const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+            const double lu = log(u01(r.c[0], r.c[1]));
+            const double cand = new_lnp[i];
+            if (status[i] == MTG_ST_NOTPD) atomicAdd(g.n_notpd, 1);
+            const int64_t wi = (int64_t)e * W + w;
+            const double diff = g.factor[i] + cand - g.lnp[wi];
+            if (diff > lu) {  // false for NaN and for cand = -inf
+                for (int d = 0; d < P; ++d) g.coords[wi * P + d] = q[i * P + d];
+                g.lnp[wi] = cand;
+                g.naccept[wi] += 1;
+                if (cand > my_best) { my_best = cand; my_idx = (int)i; }
+            }
         }
-    }
-    s_best[threadIdx.x] = my_best;
-    s_idx[threadIdx.x] = my_idx;
+    if (worker) { s_best[threadIdx.x] = my_best; s_idx[threadIdx.x] = my_idx; }
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s && s_best[threadIdx.x + s] > s_best[threadIdx.x]) {
             s_best[threadIdx.x] = s_best[threadIdx.x + s];
             s_idx[threadIdx.x] = s_idx[threadIdx.x + s];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && s_idx[0] >= 0 && s_best[0] > best_lnp[e]) {
-        best_lnp[e] = s_best[0];
-        for (int d = 0; d < P; ++d) best_coords[(int64_t)e * P + d] = q[(int64_t)s_idx[0] * P + d];
+    if (threadIdx.x == 0 && s_idx[0] >= 0 && s_best[0] > g.best_lnp[e]) {
+        g.best_lnp[e] = s_best[0];
+        for (int d = 0; d < P; ++d) g.best_coords[(int64_t)e * P + d] = q[(int64_t)s_idx[0] * P + d];
     }
     // emcee stores the ensemble after both halves moved (every update of this ensemble's walkers
     // was made by this workgroup, before the barriers above)
-    if (chain_row)
-        for (int j = threadIdx.x; j < W * P; j += blockDim.x)
-            chain_row[(int64_t)e * W * P + j] = coords[(int64_t)e * W * P + j];
-    if (lnp_chain_row)
-        for (int w = threadIdx.x; w < W; w += blockDim.x) lnp_chain_row[(int64_t)e * W + w] = lnp[(int64_t)e * W + w];
+    if (chain_row && worker)
+        for (int j = threadIdx.x; j < W * P; j += 256)
+            chain_row[(int64_t)e * W * P + j] = g.coords[(int64_t)e * W * P + j];
+    if (lnp_chain_row && worker)
+        for (int w = threadIdx.x; w < W; w += 256) lnp_chain_row[(int64_t)e * W + w] = g.lnp[(int64_t)e * W + w];
+}
+
+// One kernel between two solves: the accept step of the half-step just evaluated, then -- do_propose -- the
+// proposals of the next one (expanded into the OTHER bank of structure lists: workgroup 0 clears the bank the
+// solver has just used while the others may already be appending to the next one).  do_accept = 0: the very first
+// proposals of a run.
+__global__ void __launch_bounds__(1024)
+mtg_sampler_step_kernel(MtgEnsembleArgs g, int do_accept, int half, uint32_t iteration, const double *new_lnp,
+                        const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
+                        int next_half, uint32_t next_iteration, MtgPrepArgs pa)
+{
+    extern __shared__ uint64_t s_key[];
+    __shared__ double s_best[256];
+    __shared__ int s_idx[256];
+    if (do_accept) {
+        mtg_accept_part(g, half, iteration, pa.theta, new_lnp, status, clear_counts, chain_row, lnp_chain_row, s_best, s_idx);
+        __syncthreads();  // this workgroup's updates of the ensemble are visible to all its threads
+    }
+    if (do_propose) mtg_propose_part(g, next_half, next_iteration, pa, s_key);
 }
 
 // Running best of the INITIAL state (before any move).
@@ -196,25 +208,18 @@ mtg_initial_best_kernel(int E, int W, int P, const double *__restrict__ coords, 
     for (int d = 0; d < P; ++d) best_coords[(int64_t)e * P + d] = coords[((int64_t)e * W + bi) * P + d];
 }
 
-void mtg_launch_propose(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, double a, int32_t *perm,
-                        const double *coords, double *factor, const MtgPrepArgs &pa, hipStream_t s)
+void mtg_launch_sampler_step(const MtgEnsembleArgs &g, int do_accept, int half, uint32_t iteration, const double *new_lnp,
+                             const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
+                             int next_half, uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t s)
 {
-    // the proposals need W / 2 threads; the split of the first half-step ranks W keys against each other and
-    // takes as many threads as a workgroup of a few ensembles can have (many ensembles: the GPU is full anyway)
-    int threads = W / 2 >= 256 ? 256 : (W / 2 + 63) / 64 * 64;
-    if (half == 0 && E <= 64) threads = 1024;
-    hipLaunchKernelGGL(mtg_propose_kernel, dim3(E), dim3(threads), (size_t)W * (sizeof(uint64_t) + sizeof(int)), s, W, P, half, iteration,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), a, perm, coords, factor, pa);
-}
-
-void mtg_launch_accept(int E, int W, int P, int half, uint32_t iteration, uint64_t seed, const int32_t *perm,
-                       const double *q, const double *factor, const double *new_lnp, const int32_t *status,
-                       double *coords, double *lnp, int32_t *naccept, double *best_lnp, double *best_coords,
-                       int32_t *n_notpd, int *counts, double *chain_row, double *lnp_chain_row, hipStream_t s)
-{
-    hipLaunchKernelGGL(mtg_accept_kernel, dim3(E), dim3(256), 0, s, E, W, P, half, iteration, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), perm, q, factor, new_lnp, status, coords, lnp, naccept, best_lnp,
-                       best_coords, n_notpd, counts, chain_row, lnp_chain_row);
+    // the proposals need W / 2 threads, the accept step up to 256; the split of a first half-step ranks W keys against
+    // each other and takes as many threads as a workgroup of a few ensembles can have (many ensembles: the GPU is
+    // full anyway)
+    int threads = 256;
+    if (do_propose && next_half == 0 && g.E <= 64) threads = 1024;
+    hipLaunchKernelGGL(mtg_sampler_step_kernel, dim3((unsigned)g.E), dim3(threads), (size_t)g.W * (sizeof(uint64_t) + sizeof(int)), s,
+                       g, do_accept, half, iteration, new_lnp, status, clear_counts, chain_row, lnp_chain_row, do_propose, next_half,
+                       next_iteration, pa);
 }
 
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
