@@ -4,12 +4,13 @@
 // 3.1.4 semantics restated in SURVEY.md Appendix B), for E independent ensembles of
 // W walkers at once, with the walkers, their log-probabilities, the random
 // numbers and the accept/reject step all resident on the GPU: one iteration is
-//     2 x { mtg_propose_kernel -> solve (the likelihood) -> mtg_accept_kernel }
-// enqueued on one stream with no host synchronisation in between.  The proposal kernel also
-// draws the red/blue split (first half-step) and expands the proposals into celerite
-// coefficients (mtg_prepare_one); the accept kernel also appends the state to the chain and
-// clears the structure lists for the next half-step: three launches per half-step where the
-// straightforward split | propose | memset | prepare | solve | accept | copy sequence needs six.
+//     2 x { solve (the likelihood) -> mtg_sampler_step_kernel }
+// enqueued on one stream with no host synchronisation in between.  The step kernel takes the accept step of
+// the half-step just evaluated (state update, running best, chain row after the second half, clearing the
+// structure lists the solver used) and then makes the proposals of the next half-step: the red/blue split
+// (first half-step of an iteration), the stretch move, and their expansion into celerite coefficients
+// (mtg_prepare_one) -- two launches per half-step where the straightforward
+// split | propose | memset | prepare | solve | accept | copy sequence needs six.
 //
 // Random numbers: Philox4x32-10 (Salmon et al. 2011), counter-based, so every draw is a
 // pure function of (seed, iteration, purpose, ensemble, walker) -- reproducible and
