@@ -111,3 +111,36 @@ def test_time_parallel_five_sho(engine, N):
     assert ok.sum() >= B // 2
     assert np.max(np.abs(out[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
     assert np.max(np.abs(out[ok] - thr[ok]) / np.abs(thr[ok])) <= 1e-9
+
+
+@pytest.mark.parametrize("name", ["drw", "drw+sho", "drw+sho+lor", "3sho"])
+@pytest.mark.parametrize("N,B", [(300, 5), (5000, 40), (5000, 300)])
+def test_scanned_likelihood_against_the_filter_pass(engine, name, N, B):
+    """The likelihood carried by the scan (mtg_set_tp_direct 1, the default) against the filter pass over every
+    chunk (0) -- the path an evaluation takes when the scanned number is suspect: one wave (scan) and four waves
+    (tree, then re-composition and scan), every rank up to 6, mixed SHO signatures; both against the oracle."""
+    kinds = MODELS[name]
+    t, y, dy = synth.make_lightcurves(N, 1, seed=77 + N)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    y_mean = y.mean(axis=1)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds)
+    theta = synth.draw_thetas(kinds, B, seed=5)
+    for col in OVERDAMP.get(name, []):
+        theta[::2, col] = np.log(0.3)
+    try:
+        engine.set_time_parallel(1)
+        engine.set_tp_direct(1)
+        scanned, st_s = engine.loglike(theta, add_prior=False)
+        engine.set_tp_direct(0)
+        filtered, st_f = engine.loglike(theta, add_prior=False)
+    finally:
+        engine.set_tp_direct(1)
+        engine.set_time_parallel(2)
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, np.full((B, 1), y_mean[0])]), bounds=bounds,
+                                      add_prior=False, nthreads=4)
+    assert np.array_equal(st_s, rst) and np.array_equal(st_f, rst)
+    ok = rst == 0
+    assert ok.sum() > B // 2
+    assert np.max(np.abs(scanned[ok] - filtered[ok]) / np.abs(filtered[ok])) <= 1e-11
+    assert np.max(np.abs(scanned[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
