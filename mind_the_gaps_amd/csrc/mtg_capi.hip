@@ -315,14 +315,17 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
     // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip); the rank-10
     // structures get as many chunks per evaluation as fill the GPU (mtg_tp_big.h).
-    // Measured crossovers: J <= 6 (elements in registers) pays up to ~1000 evaluations; the J = 10
+    // Measured crossovers: J <= 6 (one workgroup per evaluation) pays up to several thousand evaluations -- the serial
+    // sweep runs one wave per 64 evaluations, latency bound, on a fraction of the SIMDs until ~10^5 of them; the J = 10
     // path costs ~3 x the serial sweep's work per sample, spread over every SIMD instead of B / 64 of
     // them, against ~1.05 us x N for the serial sweep whatever B <= 65 536 is.
     const int Jmodel = m.nr0 + 2 * m.nc0;
     // rows that do work: a walker-sharded half-step skips the rows of the other ranks (MTG_ST_REMOTE)
     const int64_t Bw = ctx->live_rows > 0 ? ctx->live_rows : B;
     bool pays;
-    if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= 1024;
+    // (scripts/crossover_probe.py, serial sweep / time-parallel in ms: N = 1e4, J = 5: 3.4 / 0.35 at 1024 evaluations,
+    // 3.4 / 1.0 at 4096, 3.4 / 1.8 at 8192, equal at 16 384; N = 1e3, J = 5: 0.36 / 0.29 at 4096, 0.36 / 0.51 at 8192)
+    if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= (ctx->N >= 4096 ? 8192 : 4096);
     else pays = ctx->N >= 1024 && Bw <= 8192;
     const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
