@@ -50,8 +50,13 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
     on_device = getattr(engine, "fft_ready", False) and n_t >= 2 and (
         key == state["planned"] or estimate > plan or rented > plan)
     if on_device:
-        state["planned"] = key
-        return taus(engine.chain_autocorr(chain))
+        try:
+            rho = engine.chain_autocorr(chain)
+        except Exception:        # (too large for the device's workspace, hipFFT refusing a plan ...): the host can always
+            rho = None
+        else:
+            state["planned"] = key
+            return taus(rho)
     t0 = time.perf_counter()
     try:
         return taus(None)
