@@ -981,9 +981,12 @@ int shard_exchange(mtg_ctx *ctx, int64_t EH, hipStream_t s)
         // in place: this rank's block already sits at rank * chunk of the receive buffer
         const int64_t at = (int64_t)ctx->shard_rank * chunk;
         RCCL_TRY(ctx, g_rccl.GroupStart());
-        RCCL_TRY(ctx, g_rccl.AllGather(lnp + at, lnp, (size_t)chunk, RCCL_FLOAT64, ctx->shard_comm, s));
-        RCCL_TRY(ctx, g_rccl.AllGather(st + at, st, (size_t)chunk, RCCL_INT32, ctx->shard_comm, s));
-        RCCL_TRY(ctx, g_rccl.GroupEnd());
+        int r1 = g_rccl.AllGather(lnp + at, lnp, (size_t)chunk, RCCL_FLOAT64, ctx->shard_comm, s);
+        int r2 = r1 ? r1 : g_rccl.AllGather(st + at, st, (size_t)chunk, RCCL_INT32, ctx->shard_comm, s);
+        const int r3 = g_rccl.GroupEnd();   // (always closed, whatever the calls inside it said)
+        if (r2 || r3)
+            return fail(ctx, MTG_E_HIP, "ncclAllGather of the half-step's log-probabilities failed: %s",
+                        g_rccl.GetErrorString(r2 ? r2 : r3));
         return MTG_OK;
     }
     // host callback: stage this rank's rows, let the caller fill in the others, upload everything
