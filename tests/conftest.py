@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "timeout(seconds): fail a multi-process test that waits forever")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The multi-process GPU tests (several processes sharing the box's card, each paging PyTorch in) go last: a slow
+    or stuck rendezvous there must not stand between the single-process parity tests and their verdict."""
+    late = [it for it in items if it.get_closest_marker("gpu") and it.module.__name__.endswith("test_distributed")]
+    if late:
+        items[:] = [it for it in items if it not in late] + late
+
+
 @pytest.fixture(scope="session")
 def engine():
     """One MI355X context shared by the GPU parity tests (fails loudly without a GPU)."""
