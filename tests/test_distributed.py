@@ -239,13 +239,26 @@ def _watchdog(out_dir, tag, seconds=360):
 
 
 def _spawn(fn, args, nprocs, out_dir):
+    """mp.spawn with one retry when a worker was stopped by its watchdog (a rendezvous that never completed on a box
+    still paging its libraries in); any other failure, or a second one, fails the test with the workers' stacks."""
     import glob
     import torch.multiprocessing as mp
-    try:
-        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
-    except Exception as exc:
-        dumps = "".join("\n--- %s ---\n%s" % (f, open(f).read()) for f in sorted(glob.glob(os.path.join(str(out_dir), "hang_*.txt"))))
-        raise AssertionError("worker failed: %s%s" % (exc, dumps))
+
+    def dumps():
+        files = sorted(glob.glob(os.path.join(str(out_dir), "hang_*.txt")))
+        return "".join("\n--- %s ---\n%s" % (f, open(f).read()) for f in files if os.path.getsize(f))
+
+    for attempt in (0, 1):
+        try:
+            mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+            return
+        except Exception as exc:
+            stacks = dumps()
+            if attempt == 1 or not stacks:
+                raise AssertionError("worker failed: %s%s" % (exc, stacks))
+            for f in glob.glob(os.path.join(str(out_dir), "hang_*.txt")):
+                os.remove(f)
+            args = (args[0], _free_port()) + tuple(args[2:])    # (world, port, ...): a fresh rendezvous
 
 
 def _gpu_chain_worker(rank, world, port, out_dir):
