@@ -228,7 +228,7 @@ def test_failure_on_one_rank_reaches_every_rank(tmp_path):
     assert open(tmp_path / "fail0.txt").read() == "peer error" and open(tmp_path / "fail1.txt").read() == "own error"
 
 
-def _watchdog(out_dir, tag, seconds=360):
+def _watchdog(out_dir, tag, seconds=150):
     """A worker that is still running after `seconds` writes every thread's stack to out_dir and exits: a
     deadlock between the ranks then fails the test with the place where each rank waited instead of hanging
     the suite."""
