@@ -222,6 +222,11 @@ MTG_API int mtg_profile_read(mtg_ctx *ctx, int capacity, double *prepare_ms, dou
 MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, const double *coords,
                               const int32_t *lc_of_ensemble);
 MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp_chain);
+/* Resume: after mtg_ensemble_init with the coordinates and the seed of a saved state (mtg_ensemble_get), put the
+ * iteration counter -- every random number is a function of (seed, iteration, ...) -- and, optionally, the
+ * acceptance counts and the running best back; mtg_ensemble_run then continues the chain bit for bit. */
+MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const int32_t *naccept, const double *best_lnp,
+                                 const double *best_coords);
 MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *best_lnp, double *best_coords,
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
 

@@ -1150,6 +1150,25 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     return MTG_OK;
 }
 
+MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const int32_t *naccept, const double *best_lnp,
+                                 const double *best_coords)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (ctx->ens_E <= 0) return fail(ctx, MTG_E_STATE, "mtg_ensemble_init has not been called");
+    if (iteration < 0 || iteration > 0xffffffffll) return fail(ctx, MTG_E_ARG, "mtg_ensemble_restore: iteration out of range");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const int64_t E = ctx->ens_E, EW = E * ctx->ens_W;
+    hipStream_t s = ctx->stream;
+    if (naccept) HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_naccept.p, naccept, (size_t)EW * 4, hipMemcpyHostToDevice, s));
+    if (best_lnp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_best_lnp.p, best_lnp, (size_t)E * 8, hipMemcpyHostToDevice, s));
+    if (best_coords)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_best_coords.p, best_coords, (size_t)E * ctx->ens_P * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->ens_iteration = (uint32_t)iteration;
+    return MTG_OK;
+}
+
 MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *best_lnp, double *best_coords,
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd)
 {

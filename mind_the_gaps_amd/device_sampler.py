@@ -124,6 +124,33 @@ class DeviceEnsembleSampler:
         self._state = eng.ensemble_state()
         return self._state
 
+    # -- checkpoint / resume (the reference keeps its chains in memory only) -----------------
+    def save(self, path):
+        """Everything needed to continue this run in another process: state, Philox seed, iteration, chain."""
+        np.savez(path, seed=np.uint64(self.seed), iteration=self.iteration, chain=self._chain, log_prob=self._log_prob,
+                 shape=np.array([self.E, self.nwalkers, self.ndim]), **{"state_" + k: v for k, v in self._state.items()})
+
+    def load(self, path):
+        """Continue the run ``save`` wrote: the next ``run_mcmc(None, n)`` produces the iterations the original run
+        would have produced (random numbers are functions of (seed, iteration, walker); the log-probabilities of the
+        saved coordinates are evaluated again by the same kernels)."""
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        if tuple(z["shape"]) != (self.E, self.nwalkers, self.ndim):
+            raise ValueError("the checkpoint holds %s ensembles x walkers x parameters, this sampler %s"
+                             % (tuple(z["shape"]), (self.E, self.nwalkers, self.ndim)))
+        eng = self._bind()
+        self.seed = int(z["seed"])
+        eng.ensemble_init(z["state_coords"], seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
+        eng.ensemble_restore(int(z["iteration"]), z["state_naccept"], z["state_best_log_prob"], z["state_best_coords"])
+        if self.shard_group is not False:
+            from .distributed import shard_device_ensemble
+            self.transport = shard_device_ensemble(eng, self.shard_group, self.shard_transport)
+        self.iteration = int(z["iteration"])
+        self._chain, self._log_prob = z["chain"], z["log_prob"]
+        self._state = eng.ensemble_state()
+        self._started = True
+        return self._state
+
     # -- emcee-style views (ensemble 0 unless ``ensemble`` is given) --------------------
     def _get(self, arr, flat, thin, discard, ensemble):
         v = arr[discard + thin - 1::thin, ensemble]

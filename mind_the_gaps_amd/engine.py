@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_ensemble_restore",
 )
 
 # the exchange of a walker-sharded ensemble as a callback (include/mtg.h, mtg_exchange_fn)
@@ -163,6 +163,8 @@ def load_library():
     lib.mtg_fft_warmup.argtypes = []
     lib.mtg_chain_autocorr.restype = c_int
     lib.mtg_chain_autocorr.argtypes = [c_vp, c_i64, c_i64, c_int, c_int, _dp, _dp]
+    lib.mtg_ensemble_restore.restype = c_int
+    lib.mtg_ensemble_restore.argtypes = [c_vp, c_i64, _ip, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_simulate_tk95.restype = c_int
@@ -438,6 +440,13 @@ class Engine:
         self._check(self._lib.mtg_chain_autocorr(self._ctx, n_t, E, W, P, _ptr(chain), _ptr(rho)))
         self.fft_ready = True
         return rho if chain.ndim == 4 else rho[:, 0]
+
+    def ensemble_restore(self, iteration, naccept=None, best_log_prob=None, best_coords=None):
+        """After ``ensemble_init`` with a saved state's coordinates and seed: continue from ``iteration``."""
+        na = None if naccept is None else np.ascontiguousarray(naccept, dtype=np.int32)
+        bl = None if best_log_prob is None else _f64(best_log_prob)
+        bc = None if best_coords is None else _f64(best_coords)
+        self._check(self._lib.mtg_ensemble_restore(self._ctx, int(iteration), _iptr(na), _ptr(bl), _ptr(bc)))
 
     def ensemble_state(self):
         """dict(coords, log_prob, best_log_prob, best_coords, naccept, iteration, n_not_pd)."""

@@ -111,3 +111,31 @@ def test_chain_autocorr_on_the_device_matches_the_host(engine):
     still[:, 1, 0] = 1.25                              # a walker that never moved: NaN in its dimension, as emcee
     got = engine.chain_autocorr(still)
     assert np.all(np.isnan(got[:, 0])) and np.all(np.isfinite(got[:, 1]))
+
+
+def test_checkpoint_and_resume_continue_the_chain_bit_for_bit(engine, tmp_path):
+    """DeviceEnsembleSampler.save / load: 12 iterations in one go against 5, a checkpoint, a NEW sampler that loads it,
+    and 7 more -- chain, log-probabilities, acceptance counts and running best identical."""
+    from mind_the_gaps_amd.device_sampler import DeviceEnsembleSampler
+    kinds = synth.NULL_MODEL
+    t, y, dy = synth.make_lightcurves(400, 1, seed=9)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+
+    def bind():
+        engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+        engine.set_model(kinds, full, free, bounds)
+        return engine
+    P, W = len(free), 16
+    p0 = synth.draw_thetas(kinds, W, seed=2, percent=0.02)[None]
+    whole = DeviceEnsembleSampler(bind, W, P, seed=1234)
+    whole.run_mcmc(p0, 12)
+    first = DeviceEnsembleSampler(bind, W, P, seed=1234)
+    first.run_mcmc(p0, 5)
+    first.save(tmp_path / "ckpt")
+    second = DeviceEnsembleSampler(bind, W, P, seed=999)        # (its own seed is replaced by the checkpoint's)
+    second.load(tmp_path / "ckpt")
+    state = second.run_mcmc(None, 7)
+    assert second.iteration == 12 and np.array_equal(second.get_chain(), whole.get_chain())
+    assert np.array_equal(second.get_log_prob(), whole.get_log_prob())
+    for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
+        assert np.array_equal(state[key], whole.state[key]), key
