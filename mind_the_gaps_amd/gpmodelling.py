@@ -14,6 +14,7 @@ engine.Engine -> libmtg_hip.so).  What changes underneath:
   launch; ``cores`` (a multiprocessing.Pool size in the reference,
   gpmodelling.py:245) is accepted and ignored.
 """
+import time
 import warnings
 from typing import List, Tuple
 
@@ -206,6 +207,7 @@ class GPModelling:
         old_tau = np.inf
         self.converged = False
         tau = None
+        started = time.perf_counter()
         if device_sampler:
             sampler = self._device_sampler(walkers, shard_group=group if shard_walkers else False)
             first, done = initial_chain_params, 0
@@ -265,6 +267,8 @@ class GPModelling:
         self._loglikelihoods = sampler.get_log_prob(discard=discard, thin=thin, flat=True)
         self._mcmc_samples = sampler.get_chain(discard=discard, thin=thin, flat=True)
         self._sampler = sampler
+        # metrics: log-probability evaluations per second of this run, convergence checks included
+        self.evals_per_second = sampler.iteration * walkers / max(time.perf_counter() - started, 1e-12)
 
     def _device_sampler(self, walkers, shard_group=False):
         """One device-resident ensemble on this light curve (see device_sampler.py)."""
