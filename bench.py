@@ -216,13 +216,17 @@ def main():
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    # MTG_BENCH_FORCE_DIST=1 (rehearsal on a one-GPU box): a process group of ONE rank over RCCL, so that every
+    # collective of the multi-GPU path -- initialisation, all-gather, barrier, all-reduce -- runs as it will on a node
+    grouped = world > 1 or os.environ.get("MTG_BENCH_FORCE_DIST") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if oversubscribed:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=dev)
-    scaling = args.scaling or ("strong" if world > 1 else "weak")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    scaling = args.scaling or ("strong" if grouped else "weak")
 
     from mind_the_gaps_amd import synthetic as synth
     from mind_the_gaps_amd.distributed import block_bounds
@@ -263,7 +267,7 @@ def main():
     # the exchange step of the sharded sweep: per-light-curve maxima of lnP, all-gathered
     d_best = torch.full((L_pad,), -np.inf, dtype=torch.float64, device=dev)
     gdev = "cpu" if oversubscribed else dev
-    d_gather = torch.empty(world * L_pad, dtype=torch.float64, device=gdev) if world > 1 else None
+    d_gather = torch.empty(world * L_pad, dtype=torch.float64, device=gdev) if grouped else None
     stream = torch.cuda.current_stream(dev)
 
     def sweep(n_eval=B):
@@ -272,13 +276,13 @@ def main():
 
     def step():
         sweep()
-        if world > 1:
+        if grouped:
             torch.amax(d_out.view(L, W), dim=1, out=d_best[:L])
             dist.all_gather_into_tensor(d_gather, d_best.cpu() if oversubscribed else d_best)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -293,7 +297,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prep_ms, solve_ms = eng.profile_read()
 
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -417,7 +421,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
