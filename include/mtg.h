@@ -149,8 +149,18 @@ MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, cons
  * NULL is what it is everywhere in HIP: the (legacy) default stream -- PyTorch's
  * torch.cuda.current_stream().cuda_stream is 0 for its default stream, and work the caller has
  * queued there (the producer of d_theta, the consumer of d_out) is ordered with the launch.
- * MTG_STREAM_CONTEXT selects the context's own non-blocking stream (mtg_synchronize waits for it),
- * which is NOT ordered against the default stream.
+ * MTG_STREAM_CONTEXT selects the context's own non-blocking stream, which is NOT ordered against the
+ * default stream as far as the CALLER's work goes.  The library's own calls are always ordered one after
+ * the other whatever streams they run on (they share the context's workspaces): a call that follows one on
+ * a different stream waits for it through an event, and mtg_synchronize waits for the last call on a
+ * caller's stream as well as for the context's stream.
+ *
+ * Order of evaluation: the throughput kernel gives every evaluation a lane and each lane reads its own
+ * light curve, so it wants the lanes of a wave on one or two light curves.  Large batches are therefore
+ * swept in the order of a stable sort by (structure, light curve) of the library's own making, whatever
+ * order the caller's rows have (results are per row and do not depend on it); mtg_set_sort: 0 = keep the
+ * caller's order, 1 = always sort, 2 (default) = sort unless the host-pointer entry point sees that the
+ * rows are grouped by light curve already.
  */
 #define MTG_STREAM_CONTEXT ((void *)(intptr_t)-1)
 MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_theta,
@@ -181,6 +191,10 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
  * the 32-256 evaluations of an ensemble half-step).
  */
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
+MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
+/* Name of the kernel the last batch was dispatched to, e.g. "mtg_solve_kernel<1,2,1>" (first structure of the
+ * model when several were launched); "" before the first call.  For measurements (bench.py roofline.kernel). */
+MTG_API const char *mtg_last_solver(const mtg_ctx *ctx);
 /*
  * J = 10 time-parallel path: enabled != 0 (default) takes the likelihood from the chunk-composition pass
  * and the scan alone and sends only evaluations whose terms cancel badly (or meet a non-positive pivot)
@@ -188,7 +202,8 @@ MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
  * switch for tests and measurements.
  */
 MTG_API int mtg_set_tp_direct(mtg_ctx *ctx, int enabled);
-/* Block until everything enqueued on the context's stream has finished. */
+/* Block until everything enqueued on the context's stream has finished, and the last
+ * mtg_loglike_batch_device call made on a caller's stream. */
 MTG_API int mtg_synchronize(mtg_ctx *ctx);
 /* Device time (ms, HIP events on the launch stream) of the last
  * mtg_loglike_batch / mtg_loglike_coeffs call: kernels only, no copies. */
@@ -223,10 +238,14 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
                               const int32_t *lc_of_ensemble);
 MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp_chain);
 /* Resume: after mtg_ensemble_init with the coordinates and the seed of a saved state (mtg_ensemble_get), put the
- * iteration counter -- every random number is a function of (seed, iteration, ...) -- and, optionally, the
- * acceptance counts and the running best back; mtg_ensemble_run then continues the chain bit for bit. */
-MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const int32_t *naccept, const double *best_lnp,
-                                 const double *best_coords);
+ * iteration counter -- every random number is a function of (seed, iteration, ...) --, the saved
+ * log-probabilities lnp [E][W] and, optionally, the acceptance counts and the running best back;
+ * mtg_ensemble_run then continues the chain bit for bit.  lnp = NULL keeps the values mtg_ensemble_init has
+ * just computed for the saved coordinates: the same numbers to rounding, but from ONE batch of E W rows where
+ * the run evaluated half-ensembles -- another row count may mean another kernel and summation order, and a
+ * last-bit difference can flip an accept decision; pass the saved values for a bit-for-bit continuation. */
+MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const double *lnp, const int32_t *naccept,
+                                 const double *best_lnp, const double *best_coords);
 MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *best_lnp, double *best_coords,
                              int32_t *naccept, int64_t *iteration, int32_t *n_notpd);
 
@@ -240,9 +259,9 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
  * its dimension, as emcee does.
  */
 MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int P, const double *chain, double *rho);
-/* hipFFT's one-time start-up (~1.4 s: the first plan of a process) paid now; safe to call from a helper thread,
- * with a device already selected by an mtg_create in this process. */
-MTG_API int mtg_fft_warmup(void);
+/* hipFFT's one-time start-up (~1.4 s: the first plan of a process) paid now, on the context's device; safe to call
+ * from a helper thread (HIP's current device is per thread: the call selects ctx's; NULL = the thread's current). */
+MTG_API int mtg_fft_warmup(mtg_ctx *ctx);
 
 /*
  * Walker sharding of the resident ensembles across the GPUs of a job (one process per GPU; the
@@ -278,6 +297,16 @@ MTG_API int mtg_rccl_unique_id(void *id128);
 MTG_API int mtg_ensemble_shard_rccl(mtg_ctx *ctx, const void *id128, int rank, int world);
 MTG_API int mtg_ensemble_shard_host(mtg_ctx *ctx, int rank, int world, mtg_exchange_fn fn, void *user);
 MTG_API int mtg_ensemble_unshard(mtg_ctx *ctx);
+/* How the resident ensembles are sharded: kind 0 none / 1 RCCL / 2 host callback, this process's rank and the
+ * world it was given, and -- RCCL -- the communicator's own idea of its size (ncclCommCount).  Any pointer may
+ * be NULL. */
+MTG_API int mtg_ensemble_shard_info(const mtg_ctx *ctx, int *kind, int *rank, int *world, int *comm_ranks);
+/* Time the RCCL exchange: HIP events on the launch stream around the first `capacity` all-gather pairs of the
+ * following mtg_ensemble_run calls; mtg_ensemble_shard_profile_read waits for them, writes their durations (ms)
+ * and returns how many were recorded, ending the session.  (What an exchange costs on the stream -- including
+ * the wait for the slowest rank's solve -- not the wire time alone.) */
+MTG_API int mtg_ensemble_shard_profile(mtg_ctx *ctx, int capacity);
+MTG_API int mtg_ensemble_shard_profile_read(mtg_ctx *ctx, int capacity, double *exchange_ms);
 
 /*
  * Posterior-predictive light-curve simulation, the step before the hot path in the

@@ -116,6 +116,25 @@ struct mtg_ctx {
     // per-call kernel timing (mtg_profile_*): event triples start / solve / end
     std::vector<hipEvent_t> prof_ev;
     int prof_cap = 0, prof_n = 0;
+
+    // order of the serial sweep (mtg_sort.hip): 0 the caller's order, 1 always sorted by (structure, light curve),
+    // 2 sorted unless the caller's order is known to be grouped already (host entry points look at lc_index)
+    int sort_mode = 2;
+    int lc_grouped_hint = 0;   // set by the host-pointer entry points for the call in flight
+    DevBuf sort_keys, sort_keys_out, sort_order, sort_tmp;
+    char last_solver[96] = "";   // what the last solve dispatched (mtg_last_solver)
+
+    // Calls may come on the caller's streams (mtg_loglike_batch_device) and on the context's own; they share the
+    // workspaces, so consecutive calls on different streams are chained with events: every call on a foreign
+    // stream ends by recording `foreign_done` on it, every call begins by waiting for whatever ran last elsewhere.
+    hipEvent_t foreign_done = nullptr, own_done = nullptr;
+    bool foreign_pending = false;   // work recorded in foreign_done that the context's stream has not waited for
+    bool own_dirty = false;         // the context's stream has had work since the last foreign call waited for it
+    hipStream_t last_foreign = nullptr;
+
+    // timing of the walker-sharded exchange (mtg_ensemble_shard_profile): event pairs around the first exchanges of a run
+    std::vector<hipEvent_t> shard_ev;
+    int shard_ev_cap = 0, shard_ev_n = 0;
 };
 
 namespace {
@@ -167,6 +186,44 @@ int use_device(mtg_ctx *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return MTG_OK;
 }
+
+// Begin a call that launches on stream `s`: wait for what the previous calls left running on other streams.
+int enter_stream(mtg_ctx *ctx, hipStream_t s)
+{
+    if (s == ctx->stream) {
+        if (ctx->foreign_pending) {
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->foreign_done, 0));
+            ctx->foreign_pending = false;
+        }
+        ctx->own_dirty = true;
+        return MTG_OK;
+    }
+    if (ctx->own_dirty) {
+        HIP_TRY(ctx, hipEventRecord(ctx->own_done, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->own_done, 0));
+        ctx->own_dirty = false;
+    }
+    if (ctx->foreign_pending && ctx->last_foreign != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->foreign_done, 0));
+    return MTG_OK;
+}
+
+// End of a call on a foreign stream: later calls (and mtg_synchronize) wait for this point.
+int leave_stream(mtg_ctx *ctx, hipStream_t s)
+{
+    if (s == ctx->stream) return MTG_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->foreign_done, s));
+    ctx->foreign_pending = true;
+    ctx->last_foreign = s;
+    return MTG_OK;
+}
+
+// the context's own stream, ordered after whatever ran last on a caller's stream
+#define CTX_STREAM(ctx, s)                         \
+    hipStream_t s = (ctx)->stream;                 \
+    do {                                           \
+        int rc__ = enter_stream((ctx), s);         \
+        if (rc__) return rc__;                     \
+    } while (0)
 
 int reserve_workspace(mtg_ctx *ctx, int64_t B, int nslots, int nsig)
 {
@@ -251,7 +308,8 @@ int sweep_launch(mtg_ctx *ctx, mtg_solve_launcher fn, MtgSolveArgs sa, int64_t B
     return MTG_OK;
 }
 
-int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s);
+int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s,
+                   bool may_sort = false);
 
 // theta -> coefficients -> solver(s) for B evaluations; timing events around the launches
 int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_t *d_lc,
@@ -272,7 +330,7 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
     {
         mtg_trace::Range range("mtg:solve (factorisation + forward solve)");
-        rc = solve_prepared(ctx, B, d_lc, d_out, d_status, s);
+        rc = solve_prepared(ctx, B, d_lc, d_out, d_status, s, true);
     }
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
@@ -285,7 +343,9 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
 }
 
 // Launch the solver(s) for B prepared evaluations living in ctx->coef (lists / counts filled).
-int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s)
+// may_sort: the caller's order is arbitrary (mtg_loglike_batch[_device]); the device sampler's batches are grouped
+// by ensemble, hence by light curve, by construction.
+int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s, bool may_sort)
 {
     const MtgModel &m = ctx->model;
     const int nsig = m.nsho + 1;
@@ -360,13 +420,32 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         if (!fused) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 64);
     }
     sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
+    // The serial sweep reads each lane's own light curve: sort the evaluations by (structure, light curve) unless the
+    // caller's order is known to be grouped (mtg_sort.hip).  One light curve, or no index at all: nothing to sort.
+    const int *sorted = nullptr;
+    if (may_sort && !small_ok && d_lc && ctx->L > 1 && B > 64 && (uint64_t)ctx->L * (uint64_t)nsig < 0x7fffffffull &&
+        (ctx->sort_mode == 1 || (ctx->sort_mode == 2 && !ctx->lc_grouped_hint))) {
+        mtg_trace::Range range("mtg:sort (evaluations by structure, light curve)");
+        const size_t tmp = mtg_sort_temp_bytes(B, mtg_sort_key_bits(ctx->L, nsig));
+        HIP_TRY(ctx, ctx->sort_keys.reserve((size_t)B * 4));
+        HIP_TRY(ctx, ctx->sort_keys_out.reserve((size_t)B * 4));
+        HIP_TRY(ctx, ctx->sort_order.reserve((size_t)B * 4));
+        HIP_TRY(ctx, ctx->sort_tmp.reserve(tmp > 0 ? tmp : 16));
+        HIP_TRY(ctx, mtg_launch_sort_by_lightcurve(B, d_status, nsig > 1 ? ctx->sig.as<int32_t>() : nullptr, d_lc, ctx->L, nsig,
+                                                   ctx->sort_keys.as<uint32_t>(), ctx->sort_keys_out.as<uint32_t>(),
+                                                   ctx->sort_order.as<int>(), ctx->sort_tmp.p, tmp, s));
+        sorted = ctx->sort_order.as<int>();
+    }
     if (small_ok && Jmodel > 6) {  // rank 10: every structure in one sequence of launches (mtg_tp_big.h)
         sa.list = nullptr;
         sa.count_ptr = nullptr;
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tpb_compose2_kernel (+ mtg_tpb_reduce_kernel<10>, C = %d)", sa.tp_chunks);
         mtg_launch_tp_big(sa, B, s);
     } else if (fused) {  // every signature in one launch
         sa.list = bank_lists(ctx);
         sa.count_ptr = bank_counts(ctx);
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_fused_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig,
+                 wide && mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256) ? 256 : 64);
         fused(sa, B, s);
     } else {
         // A time-parallel launch is latency bound: a structure holding three evaluations takes as long
@@ -390,6 +469,16 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             if (tp && wide && mtg_find_tp_wide_solver(nr, nc)) tp = mtg_find_tp_wide_solver(nr, nc);
             sa.list = nsig > 1 ? bank_lists(ctx) + (int64_t)k * ctx->cstride : nullptr;
             sa.count_ptr = nsig > 1 ? bank_counts(ctx) + k : nullptr;
+            sa.seg_counts = nullptr; sa.seg_k = 0;
+            if (sorted && !tp) {  // the k-th segment of the sorted order
+                sa.list = sorted;
+                sa.seg_counts = nsig > 1 ? bank_counts(ctx) : nullptr;
+                sa.seg_k = k;
+            }
+            if (k == 0) {
+                if (tp) snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_kernel<%d,%d,%d>", nr, nc, tp == mtg_find_tp_solver(nr, nc) ? 64 : 256);
+                else snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_solve_kernel<%d,%d,%d>", nr, nc, mtg_solver_uses_b0(nr, nc, m.last_b0));
+            }
             hipStream_t sk = fan_out && k > 0 ? ctx->side[k - 1] : s;
             if (sk != s) HIP_TRY(ctx, hipStreamWaitEvent(sk, ctx->fork, 0));
             if (tp) {
@@ -452,7 +541,9 @@ MTG_API mtg_ctx *mtg_create(int device)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->foreign_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->own_done, hipEventDisableTiming) != hipSuccess) {
         fail(nullptr, MTG_E_HIP, "could not create stream/events on device %d", device);
         delete ctx;
         return nullptr;
@@ -465,7 +556,8 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
+    if (ctx->foreign_pending) (void)hipEventSynchronize(ctx->foreign_done);
+    DevBuf *bufs[] = {&ctx->sort_keys, &ctx->sort_keys_out, &ctx->sort_order, &ctx->sort_tmp, &ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->tp_ws, &ctx->sig, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
                       &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
                       &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_naccept,
@@ -476,6 +568,9 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
     for (DevBuf *b : {&ctx->acf_chain, &ctx->acf_x, &ctx->acf_f, &ctx->acf_g, &ctx->acf_r, &ctx->acf_ss, &ctx->acf_tmp}) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->shard_ev) (void)hipEventDestroy(e);
+    if (ctx->foreign_done) (void)hipEventDestroy(ctx->foreign_done);
+    if (ctx->own_done) (void)hipEventDestroy(ctx->own_done);
     for (hipStream_t st : ctx->side) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
     if (ctx->fork) (void)hipEventDestroy(ctx->fork);
@@ -516,6 +611,8 @@ static int set_lightcurves_common(mtg_ctx *ctx, int64_t N, int64_t L, const doub
     if (rc) return rc;
     mtg_trace::Range range("mtg:set_lightcurves (upload, sigma^2, dx)");
     const int64_t t_rows = t_per_lc ? L : 1;
+    rc = enter_stream(ctx, ctx->stream);
+    if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, ctx->dxt.reserve((size_t)t_rows * N * 16));
     HIP_TRY(ctx, ctx->yv.reserve((size_t)L * N * 16));
@@ -669,7 +766,12 @@ MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_th
     rc = use_device(ctx);
     if (rc) return rc;
     hipStream_t s = stream == MTG_STREAM_CONTEXT ? ctx->stream : (hipStream_t)stream;  // NULL: HIP's default stream
-    return run_model_batch(ctx, B, d_theta, d_lc_index, add_prior, d_out, d_status, s);
+    rc = enter_stream(ctx, s);
+    if (rc) return rc;
+    ctx->lc_grouped_hint = 0;   // device-resident indices: the host cannot see their order
+    rc = run_model_batch(ctx, B, d_theta, d_lc_index, add_prior, d_out, d_status, s);
+    if (rc) return rc;
+    return leave_stream(ctx, s);
 }
 
 MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index,
@@ -681,15 +783,24 @@ MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, cons
         return fail(ctx, MTG_E_ARG, "mtg_loglike_batch: bad arguments");
     if (B == 0) return MTG_OK;
     if (B > INT32_MAX) return fail(ctx, MTG_E_ARG, "batch too large");
+    // (the same pass tells whether the caller's order is already grouped by light curve: then the sweep keeps it)
+    int64_t runs = 1;
+    bool ascending = true;
     if (lc_index)
-        for (int64_t b = 0; b < B; ++b)
+        for (int64_t b = 0; b < B; ++b) {
             if (lc_index[b] < 0 || lc_index[b] >= ctx->L)
                 return fail(ctx, MTG_E_ARG, "lc_index[%lld] = %d outside [0, %lld)", (long long)b,
                             lc_index[b], (long long)ctx->L);
+            if (b > 0 && lc_index[b] != lc_index[b - 1]) ++runs;
+            if (b > 0 && lc_index[b] < lc_index[b - 1]) ascending = false;
+        }
     rc = use_device(ctx);
     if (rc) return rc;
+    // grouped: already in ascending order (sorting changes nothing), or in runs of equal indices long enough that a
+    // wave of 64 lanes straddles two or three light curves at most
+    ctx->lc_grouped_hint = !lc_index || ascending || B / runs >= 32;
     const int P = ctx->model.P;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     HIP_TRY(ctx, ctx->theta.reserve((size_t)B * (P > 0 ? P : 1) * 8));
     HIP_TRY(ctx, ctx->out.reserve((size_t)B * 8));
     HIP_TRY(ctx, ctx->status.reserve((size_t)B * 4));
@@ -740,7 +851,7 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
     rc = reserve_workspace(ctx, B, lay.nslots(), 1);
     if (rc) return rc;
     const int64_t cs = ctx->cstride;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     // host-side transpose [B][j] -> SoA columns, then one upload
     const int nmean = mean_kind == MTG_MEAN_LINEAR ? 2 : 1;
     double *h = (double *)malloc((size_t)cs * lay.nslots() * 8);
@@ -844,7 +955,7 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
         for (int w = 0; w < W; ++w) lc_full[(size_t)(e * W + w)] = l;
         for (int k = 0; k < W / 2; ++k) lc_half[(size_t)(e * (W / 2) + k)] = l;
     }
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     HIP_TRY(ctx, ctx->ens_coords.reserve((size_t)EW * P * 8));
     HIP_TRY(ctx, ctx->ens_lnp.reserve((size_t)EW * 8));
     HIP_TRY(ctx, ctx->ens_perm.reserve((size_t)EW * 4));
@@ -896,6 +1007,7 @@ struct Rccl {
     int (*GetUniqueId)(void *id128) = nullptr;
     int (*CommInitRank)(void **comm, int nranks, Id128 id, int rank) = nullptr;
     int (*CommDestroy)(void *comm) = nullptr;
+    int (*CommCount)(void *comm, int *count) = nullptr;
     int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -920,6 +1032,7 @@ bool rccl_load(const char *path)
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
@@ -980,6 +1093,12 @@ int shard_exchange(mtg_ctx *ctx, int64_t EH, hipStream_t s)
         mtg_trace::Range range("mtg:all-gather of the half-step's log-probabilities (RCCL)");
         // in place: this rank's block already sits at rank * chunk of the receive buffer
         const int64_t at = (int64_t)ctx->shard_rank * chunk;
+        const bool timed = ctx->shard_ev_n < ctx->shard_ev_cap;
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->shard_ev[2 * (size_t)ctx->shard_ev_n], s));
+        struct Stamp {  // the closing event, whatever way the block is left
+            mtg_ctx *c; hipStream_t st; bool on;
+            ~Stamp() { if (on) { (void)hipEventRecord(c->shard_ev[2 * (size_t)c->shard_ev_n + 1], st); c->shard_ev_n += 1; } }
+        } stamp{ctx, s, timed};
         RCCL_TRY(ctx, g_rccl.GroupStart());
         int r1 = g_rccl.AllGather(lnp + at, lnp, (size_t)chunk, RCCL_FLOAT64, ctx->shard_comm, s);
         int r2 = r1 ? r1 : g_rccl.AllGather(st + at, st, (size_t)chunk, RCCL_INT32, ctx->shard_comm, s);
@@ -1051,6 +1170,48 @@ MTG_API int mtg_ensemble_shard_host(mtg_ctx *ctx, int rank, int world, mtg_excha
     return MTG_OK;
 }
 
+MTG_API int mtg_ensemble_shard_info(const mtg_ctx *ctx, int *kind, int *rank, int *world, int *comm_ranks)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (kind) *kind = ctx->shard_kind;
+    if (rank) *rank = ctx->shard_rank;
+    if (world) *world = ctx->shard_world;
+    if (comm_ranks) {
+        *comm_ranks = 0;
+        if (ctx->shard_kind == 1 && ctx->shard_comm && g_rccl.CommCount) (void)g_rccl.CommCount(ctx->shard_comm, comm_ranks);
+    }
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_shard_profile(mtg_ctx *ctx, int capacity)
+{
+    if (!ctx || capacity < 0) return MTG_E_ARG;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    while ((int)ctx->shard_ev.size() < 2 * capacity) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->shard_ev.push_back(e);
+    }
+    ctx->shard_ev_cap = capacity;
+    ctx->shard_ev_n = 0;
+    return MTG_OK;
+}
+
+MTG_API int mtg_ensemble_shard_profile_read(mtg_ctx *ctx, int capacity, double *exchange_ms)
+{
+    if (!ctx || capacity < 0) return MTG_E_ARG;
+    const int n = ctx->shard_ev_n < capacity ? ctx->shard_ev_n : capacity;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->shard_ev[2 * (size_t)i + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->shard_ev[2 * (size_t)i], ctx->shard_ev[2 * (size_t)i + 1]));
+        if (exchange_ms) exchange_ms[i] = ms;
+    }
+    ctx->shard_ev_cap = 0;
+    return n;
+}
+
 MTG_API int mtg_ensemble_unshard(mtg_ctx *ctx)
 {
     if (!ctx) return MTG_E_ARG;
@@ -1074,7 +1235,7 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     if (rc) return rc;
     const int E = (int)ctx->ens_E, W = ctx->ens_W, P = ctx->ens_P, H = W / 2;
     const int64_t EW = (int64_t)E * W, EH = (int64_t)E * H;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     mtg_trace::Range range("mtg:ensemble_run (stretch moves, device resident)");
     if (chain) HIP_TRY(ctx, ctx->ens_chain.reserve((size_t)steps * EW * P * 8));
     if (lnp_chain) HIP_TRY(ctx, ctx->ens_lnp_chain.reserve((size_t)steps * EW * 8));
@@ -1150,8 +1311,8 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     return MTG_OK;
 }
 
-MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const int32_t *naccept, const double *best_lnp,
-                                 const double *best_coords)
+MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const double *lnp, const int32_t *naccept,
+                                 const double *best_lnp, const double *best_coords)
 {
     if (!ctx) return MTG_E_ARG;
     if (ctx->ens_E <= 0) return fail(ctx, MTG_E_STATE, "mtg_ensemble_init has not been called");
@@ -1159,7 +1320,12 @@ MTG_API int mtg_ensemble_restore(mtg_ctx *ctx, int64_t iteration, const int32_t 
     int rc = use_device(ctx);
     if (rc) return rc;
     const int64_t E = ctx->ens_E, EW = E * ctx->ens_W;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
+    // the saved log-probabilities as they are: mtg_ensemble_init has just evaluated the saved coordinates again, but
+    // in ONE batch of E W rows, where the run evaluated them in half-steps of E W/2 (or a rank's share of them) -- the
+    // kernel and its summation order follow the row count, so those values may differ in the last bits and flip an
+    // accept decision of the continued chain
+    if (lnp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lnp.p, lnp, (size_t)EW * 8, hipMemcpyHostToDevice, s));
     if (naccept) HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_naccept.p, naccept, (size_t)EW * 4, hipMemcpyHostToDevice, s));
     if (best_lnp) HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_best_lnp.p, best_lnp, (size_t)E * 8, hipMemcpyHostToDevice, s));
     if (best_coords)
@@ -1178,7 +1344,7 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     if (rc) return rc;
     const int64_t E = ctx->ens_E, EW = E * ctx->ens_W;
     const int P = ctx->ens_P;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     if (coords) HIP_TRY(ctx, hipMemcpyAsync(coords, ctx->ens_coords.p, (size_t)EW * P * 8, hipMemcpyDeviceToHost, s));
     if (lnp) HIP_TRY(ctx, hipMemcpyAsync(lnp, ctx->ens_lnp.p, (size_t)EW * 8, hipMemcpyDeviceToHost, s));
     if (best_lnp) HIP_TRY(ctx, hipMemcpyAsync(best_lnp, ctx->ens_best_lnp.p, (size_t)E * 8, hipMemcpyDeviceToHost, s));
@@ -1191,8 +1357,10 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
     return MTG_OK;
 }
 
-MTG_API int mtg_fft_warmup(void)
+MTG_API int mtg_fft_warmup(mtg_ctx *ctx)
 {
+    // HIP's current device is per THREAD: a helper thread starts on device 0 whatever the context's is
+    if (ctx && hipSetDevice(ctx->device) != hipSuccess) return MTG_E_HIP;
     // hipFFT needs ~1.4 s the first time a plan is made in a process (rocFFT loads its kernels): callers that will
     // need mtg_chain_autocorr or mtg_simulate_tk95 later can pay that early, from another thread
     hipfftHandle plan = 0;
@@ -1212,7 +1380,7 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
         return fail(ctx, MTG_E_ARG, "mtg_chain_autocorr: chain too large");
     int rc = use_device(ctx);
     if (rc) return rc;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     mtg_trace::Range range("mtg:chain_autocorr (convergence check)");
     DevBuf &d_chain = ctx->acf_chain, &d_x = ctx->acf_x, &d_f = ctx->acf_f, &d_g = ctx->acf_g, &d_r = ctx->acf_r, &d_ss = ctx->acf_ss;
     HIP_TRY(ctx, d_chain.reserve((size_t)n2 * S * 8));        // the chain, then the transposed series [S][n2]
@@ -1285,7 +1453,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     MtgCoefLayout lay{m.nr_max, m.nc_max};
     rc = reserve_workspace(ctx, S, lay.nslots() > 4 ? lay.nslots() : 4, 1);
     if (rc) return rc;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     const int64_t nk = nfft / 2 + 1;
     // chunk the simulations so that spectrum + series stay below ~2 GiB
     int64_t chunk = (int64_t)(2.0e9 / (16.0 * (double)nfft));
@@ -1401,7 +1569,7 @@ MTG_API int mtg_tk95_observe_series(mtg_ctx *ctx, int64_t S, int64_t nfft, int64
             return fail(ctx, MTG_E_ARG, "mtg_tk95_observe_series: window %lld outside the segment", (long long)n);
     rc = use_device(ctx);
     if (rc) return rc;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     DevBuf d_series, d_lo, d_hi, d_rates, d_dy;
     hipError_t e = d_series.reserve((size_t)S * nfft * 8);
     if (e == hipSuccess) e = d_lo.reserve((size_t)N * 4);
@@ -1443,7 +1611,7 @@ MTG_API int mtg_predict(mtg_ctx *ctx, int64_t B, const double *theta, const int3
     MtgCoefLayout lay{m.nr_max, m.nc_max};
     rc = reserve_workspace(ctx, B, lay.nslots(), 1);
     if (rc) return rc;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     DevBuf work, d_mu, d_var, d_sig;
     HIP_TRY(ctx, ctx->theta.reserve((size_t)B * (P > 0 ? P : 1) * 8));
     HIP_TRY(ctx, ctx->out.reserve((size_t)B * 8));
@@ -1501,7 +1669,7 @@ MTG_API int mtg_apply_inverse(mtg_ctx *ctx, const double *theta, int32_t lc_inde
     MtgCoefLayout lay{m.nr_max, m.nc_max};
     rc = reserve_workspace(ctx, 1, lay.nslots(), 1);
     if (rc) return rc;
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     DevBuf work, d_mu, d_var, d_sig, d_x;
     HIP_TRY(ctx, ctx->theta.reserve((size_t)(P > 0 ? P : 1) * 8));
     HIP_TRY(ctx, ctx->out.reserve(8));
@@ -1555,7 +1723,7 @@ MTG_API int mtg_math_probe(mtg_ctx *ctx, int64_t n, const double *x, double *exp
     DevBuf buf;
     HIP_TRY(ctx, buf.reserve((size_t)n * 8 * 5));
     double *d = buf.as<double>();
-    hipStream_t s = ctx->stream;
+    CTX_STREAM(ctx, s);
     hipError_t e = hipMemcpyAsync(d, x, (size_t)n * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         mtg_launch_math_probe(n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, s);
@@ -1585,12 +1753,23 @@ MTG_API int mtg_set_tp_direct(mtg_ctx *ctx, int enabled)
     return MTG_OK;
 }
 
+MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MTG_E_ARG;
+    ctx->sort_mode = mode;
+    return MTG_OK;
+}
+
+MTG_API const char *mtg_last_solver(const mtg_ctx *ctx) { return ctx ? ctx->last_solver : ""; }
+
 MTG_API int mtg_synchronize(mtg_ctx *ctx)
 {
     if (!ctx) return MTG_E_ARG;
     int rc = use_device(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // ... and on the caller's stream of the last mtg_loglike_batch_device, if nothing has waited for it since
+    if (ctx->foreign_pending) HIP_TRY(ctx, hipEventSynchronize(ctx->foreign_done));
     return MTG_OK;
 }
 

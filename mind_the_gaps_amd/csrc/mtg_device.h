@@ -100,6 +100,10 @@ struct MtgSolveArgs {
     int tp_direct;  // likelihood without the filter pass (mtg_tp_big.h)
     int tp_nr0, tp_nc0;    // structure with no over-damped SHO term; evaluation ev has (tp_nr0 + 2 sig[ev], tp_nc0 - sig[ev])
     const int32_t *sig;    // [B] over-damped SHO terms per evaluation (mtg_prepare_one), or NULL = 0
+    // serial sweep in sorted order (mtg_sort.hip): `list` is the whole batch sorted by (structure, light curve) and
+    // this launch takes the seg_k-th segment of it, which starts after seg_counts[0 .. seg_k); NULL: list starts at 0
+    const int *seg_counts = nullptr;
+    int seg_k = 0;
 };
 
 // doubles per filtering element (A | b | eta | C | Jm | five likelihood scalars) of the time-parallel kernel,
@@ -136,6 +140,14 @@ mtg_solve_launcher mtg_find_tp_wide_solver(int nr, int nc);
 // takes list = base of the per-structure lists, count_ptr = base of the counts; lanes 64 or 256.
 mtg_solve_launcher mtg_find_tp_fused_solver(int nr0, int nc0, int nsig, int lanes);
 void mtg_launch_prepare(const MtgPrepArgs &, hipStream_t);
+// mtg_sort.hip: evaluation indices sorted (stable) by key = structure * L + light curve, rejected rows last
+int mtg_sort_key_bits(int64_t L, int nsig);
+size_t mtg_sort_temp_bytes(int64_t B, int bits);
+hipError_t mtg_launch_sort_by_lightcurve(int64_t B, const int32_t *status, const int32_t *sig, const int32_t *lc, int64_t L,
+                                         int nsig, uint32_t *keys_in, uint32_t *keys_out, int *order, void *temp,
+                                         size_t temp_bytes, hipStream_t stream);
+// does mtg_find_solver(nr, nc, last_b0) return the b = 0 specialisation?
+int mtg_solver_uses_b0(int nr, int nc, int last_b0);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,
                          const double *yerr, const double *y_offset, double2 *dxt, double2 *yv,
                          double *dxmax, hipStream_t);

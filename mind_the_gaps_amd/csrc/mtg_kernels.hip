@@ -265,8 +265,13 @@ __global__ void __launch_bounds__(MTG_BLOCK, mtg_waves_for(NR + 2 * NC)) mtg_sol
     if (a.solo && (threadIdx.x & 63) != 0) return;
     const int64_t gid = (int64_t)blockIdx.x * per_block + (a.solo ? threadIdx.x >> 6 : threadIdx.x);
     if (gid >= count) return;
-    const int64_t e = a.list ? (int64_t)a.list[gid] : gid;
-    if (!a.list && a.status[e] != MTG_ST_OK) return;  // prior said -inf
+    int64_t first = 0;  // sorted order: this structure's segment of the sorted batch
+    if (a.seg_counts)
+        for (int i = 0; i < a.seg_k; ++i) first += a.seg_counts[i];
+    const int64_t e = a.list ? (int64_t)a.list[first + gid] : gid;
+    // prior said -inf (the structure lists hold accepted rows only; a sorted single-structure batch keeps its rejected
+    // rows at the end of the order)
+    if (a.status[e] != MTG_ST_OK) return;
 
     // ---- coefficients of this evaluation -----------------------------------
     MtgLane<NR, NC> L;
@@ -419,6 +424,12 @@ static const mtg_solve_launcher mtg_solver_table_b0[5][4] = {MTG_ROW_B0(0), MTG_
                                                             MTG_ROW_B0(4)};
 
 // last_b0: the model's last complex term has b = 0 whatever its parameters (mtg_set_model works it out)
+int mtg_solver_uses_b0(int nr, int nc, int last_b0)
+{
+    if (nr < 0 || nc < 0 || nr > MTG_MAX_NR || nc > MTG_MAX_NC) return 0;
+    return last_b0 && nr < 5 && nc < 4 && mtg_solver_table_b0[nr][nc] ? 1 : 0;
+}
+
 mtg_solve_launcher mtg_find_solver(int nr, int nc, int last_b0)
 {
     if (nr < 0 || nc < 0 || nr > MTG_MAX_NR || nc > MTG_MAX_NC) return nullptr;

@@ -19,9 +19,11 @@ __all__ = ["DeviceEnsembleSampler"]
 # 53 ms) -- once hipFFT is up (~0.8 s the first time in a process; the sampler starts that on a helper thread when it
 # starts sampling) and has a plan for the padded length: ~15 ms with the kernels in rocFFT's cache, ~1.2 s when
 # rocFFT has to compile them first (it does that at run time for every new length on this ROCm build; the package
-# ships a cache file with the power-of-two lengths, engine._seed_rocfft_cache).  So every padded length is rented
-# before it is bought: the host does the checks of a length until it has spent as long on them as the plan would
-# cost (or a single check would) -- at most twice the cost of always choosing right.
+# ships a seed of the cache with the power-of-two lengths, engine._seed_rocfft_cache).  So every padded length is
+# rented before it is bought: the host does the checks of a length until their ESTIMATED cost (a fixed rate per
+# chain point -- not a measured time) has reached what the plan would cost, or a single check would -- at most
+# twice the cost of always choosing right.  The choice is a pure function of the sequence of chain shapes checked
+# so far: the same run takes the same path (and gets the same tau, to the last bit) every time, on every rank.
 HOST_SECONDS_PER_POINT = 1.1e-8      # measured: 7 ms for 6.4e5 points, 30 ms for 2e6, 220 ms for 2e7
 
 
@@ -32,7 +34,6 @@ def _plan_seconds():
 
 def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
     """chain[n_t, W, P] -> tau[P]; or chain[n_t, E, W, P] (independent ensembles) -> tau[E, P]."""
-    import time
     n_t = chain.shape[0]
     many = chain.ndim == 4
 
@@ -47,21 +48,17 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
     estimate = HOST_SECONDS_PER_POINT * chain.size
     rented = state["rented"].get(key, 0.0)
     plan = _plan_seconds()
-    on_device = getattr(engine, "fft_ready", False) and n_t >= 2 and (
-        key == state["planned"] or estimate > plan or rented > plan)
+    on_device = n_t >= 2 and (key == state["planned"] or estimate > plan or rented > plan)
     if on_device:
         try:
-            rho = engine.chain_autocorr(chain)
+            rho = engine.chain_autocorr(chain)   # (waits for the hipFFT warm-up thread if it is still at it)
         except Exception:        # (too large for the device's workspace, hipFFT refusing a plan ...): the host can always
             rho = None
         else:
             state["planned"] = key
             return taus(rho)
-    t0 = time.perf_counter()
-    try:
-        return taus(None)
-    finally:
-        state["rented"][key] = rented + time.perf_counter() - t0
+    state["rented"][key] = rented + estimate
+    return taus(None)
 
 
 class DeviceEnsembleSampler:
@@ -132,8 +129,9 @@ class DeviceEnsembleSampler:
 
     def load(self, path):
         """Continue the run ``save`` wrote: the next ``run_mcmc(None, n)`` produces the iterations the original run
-        would have produced (random numbers are functions of (seed, iteration, walker); the log-probabilities of the
-        saved coordinates are evaluated again by the same kernels)."""
+        would have produced (random numbers are functions of (seed, iteration, walker); the saved log-probabilities
+        go back as they are -- evaluating the saved coordinates again, in one batch instead of half-steps, may take
+        another kernel and differ in the last bits, enough to flip an accept decision)."""
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
         if tuple(z["shape"]) != (self.E, self.nwalkers, self.ndim):
             raise ValueError("the checkpoint holds %s ensembles x walkers x parameters, this sampler %s"
@@ -141,7 +139,8 @@ class DeviceEnsembleSampler:
         eng = self._bind()
         self.seed = int(z["seed"])
         eng.ensemble_init(z["state_coords"], seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
-        eng.ensemble_restore(int(z["iteration"]), z["state_naccept"], z["state_best_log_prob"], z["state_best_coords"])
+        eng.ensemble_restore(int(z["iteration"]), z["state_log_prob"], z["state_naccept"], z["state_best_log_prob"],
+                             z["state_best_coords"])
         if self.shard_group is not False:
             from .distributed import shard_device_ensemble
             self.transport = shard_device_ensemble(eng, self.shard_group, self.shard_transport)
@@ -165,8 +164,17 @@ class DeviceEnsembleSampler:
     def get_autocorr_time(self, discard=0, thin=1, ensemble=0, **kwargs):
         chain = self.get_chain(discard=discard, thin=thin, ensemble=ensemble)
         if "acf" not in kwargs:
-            return thin * _autocorr_time_where_it_is_cheapest(self._bind(), chain, kwargs)
-        return thin * integrated_time(chain, **kwargs)
+            tau = thin * _autocorr_time_where_it_is_cheapest(self._bind(), chain, kwargs)
+        else:
+            tau = thin * integrated_time(chain, **kwargs)
+        if self.shard_group is not False:
+            # every rank holds the same chain, but host and device FFTs agree to ~1e-11 only and a device failure
+            # falls back to the host on that rank alone: the ranks must take the SAME convergence decision (one that
+            # stops sampling while the others enter the next all-gather hangs the job), so rank 0's value is
+            # everybody's
+            from .distributed import broadcast_array
+            tau = broadcast_array(tau, self.shard_group)
+        return tau
 
     @property
     def acceptance_fraction(self):

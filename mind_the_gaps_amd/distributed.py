@@ -15,7 +15,7 @@ import numpy as np
 
 __all__ = ["block_bounds", "shard_rows", "shard_lightcurves", "all_gather_rows",
            "sharded_log_prob", "LightcurveShard", "WalkerShardedLogProb", "lockstep", "shard_device_ensemble",
-           "broadcast_start"]
+           "broadcast_start", "broadcast_array"]
 
 
 def block_bounds(n_items, world_size):
@@ -186,6 +186,22 @@ def broadcast_start(p0, seed, group=None):
     dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
                                device=_object_device(group))
     return objs[0], objs[1]
+
+
+def broadcast_array(values, group=None):
+    """Rank 0's float64 array to every rank (same shape everywhere): decisions that must not differ between the
+    ranks of a walker-sharded run -- the autocorrelation times behind the convergence test -- are taken from it."""
+    import torch
+    import torch.distributed as dist
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return values
+    buf = torch.from_numpy(values.copy())
+    dev = _object_device(group)
+    if dev is not None:
+        buf = buf.to(dev)
+    dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return buf.cpu().numpy().reshape(values.shape)
 
 
 def _object_device(group):

@@ -32,7 +32,8 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_ensemble_restore",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_ensemble_restore", "mtg_set_sort", "mtg_last_solver",
+    "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
 
 # the exchange of a walker-sharded ensemble as a callback (include/mtg.h, mtg_exchange_fn)
@@ -81,21 +82,71 @@ def _adopt_pytorch_hip_runtime():
 
 
 ROCFFT_CACHE_SEED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rocfft_cache_gfx950.db")
+ROCFFT_CACHE_STAMP = ROCFFT_CACHE_SEED + ".version"   # the librocfft the seed was made with (make_rocfft_cache.py)
 rocfft_cache_seeded = False
+_rocfft_cache_copy = None
+
+
+def rocfft_library_version():
+    """Fingerprint of the librocfft this process will load -- PyTorch's bundled copy when PyTorch is installed
+    (``_adopt_pytorch_hip_runtime`` loads its libhipfft first), else /opt/rocm's: ``<file name>:<size in bytes>``.
+    rocFFT's run-time-compiled code objects are only valid for the build that made them."""
+    dirs = []
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            dirs.append(os.path.join(list(spec.submodule_search_locations)[0], "lib"))
+    except (ImportError, ValueError):
+        pass
+    dirs.append(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"))
+    for libdir in dirs:
+        for name in ("librocfft.so", "librocfft.so.0"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                real = os.path.realpath(path)
+                return "%s:%d" % (os.path.basename(real), os.path.getsize(real))
+    return "unknown"
 
 
 def _seed_rocfft_cache():
     """rocFFT compiles the kernels of every new transform length at run time (~1.2 s each on this ROCm build) and
     keeps them in the file ROCFFT_RTC_CACHE_PATH names -- by default under ~/.cache, which a fresh machine or an
-    ephemeral box does not have.  The package ships that file filled with the power-of-two lengths
-    mtg_chain_autocorr uses (scripts/make_rocfft_cache.py); rocFFT is pointed at it unless the user chose a file."""
-    global rocfft_cache_seeded
+    ephemeral box does not have.  The package ships a SEED of that file with the power-of-two lengths
+    mtg_chain_autocorr uses (scripts/make_rocfft_cache.py).  The seed itself is never opened by rocFFT: every
+    process works on its own copy in the temporary directory (rocFFT writes to the file it is given -- eight ranks
+    of a node must not share one, and the tracked file must not change under a run), removed at exit; the seed is
+    skipped when it was made with another rocFFT build (version stamp next to it) or when the user chose a file."""
+    global rocfft_cache_seeded, _rocfft_cache_copy
     if "ROCFFT_RTC_CACHE_PATH" in os.environ:
-        rocfft_cache_seeded = os.path.abspath(os.environ["ROCFFT_RTC_CACHE_PATH"]) == ROCFFT_CACHE_SEED
+        rocfft_cache_seeded = False
         return
-    if os.path.exists(ROCFFT_CACHE_SEED) and os.access(ROCFFT_CACHE_SEED, os.W_OK):
-        os.environ["ROCFFT_RTC_CACHE_PATH"] = ROCFFT_CACHE_SEED
-        rocfft_cache_seeded = True
+    if not os.path.exists(ROCFFT_CACHE_SEED):
+        return
+    try:
+        stamp = open(ROCFFT_CACHE_STAMP).read().strip()
+    except OSError:
+        stamp = None
+    if stamp != rocfft_library_version():
+        return
+    import atexit
+    import shutil
+    import tempfile
+    try:
+        fd, copy = tempfile.mkstemp(prefix="mtg_rocfft_%d_" % os.getpid(), suffix=".db")
+        os.close(fd)
+        shutil.copyfile(ROCFFT_CACHE_SEED, copy)
+    except OSError:
+        return
+    _rocfft_cache_copy = copy
+
+    def _remove(path=copy):
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    atexit.register(_remove)
+    os.environ["ROCFFT_RTC_CACHE_PATH"] = copy
+    rocfft_cache_seeded = True
 
 
 def load_library():
@@ -160,11 +211,21 @@ def load_library():
     lib.mtg_ensemble_unshard.restype = c_int
     lib.mtg_ensemble_unshard.argtypes = [c_vp]
     lib.mtg_fft_warmup.restype = c_int
-    lib.mtg_fft_warmup.argtypes = []
+    lib.mtg_fft_warmup.argtypes = [c_vp]
+    lib.mtg_set_sort.restype = c_int
+    lib.mtg_set_sort.argtypes = [c_vp, c_int]
+    lib.mtg_last_solver.restype = ctypes.c_char_p
+    lib.mtg_last_solver.argtypes = [c_vp]
+    lib.mtg_ensemble_shard_info.restype = c_int
+    lib.mtg_ensemble_shard_info.argtypes = [c_vp, _ip, _ip, _ip, _ip]
+    lib.mtg_ensemble_shard_profile.restype = c_int
+    lib.mtg_ensemble_shard_profile.argtypes = [c_vp, c_int]
+    lib.mtg_ensemble_shard_profile_read.restype = c_int
+    lib.mtg_ensemble_shard_profile_read.argtypes = [c_vp, c_int, _dp]
     lib.mtg_chain_autocorr.restype = c_int
     lib.mtg_chain_autocorr.argtypes = [c_vp, c_i64, c_i64, c_int, c_int, _dp, _dp]
     lib.mtg_ensemble_restore.restype = c_int
-    lib.mtg_ensemble_restore.argtypes = [c_vp, c_i64, _ip, _dp, _dp]
+    lib.mtg_ensemble_restore.argtypes = [c_vp, c_i64, _dp, _ip, _dp, _dp]
     lib.mtg_ensemble_get.restype = c_int
     lib.mtg_ensemble_get.argtypes = [c_vp, _dp, _dp, _dp, _dp, _ip, ctypes.POINTER(c_i64), _ip]
     lib.mtg_simulate_tk95.restype = c_int
@@ -223,6 +284,7 @@ class Engine:
     # -- lifetime -----------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None):
+            self._join_fft_warmup()   # the helper thread works on this context's device
             self._lib.mtg_destroy(self._ctx)
             self._ctx = None
 
@@ -399,6 +461,25 @@ class Engine:
         self._check(self._lib.mtg_ensemble_unshard(self._ctx))
         self._exchange_cb = None
 
+    def ensemble_shard_info(self):
+        """dict(kind: "none" | "rccl" | "host", rank, world, comm_ranks: size of the library's RCCL communicator or 0)."""
+        v = [np.zeros(1, dtype=np.int32) for _ in range(4)]
+        self._check(self._lib.mtg_ensemble_shard_info(self._ctx, *[_iptr(a) for a in v]))
+        return dict(kind=("none", "rccl", "host")[int(v[0][0])], rank=int(v[1][0]), world=int(v[2][0]), comm_ranks=int(v[3][0]))
+
+    def shard_profile_begin(self, capacity):
+        """HIP events around the first ``capacity`` RCCL exchanges of the following ``ensemble_run`` calls."""
+        self._check(self._lib.mtg_ensemble_shard_profile(self._ctx, int(capacity)))
+        self._shard_prof_cap = int(capacity)
+
+    def shard_profile_read(self):
+        cap = getattr(self, "_shard_prof_cap", 0)
+        ms = np.zeros(cap)
+        n = self._lib.mtg_ensemble_shard_profile_read(self._ctx, cap, _ptr(ms))
+        if n < 0:
+            self._check(n)
+        return ms[:n]
+
     def ensemble_run(self, steps, store_chain=False):
         """Advance every ensemble ``steps`` iterations; optionally return
         (chain [steps][E][W][P], log_prob [steps][E][W])."""
@@ -415,8 +496,10 @@ class Engine:
         if getattr(self, "fft_ready", False) or getattr(self, "_fft_thread", None) is not None:
             return
 
+        ctx = self._ctx
+
         def work():
-            if self._lib.mtg_fft_warmup() == 0:
+            if self._lib.mtg_fft_warmup(ctx) == 0:   # (selects the context's device: HIP's current device is per thread)
                 self.fft_ready = True
         self._fft_thread = threading.Thread(target=work, name="mtg-fft-warmup", daemon=True)
         self._fft_thread.start()
@@ -441,12 +524,16 @@ class Engine:
         self.fft_ready = True
         return rho if chain.ndim == 4 else rho[:, 0]
 
-    def ensemble_restore(self, iteration, naccept=None, best_log_prob=None, best_coords=None):
-        """After ``ensemble_init`` with a saved state's coordinates and seed: continue from ``iteration``."""
+    def ensemble_restore(self, iteration, log_prob=None, naccept=None, best_log_prob=None, best_coords=None):
+        """After ``ensemble_init`` with a saved state's coordinates and seed: continue from ``iteration`` with the
+        saved ``log_prob`` [E][W] (None: keep what ``ensemble_init`` has just evaluated -- equal to rounding only)."""
+        lp = None if log_prob is None else _f64(log_prob)
+        if lp is not None and lp.shape != tuple(self._ens_shape[:2]):
+            raise ValueError("log_prob must be [E][W]")
         na = None if naccept is None else np.ascontiguousarray(naccept, dtype=np.int32)
         bl = None if best_log_prob is None else _f64(best_log_prob)
         bc = None if best_coords is None else _f64(best_coords)
-        self._check(self._lib.mtg_ensemble_restore(self._ctx, int(iteration), _iptr(na), _ptr(bl), _ptr(bc)))
+        self._check(self._lib.mtg_ensemble_restore(self._ctx, int(iteration), _ptr(lp), _iptr(na), _ptr(bl), _ptr(bc)))
 
     def ensemble_state(self):
         """dict(coords, log_prob, best_log_prob, best_coords, naccept, iteration, n_not_pd)."""
@@ -543,6 +630,15 @@ class Engine:
     def set_tp_direct(self, enabled):
         """J = 10 time-parallel path: likelihood without the filter pass (default on); see include/mtg.h."""
         self._check(self._lib.mtg_set_tp_direct(self._ctx, int(enabled)))
+
+    def set_sort(self, mode):
+        """Order of the throughput kernel's sweep: 0 the caller's, 1 sorted by (structure, light curve), 2 auto."""
+        self._check(self._lib.mtg_set_sort(self._ctx, int(mode)))
+
+    @property
+    def last_solver(self):
+        """Name of the kernel the last batch was dispatched to (include/mtg.h, mtg_last_solver)."""
+        return self._lib.mtg_last_solver(self._ctx).decode()
 
     def set_window_bytes(self, nbytes):
         """Testing aid: reach of one buffer descriptor of the sweep (default 2^32 - 1); see include/mtg.h."""

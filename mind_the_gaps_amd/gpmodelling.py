@@ -236,6 +236,9 @@ class GPModelling:
                 continue
             # tol=0: always get an estimate, even an untrustworthy one
             tau = sampler.get_autocorr_time(tol=0)
+            if shard_walkers and not device_sampler:   # (the device sampler broadcasts rank 0's value itself)
+                from .distributed import broadcast_array
+                tau = broadcast_array(tau, group)
             self.autocorr.append(np.mean(tau))
             if np.all(tau * 100 < sampler.iteration) and np.all(np.abs(old_tau - tau) / tau < 0.01) and converge:
                 print("Convergence reached after %d samples!" % sampler.iteration)

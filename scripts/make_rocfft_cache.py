@@ -3,8 +3,10 @@ power-of-two length 2^3 .. 2^21): on this ROCm build rocFFT compiles the kernels
 plan asks for it, ~1.2 s each, and keeps them in the file ROCFFT_RTC_CACHE_PATH names (default: under ~/.cache).
 Run on an MI355X:
     ROCFFT_RTC_CACHE_PATH=$PWD/gpurun_out/rocfft_cache_gfx950.db python scripts/make_rocfft_cache.py
-and copy the file to mind_the_gaps_amd/rocfft_cache_gfx950.db; engine.load_library points rocFFT at it when the
-variable is not set and the file is writable."""
+and copy the file to mind_the_gaps_amd/rocfft_cache_gfx950.db; the script writes the name of the librocfft build next to
+it (rocfft_cache_gfx950.db.version).  engine.load_library gives every process a private copy of the seed in the
+temporary directory and points rocFFT at that copy -- never at the tracked file -- when the variable is not set and the
+stamp matches the librocfft it finds."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,3 +21,5 @@ for bits in range(3, 22):
     eng.chain_autocorr(rng.standard_normal((n_t, 2, 1)))
     print("length 2^%d: %.2f s" % (bits, time.perf_counter() - t0), flush=True)
 print(os.path.getsize(os.environ["ROCFFT_RTC_CACHE_PATH"]), "bytes")
+from mind_the_gaps_amd.engine import rocfft_library_version
+open(os.environ["ROCFFT_RTC_CACHE_PATH"] + ".version", "w").write(rocfft_library_version() + "\n")

@@ -139,3 +139,44 @@ def test_checkpoint_and_resume_continue_the_chain_bit_for_bit(engine, tmp_path):
     assert np.array_equal(second.get_log_prob(), whole.get_log_prob())
     for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
         assert np.array_equal(state[key], whole.state[key]), key
+
+
+@pytest.mark.parametrize("case", ["four_waves", "rank10"])
+def test_resume_is_bit_for_bit_where_the_batch_size_picks_the_kernel(engine, tmp_path, case):
+    """The resume must not re-evaluate the saved state: `mtg_ensemble_init` evaluates E W rows in ONE batch, the run
+    evaluated half-ensembles, and the row count picks kernel and summation order -- four waves per evaluation up to
+    256 rows at N >= 4096 (one wave beyond), more chunks per evaluation for the rank-10 model's smaller batches.
+    (i) E W = 512 walkers on N = 4100 samples: 256-row half-steps on the four-wave kernel, a 512-row restart on
+    the one-wave kernel; (ii) five SHO terms, N = 2e5, 32 walkers: 16-row half-steps cut the series into 4096 chunks, the
+    32-row restart into 2048.  `mtg_ensemble_restore` puts the saved log-probabilities back: identical continuation."""
+    from mind_the_gaps_amd.device_sampler import DeviceEnsembleSampler
+    if case == "four_waves":
+        kinds, n, W, steps = synth.NULL_MODEL, 4100, 512, (4, 2, 2)
+        p0 = synth.draw_thetas(kinds, W, seed=2, percent=0.02)[None]
+    else:
+        kinds, n, W, steps = [synth.K_SHO] * 5, 200000, 32, (4, 2, 2)
+        base = np.concatenate([[np.log(20.0 + 10 * i), np.log([3.0, 8.0, 10.0, 1.0, 0.8][i]), np.log(2 * np.pi / (5.0 + 6 * i))]
+                               for i in range(5)])
+        p0 = (base * (1 + 0.01 * np.random.default_rng(5).standard_normal((W, 15))))[None]
+    t, y, dy = synth.make_lightcurves(n, 1, seed=9)
+    bnd = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)]])
+    full = np.concatenate([p0[0, 0], [0.0]])
+    free = np.arange(len(full) - 1, dtype=np.int32)
+
+    def bind():
+        engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+        engine.set_model(kinds, full, free, bnd)
+        return engine
+    P = len(free)
+    whole = DeviceEnsembleSampler(bind, W, P, seed=77)
+    whole.run_mcmc(p0, steps[0])
+    first = DeviceEnsembleSampler(bind, W, P, seed=77)
+    first.run_mcmc(p0, steps[1])
+    first.save(tmp_path / "ckpt")
+    second = DeviceEnsembleSampler(bind, W, P, seed=5)
+    restored = second.load(tmp_path / "ckpt")
+    assert np.array_equal(restored["log_prob"], first.state["log_prob"])      # as saved, not as re-evaluated
+    state = second.run_mcmc(None, steps[2])
+    assert np.array_equal(second.get_chain(), whole.get_chain()) and np.array_equal(second.get_log_prob(), whole.get_log_prob())
+    for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
+        assert np.array_equal(state[key], whole.state[key]), key

@@ -365,16 +365,22 @@ def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, 
     from mind_the_gaps_amd import terms
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if world > 1:
+    device = 0
+    if world > 1 and transport == "rccl":   # one GPU per rank, RCCL between them
+        import torch
+        device = rank
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
     th = synth.truth(synth.ALT_MODEL)
     t, y, dy = synth.make_lightcurves(n, 1, seed=41)
     amp, other = (-10, 50), (-10, 10)
     kernel = DampedRandomWalk(th[0], th[1], bounds=[amp, other]) + terms.SHOTerm(
         th[2], th[3], th[4], bounds=[amp, other, other]) + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other])
-    g = GPModelling(GappyLightcurve(t, y[0], dy[0]), kernel)
+    g = GPModelling(GappyLightcurve(t, y[0], dy[0]), kernel, device=device)
     np.random.seed(7 if world == 1 else 7 + rank)
-    eng = get_engine(0)
+    eng = get_engine(device)
     eng.set_time_parallel(tp_mode)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -399,11 +405,39 @@ def _device_chain_worker(rank, world, port, out_dir, case, tp_mode, n, walkers, 
     np.savez(os.path.join(out_dir, "dev_%s_%d_%d.npz" % (case, world, rank)), chain=g.sampler.get_chain(),
              lnp=g.sampler.get_log_prob(), best=g.max_loglikelihood)
     if world > 1:
-        assert g.sampler.transport == "host"
+        assert g.sampler.transport == transport
+        if transport == "rccl":
+            info = eng.ensemble_shard_info()
+            assert info == dict(kind="rccl", rank=rank, world=world, comm_ranks=world), info
         dist.barrier()
         dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
     guard.close()
+
+
+def _visible_gpus():
+    """GPUs of this box, counted without initialising one in the test process (the workers are spawned)."""
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_device_sampler_walker_sharded_rccl_two_gpus(tmp_path):
+    """The real transport: two processes, one MI355X each, `mtg_ensemble_shard_rccl` -- a two-rank communicator
+    made by the library from the ncclUniqueId that torch.distributed (backend nccl) broadcasts, the grouped in-place
+    ncclAllGather pair over xGMI in every half-step.  Both ranks hold the same chain and it is the one-process
+    chain BIT FOR BIT (serial sweep: the same kernel whatever the number of rows).  Needs two GPUs: skipped on the
+    one-GPU boxes, run by the driver's 8-GPU tier."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs two GPUs (the one-GPU box cannot put two RCCL ranks on its card)")
+    world, port = 2, _free_port()
+    _spawn(_device_chain_worker, (world, port, str(tmp_path), "rccl2", 0, 300, 16, "rccl"), world, tmp_path)
+    _spawn(_device_chain_worker, (1, _free_port(), str(tmp_path), "rccl2", 0, 300, 16, "rccl"), 1, tmp_path)
+    r0, r1, single = (np.load(tmp_path / ("dev_rccl2_%s.npz" % name)) for name in ("2_0", "2_1", "1_0"))
+    assert np.array_equal(r0["chain"], r1["chain"]) and np.array_equal(r0["lnp"], r1["lnp"])
+    assert np.array_equal(single["chain"], r0["chain"]) and np.array_equal(single["lnp"], r0["lnp"])
+    assert len(np.unique(r0["chain"][:, :, 0])) > 16
 
 
 @pytest.mark.gpu
