@@ -11,6 +11,14 @@ one full-ensemble sweep = L x W = 512 000 log-probability evaluations through
 mtg_loglike_batch_device (prior + coefficients + fused Cholesky/solve), with t, y, sigma^2 and theta
 already resident in HBM.
 
+Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF:
+the parent spawns N copies of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, a free port
+on 127.0.0.1) before it has touched a GPU, passes rank 0's JSON line through and exits with the
+worst child's code.  Under torch.distributed.run the ranks are already there and nothing is spawned.
+More ranks than GPUs (a one-GPU box: at most 6, the box's process guard) rehearse the multi-rank path
+with the ranks sharing the card and gloo as the transport -- RCCL refuses two ranks on one device;
+the line then says "oversubscribed".
+
 Scaling (--scaling, default "strong" for --gpus N > 1, SURVEY.md 8(d) Config 4): the 2000 light
 curves are cut into contiguous blocks, one per rank (distributed.shard_lightcurves); every rank
 sweeps its own block -- no collective on the data path -- and each step ends with the only exchange
@@ -19,17 +27,28 @@ region.  "weak" gives every rank its own 2000 light curves instead.
 
 The JSON line also carries
   roofline        : algorithmic bytes (24 N + 8 P + 12 per evaluation) / mean
-                    duration of the dominant kernel (mtg_solve_kernel<1,2,1>), HIP events on the launch
-                    stream; the binding resource is FP64 vector issue (bound: "fp64_valu");
-  end_to_end      : the same sweep through the host-pointer entry point (H2D theta, kernels, D2H);
-  strong_shard_8  : one GPU on the share it gets of the 2000 light curves at 8 GPUs (250);
+                    duration of the dominant kernel (named by the library: mtg_last_solver), HIP events
+                    on the launch stream; the binding resource is FP64 vector issue ("fp64_valu");
+  walker_sharded  : (N > 1) configs[2] and configs[4] -- ONE light curve, 256 / 512 walkers -- through
+                    GPModelling.derive_posteriors(device_sampler=True, shard_walkers=True): every
+                    half-step's proposals split over the ranks, ncclAllGather pair on the launch stream
+                    (mtg_ensemble_shard_rccl): iterations/s, rows per rank, half-step ms, exchange us;
+  end_to_end      : (N = 1) the same sweep through the host-pointer entry point (H2D, kernels, D2H);
+  strong_shard_8  : (N = 1) one GPU on the share it gets of the 2000 light curves at 8 GPUs (250);
+  null_model_sweep, config2_raw_kernel, other_configs (configs[0], [1], [2] + T_LRT, [4]),
+  workflow_config3: (N = 1) the other SURVEY 8(d) figures: the null model's sweep beside the alternative's,
+                    the raw kernel at B = 65 536 for DRW+SHO (J = 3 and zero-padded J = 4), the
+                    single-light-curve chains, configs[3] as a whole workflow (scripts/config3_probe.py);
   cpu_baseline    : oracle/celerite_ref.c (a plain-C port of celerite's algorithm, fused one-sweep
                     variant, built -O3 -march=native on this host) single thread and on all usable
                     cores, bounded sample (rank 0, N = 1 only).
+A side measurement that fails fails the bench (non-zero exit): nothing hides in an "error" key.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,9 +58,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# FP64 operations per sample and lane of mtg_solve_kernel<1,2,1> (91 fma + 53 mul/add in kernel v8;
-# `scripts/loop_stats.py 1 2 1` counts the compiled loop: 182 fma + 106 mul/add per two steps)
-FLOP_PER_SAMPLE = 2 * 91 + 53
+FP64_PEAK_TFLOPS = 78.6
+# FP64 operations per sample and lane of the serial sweep's inner loop, mean-free variant (`scripts/loop_stats.py NR NC
+# NB0` on the compiled loop: 2 x fma + mul/add per step)
+FLOP_PER_SAMPLE = {"mtg_solve_kernel<1,2,1>": 2 * 91 + 53, "mtg_solve_kernel<1,1,0>": 2 * 47 + 28,
+                   "mtg_solve_kernel<2,1,0>": 2 * 66 + 39}
+MAX_RANKS_PER_GPU = 6   # the GPU box's process guard
 
 
 def parse():
@@ -57,7 +79,47 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
                     help="default: strong when --gpus > 1 (the light curves are split over the ranks)")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--no-workflow", action="store_true", help="skip configs[3] as a workflow (~30 s)")
     return ap.parse_args()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N children, one rank each, started before this process has
+    made any GPU call (counting devices does not initialise one)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    if args.gpus > ndev * MAX_RANKS_PER_GPU:
+        raise SystemExit("--gpus %d on %d GPU(s): at most %d ranks may share a card (rehearsal only)"
+                         % (args.gpus, ndev, MAX_RANKS_PER_GPU))
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    children = []
+    for rank in range(args.gpus):
+        renv = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv,
+                                         stdout=None if rank == 0 else subprocess.DEVNULL))
+    worst = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for rank in sorted(pending):
+            rc = children[rank].poll()
+            if rc is None:
+                continue
+            pending.discard(rank)
+            if rc != 0:
+                worst = worst or rc
+                for other in pending:          # a rank that died leaves the others in a collective: stop them
+                    children[other].terminate()
+        time.sleep(0.05)
+    raise SystemExit(worst)
 
 
 def usable_cores():
@@ -129,41 +191,59 @@ def cpu_baseline(t, y, dy, kinds, theta, y_mean, seconds, bounds=None, gpu_out=N
             "max_rel_diff_vs_gpu": worst if compared else None, "compared": compared}
 
 
-def single_lightcurve_configs():
-    """BASELINE configs[0], [1], [2] and [4] (ONE light curve each): stretch-move iterations/s through
-    GPModelling.derive_posteriors with the device-resident sampler; such small batches take the
-    time-parallel kernels.  Reported next to the headline, not part of `value`."""
-    import warnings
+# ---- kernels of the single-light-curve configs (same synthetic data: seed 20250704 + 2) ----------------------------
+AMP, OTHER = (-10, 50), (-10, 10)
+
+
+def _kernels():
     from mind_the_gaps_amd import synthetic as synth, terms
-    from mind_the_gaps_amd.gpmodelling import GPModelling
-    from mind_the_gaps_amd.lightcurves import GappyLightcurve
     from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
-    amp, other = (-10, 50), (-10, 10)
     th = synth.truth(synth.ALT_MODEL)
 
     def drw():
-        return DampedRandomWalk(th[0], th[1], bounds=[amp, other])
+        return DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER])
 
     def null_kernel():
-        return drw() + terms.SHOTerm(th[2], th[3], th[4], bounds=[amp, other, other])
+        return drw() + terms.SHOTerm(th[2], th[3], th[4], bounds=[AMP, OTHER, OTHER])
+
+    def alt_kernel():
+        return null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[AMP, OTHER, OTHER])
 
     def five_sho():
         k = None
         for i in range(5):
             term = terms.SHOTerm(np.log(20.0 + 10 * i), np.log([3.0, 8.0, 10.0, 1.0, 0.8][i]),
-                                 np.log(2 * np.pi / (5.0 + 6 * i)), bounds=[amp, other, other])
+                                 np.log(2 * np.pi / (5.0 + 6 * i)), bounds=[AMP, OTHER, OTHER])
             k = term if k is None else k + term
         return k
+    return drw, null_kernel, alt_kernel, five_sho
 
+
+def _gpmodel(make_kernel, n, device=0):
+    from mind_the_gaps_amd import synthetic as synth
+    from mind_the_gaps_amd.gpmodelling import GPModelling
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    t, y, dy = synth.make_lightcurves(n, 1, seed=20250704 + 2)
+    return GPModelling(GappyLightcurve(t, y[0], dy[0]), make_kernel(), device=device)
+
+
+def single_lightcurve_configs():
+    """BASELINE configs[0], [1], [2] and [4] (ONE light curve each): stretch-move iterations/s through
+    GPModelling.derive_posteriors with the device-resident sampler; such small batches take the
+    time-parallel kernels.  configs[2] also runs the null model on the same data and reports
+    T_LRT = -2 (max lnL_null - max lnL_alt) (tutorial_ppp.ipynb:336-340).  Reported next to the headline,
+    not part of `value`."""
+    import warnings
+    drw, null_kernel, alt_kernel, five_sho = _kernels()
     out = {}
     cases = (("configs[0] DRW N=1e3 32 walkers", drw, 1000, 32, 8000, 8),
              ("configs[1] DRW+SHO N=1e4 128 walkers", null_kernel, 10000, 128, 4000, 11),
-             ("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers",
-              lambda: null_kernel() + Lorentzian(th[5], th[6], th[7], bounds=[amp, other, other]), 10000, 256, 4000, 14),
+             ("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers", alt_kernel, 10000, 256, 4000, 14),
+             ("configs[2] null model DRW+SHO N=1e4 256 walkers", null_kernel, 10000, 256, 4000, 11),
              ("configs[4] 5 x SHO (J=10) N=2e5 512 walkers", five_sho, 200000, 512, 40, 21))
+    best = {}
     for name, make_kernel, n, walkers, steps, P in cases:
-        t, y, dy = synth.make_lightcurves(n, 1, seed=20250704 + 2)
-        g = GPModelling(GappyLightcurve(t, y[0], dy[0]), make_kernel())
+        g = _gpmodel(make_kernel, n)
         np.random.seed(1)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -174,31 +254,138 @@ def single_lightcurve_configs():
                                 progress=False, device_sampler=True)
             el = time.perf_counter() - t0
         evals = steps * walkers / el
+        from mind_the_gaps_amd.gp import get_engine
         out[name] = {"iterations_per_s": steps / el, "evals_per_s": evals, "iterations_timed": steps,
+                     "kernel": get_engine(0).last_solver,
                      "algorithmic_hbm_frac": evals * (24 * n + 8 * (P - 6) + 12) / (HBM_PEAK_GBS * 1e9)}
+        best[name] = float(g.max_loglikelihood)
         if n == 200000:
             # what walker sharding over 8 GPUs can gain on this chain: device time of one half-step's likelihoods for
             # the whole half-ensemble (256 rows) and for one rank's share of it (32 rows), same engine, same model
-            from mind_the_gaps_amd.gp import get_engine
             eng = get_engine(0)
             theta = np.asarray(g.sampler.get_chain()[-1], dtype=np.float64)
             ms = {}
             for rows in (256, 32):
-                best = np.inf
+                fastest = np.inf
                 for _ in range(3):
                     eng.loglike(theta[:rows])
-                    best = min(best, eng.last_kernel_ms)
-                ms[rows] = best
+                    fastest = min(fastest, eng.last_kernel_ms)
+                ms[rows] = fastest
             out[name]["walker_shard_8"] = {
                 "half_step_ms_256_rows": ms[256], "half_step_ms_32_rows": ms[32], "speedup": ms[256] / ms[32],
+                "algorithmic_hbm_frac_256_rows": 256 * (24 * n + 8 * 15 + 12) / (ms[256] * 1e-3) / (HBM_PEAK_GBS * 1e9),
                 "what": "likelihoods of one half-step on one MI355X: the whole half-ensemble against the 32 rows a rank "
                         "evaluates when the walkers are sharded over 8 GPUs (mtg_ensemble_shard_rccl); the exchange is one "
                         "all-gather of 256 doubles + status words per half-step"}
+    alt, null = (k for k in best if k.startswith("configs[2]"))
+    out[alt]["T_LRT"] = {"value": -2.0 * (best[null] - best[alt]), "max_lnL_null": best[null], "max_lnL_alt": best[alt],
+                         "what": "-2 (max lnL_null - max lnL_alt) over the burned-in, thinned chains of the two models on the same "
+                                 "(pure-noise) light curve, 256 walkers x 4000 steps each (tutorial_ppp.ipynb:336-340)"}
+    return out
+
+
+def raw_kernel_config2(dev):
+    """SURVEY 8(d) Config 2, second half: the raw throughput kernel at B = 65 536 evaluations of ONE light curve
+    (N = 1e4), DRW + SHO -- J = 3 as the model expands (1 real + 1 complex term), and J = 4 with a zero-amplitude real
+    term appended (BASELINE's label counts 4) through the raw-coefficient entry point."""
+    from mind_the_gaps_amd import synthetic as synth
+    from mind_the_gaps_amd.engine import Engine
+    N, B = 10000, 65536
+    kinds = synth.NULL_MODEL
+    t, y, dy = synth.make_lightcurves(N, 1, seed=20250704 + 2)
+    theta = synth.draw_thetas(kinds, B, seed=20250704 + 20)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    eng = Engine(dev)
+    eng.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    eng.set_model(kinds, full, free, bounds)
+    eng.set_time_parallel(0)   # the throughput kernel is what this entry is about
+    out = {}
+    fastest, name = np.inf, ""
+    for _ in range(4):
+        _, status = eng.loglike(theta, add_prior=True)
+        fastest, name = min(fastest, eng.last_kernel_ms), eng.last_solver
+    n_ok = int((status == 0).sum())
+
+    def entry(kernel, ms, J, P):
+        evals = n_ok / (ms * 1e-3)
+        flop = FLOP_PER_SAMPLE.get(kernel)
+        return {"kernel": kernel, "J": J, "evals": n_ok, "kernel_ms": ms, "evals_per_s": evals,
+                "algorithmic_hbm_frac": evals * (24 * N + 8 * P + 12) / (HBM_PEAK_GBS * 1e9),
+                "fp64_valu_frac": None if flop is None else evals * N * flop / 1e12 / FP64_PEAK_TFLOPS}
+    out["J3"] = entry(name, fastest, 3, 5)
+    # the same evaluations with raw coefficients and a second real term of amplitude 0 (decay rate 1): J = 4
+    ok = status == 0
+    S0, Q, w0 = (np.exp(theta[ok, i]) for i in (2, 3, 4))
+    f = np.sqrt(4.0 * Q * Q - 1.0)
+    a_real = np.stack([np.exp(theta[ok, 0]), np.zeros(n_ok)], axis=1)
+    c_real = np.stack([np.exp(theta[ok, 1]), np.ones(n_ok)], axis=1)
+    a_c, b_c, c_c, d_c = S0 * w0 * Q, S0 * w0 * Q / f, 0.5 * w0 / Q, 0.5 * w0 / Q * f
+    fastest4 = np.inf
+    for _ in range(3):
+        lnl4, st4 = eng.loglike_coeffs(a_real, c_real, a_c[:, None], b_c[:, None], c_c[:, None], d_c[:, None])
+        fastest4 = min(fastest4, eng.last_kernel_ms)
+    lnl3, _ = eng.loglike(theta[ok], add_prior=False)
+    if not np.all(st4 == 0) or float(np.max(np.abs(lnl4 - lnl3) / np.abs(lnl3))) > 1e-9:
+        raise SystemExit("bench: the zero-padded J = 4 evaluation differs from the J = 3 one")
+    out["J4_zero_padded"] = entry("mtg_solve_kernel<2,1,0>", fastest4, 4, 5)
+    out["what"] = ("one light curve, N = 1e4, B = 65 536 evaluations = one wave per SIMD on the serial sweep (a launch this small "
+                   "is latency bound; the device sampler never makes it -- it takes the time-parallel kernels, other_configs)")
+    eng.close()
+    return out
+
+
+def walker_sharded_configs(rank, world, local_dev, oversubscribed):
+    """configs[2] and configs[4] (ONE light curve each) with every half-step's proposals split over the ranks: the
+    device-resident sampler of GPModelling.derive_posteriors(device_sampler=True, shard_walkers=True) --
+    mtg_ensemble_shard_rccl, a grouped in-place ncclAllGather pair on the launch stream (host-staged exchange over
+    gloo when the ranks share a card).  The chains are identical on every rank by construction (same Philox key)."""
+    import warnings
+    import torch.distributed as dist
+    from mind_the_gaps_amd.gp import get_engine
+    _, _, alt_kernel, five_sho = _kernels()
+    out = {}
+    cases = (("configs[2] DRW+SHO+Lorentzian N=1e4 256 walkers", alt_kernel, 10000, 256, 2000),
+             ("configs[4] 5 x SHO (J=10) N=2e5 512 walkers", five_sho, 200000, 512, 60))
+    for name, make_kernel, n, walkers, steps in cases:
+        g = _gpmodel(make_kernel, n, device=local_dev)
+        np.random.seed(1)
+        eng = get_engine(local_dev)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            # the first run makes the communicator and warms the kernels (and RCCL's first collective) up
+            g.derive_posteriors(fit=False, max_steps=10, convergence_steps=10, walkers=walkers, progress=False,
+                                device_sampler=True, shard_walkers=True)
+        sampler = g.sampler
+        info = eng.ensemble_shard_info()
+        if info["kind"] == "rccl":
+            eng.shard_profile_begin(2 * steps)
+        dist.barrier()
+        t0 = time.perf_counter()
+        sampler.run_mcmc(None, steps)          # the same sharded ensembles, continued
+        dist.barrier()
+        el = time.perf_counter() - t0
+        exchange_ms = eng.shard_profile_read() if info["kind"] == "rccl" else np.empty(0)
+        chain_tail = np.ascontiguousarray(sampler.get_chain()[-1])
+        import torch
+        gdev = "cpu" if oversubscribed else torch.device("cuda", local_dev)
+        mine = torch.from_numpy(chain_tail).to(gdev)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        if not all(torch.equal(gathered[0], other) for other in gathered[1:]):
+            raise SystemExit("bench: the ranks of the walker-sharded chain (%s) hold different chains" % name)
+        out[name] = {"iterations_per_s": steps / el, "evals_per_s": steps * walkers / el, "half_step_ms": el / steps / 2 * 1e3,
+                     "iterations_timed": steps, "rows_per_rank": -(-(walkers // 2) // world), "kernel": eng.last_solver,
+                     "transport": info["kind"], "rccl_ranks": info["comm_ranks"],
+                     "exchange_us_median": float(np.median(exchange_ms) * 1e3) if len(exchange_ms) else None,
+                     "exchange_us_min": float(np.min(exchange_ms) * 1e3) if len(exchange_ms) else None,
+                     "chains_identical_on_all_ranks": True}
     return out
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)    # does not return
     import torch
     import torch.distributed as dist
 
@@ -270,8 +457,8 @@ def main():
     d_gather = torch.empty(world * L_pad, dtype=torch.float64, device=gdev) if grouped else None
     stream = torch.cuda.current_stream(dev)
 
-    def sweep(n_eval=B):
-        eng.loglike_device(n_eval, d_theta.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(),
+    def sweep(n_eval=B, th=d_theta):
+        eng.loglike_device(n_eval, th.data_ptr(), d_lc.data_ptr(), d_out.data_ptr(),
                            d_status.data_ptr(), add_prior=True, stream=stream.cuda_stream)
 
     def step():
@@ -296,6 +483,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prep_ms, solve_ms = eng.profile_read()
+    kernel_name = eng.last_solver
 
     if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
@@ -315,6 +503,10 @@ def main():
         raise SystemExit("bench: non-finite log-likelihoods in the timed batch")
 
     extras = {}
+    if world > 1:
+        extras["rccl_ranks"] = {"torch_distributed_world": dist.get_world_size(), "backend": dist.get_backend()}
+        if not args.no_extras:
+            extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
     if world == 1 and not args.no_extras:
         # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status
         reps = max(3, min(args.steps, 10))
@@ -344,11 +536,38 @@ def main():
                                     "what": "one MI355X sweeping 1/8 of the light curves (its share at 8 GPUs, ~1 wave per "
                                             "SIMD); 8 x per_gpu_factor is the strong-scaling speed-up the kernels allow "
                                             "before the all-gather of 2000 doubles"}
+        # (c) the NULL model's sweep over the same light curves (configs[3] fits both models; SURVEY 8(d) Config 4)
+        nkinds = synth.NULL_MODEL
+        nfull, nfree, nbounds = synth.model_spec(nkinds, y, per_lc_mean=True)
+        eng.set_model(nkinds, nfull, nfree, nbounds)
+        d_theta0 = torch.from_numpy(synth.draw_thetas(nkinds, B, seed=20250704 + 41)).to(dev)
+        for _ in range(2):
+            sweep(B, d_theta0)
+        torch.cuda.synchronize(dev)
+        eng.profile_begin(reps)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sweep(B, d_theta0)
+        torch.cuda.synchronize(dev)
+        dt0 = (time.perf_counter() - t1) / reps
+        _, solve0 = eng.profile_read()
+        n_ok0 = int((d_status.cpu().numpy() == 0).sum())
+        k0 = eng.last_solver
+        s0 = float(np.mean(solve0)) * 1e-3
+        flop0 = FLOP_PER_SAMPLE.get(k0)
+        extras["null_model_sweep"] = {
+            "model": "DRW+SHO (J=3, P=5)", "evals_per_step": B, "ms_per_step": dt0 * 1e3, "evals_per_s": B / dt0,
+            "kernel": k0, "kernel_ms": s0 * 1e3,
+            "algorithmic_hbm_frac": n_ok0 * (24 * N + 8 * 5 + 12) / s0 / 1e9 / HBM_PEAK_GBS,
+            "fp64_valu_frac": None if flop0 is None else n_ok0 * N * flop0 / s0 / 1e12 / FP64_PEAK_TFLOPS,
+            "both_models_evals_per_s": 2 * B / (dt0 + elapsed / args.steps)}
+        eng.set_model(kinds, full, free, bounds)
 
     if rank == 0:
         bytes_eval = 24 * N + 8 * P + 12
         solve_s = float(np.mean(solve_ms)) * 1e-3
         achieved = n_ok * bytes_eval / solve_s / 1e9
+        flop = FLOP_PER_SAMPLE.get(kernel_name)
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
         if os.path.exists(pmc):
@@ -387,7 +606,7 @@ def main():
                 # what binds the kernel is FP64 vector issue (fp64_valu below, profiles/): 256 walkers share a
                 # light curve through L2 / MALL and the real HBM traffic is ~1 % of the algorithmic bytes
                 "bound": "fp64_valu",
-                "kernel": "mtg_solve_kernel<1,2,1>",
+                "kernel": kernel_name,   # as dispatched by the library (mtg_last_solver)
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -397,14 +616,13 @@ def main():
                 "bytes_per_eval": bytes_eval,
                 "evals_per_launch": n_ok,
                 "kernel_ms": solve_s * 1e3,
-                "prepare_kernel_ms": float(np.mean(prep_ms)),
+                "prepare_kernel_ms": float(np.mean(prep_ms)),   # theta -> coefficients, and the sort of the sweep's order
                 "J_arith": 5,   # the Lorentzian's null real term (a = 0, c = 0) never enters D_n or z_n: not expanded
                 # FP64 vector work of the J = 6 sweep (scripts/loop_stats.py on the sweep loop) against the
                 # 78.6 TFLOP/s FP64 vector peak
-                "fp64_valu": {"flop_per_sample": FLOP_PER_SAMPLE,
-                              "achieved_tflops": n_ok * N * FLOP_PER_SAMPLE / solve_s / 1e12,
-                              "peak_tflops": 78.6,
-                              "frac": n_ok * N * FLOP_PER_SAMPLE / solve_s / 1e12 / 78.6},
+                "fp64_valu": None if flop is None else {
+                    "flop_per_sample": flop, "achieved_tflops": n_ok * N * flop / solve_s / 1e12,
+                    "peak_tflops": FP64_PEAK_TFLOPS, "frac": n_ok * N * flop / solve_s / 1e12 / FP64_PEAK_TFLOPS},
             },
         }
         line.update(extras)
@@ -412,16 +630,23 @@ def main():
             line["oversubscribed"] = "%d ranks on %d GPU(s): rehearsal of the multi-rank path, not a scaling number" % (world, ndev)
         if world == 1 and args.cpu_seconds > 0 and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds, bounds, out, status)
-            try:
-                line["other_configs"] = single_lightcurve_configs()
-            except Exception as exc:  # never let the side measurements break the headline line
-                line["other_configs"] = {"error": repr(exc)}
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            # the other SURVEY 8(d) figures; a failure here fails the bench
+            line["config2_raw_kernel"] = raw_kernel_config2(local_dev)
+            line["other_configs"] = single_lightcurve_configs()
+            if not args.no_workflow:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("config3_probe", os.path.join(ROOT, "scripts", "config3_probe.py"))
+                probe = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(probe)
+                line["workflow_config3"] = probe.run()
         print(json.dumps(line), flush=True)
 
     eng.close()
     if grouped:
+        dist.barrier()
         dist.destroy_process_group()
 
 

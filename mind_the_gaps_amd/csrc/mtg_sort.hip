@@ -18,6 +18,10 @@
 
 namespace {
 
+// rocPRIM's default falls back to a merge sort below 2^20 items (nine merge passes, ~20 launches of ~5 us for the
+// 512 000 evaluations of the bench); the few significant bits of the key make the one-sweep radix sort two passes
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+
 __global__ void __launch_bounds__(256) mtg_sort_keys_kernel(int64_t B, const int32_t *__restrict__ status,
                                                             const int32_t *__restrict__ sig,
                                                             const int32_t *__restrict__ lc, uint32_t L, uint32_t reject_key,
@@ -48,7 +52,7 @@ size_t mtg_sort_temp_bytes(int64_t B, int bits)
     size_t bytes = 0;
     uint32_t *k = nullptr;
     int *v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, rocprim::counting_iterator<int>(0), v, (size_t)B, 0u, (unsigned)bits,
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, k, k, rocprim::counting_iterator<int>(0), v, (size_t)B, 0u, (unsigned)bits,
                                     (hipStream_t) nullptr);
     return bytes;
 }
@@ -60,6 +64,6 @@ hipError_t mtg_launch_sort_by_lightcurve(int64_t B, const int32_t *status, const
     const int bits = mtg_sort_key_bits(L, nsig);
     hipLaunchKernelGGL(mtg_sort_keys_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, B, status, sig, lc,
                        (uint32_t)L, (uint32_t)((uint64_t)L * (uint64_t)nsig), keys_in);
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<int>(0), order, (size_t)B,
+    return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<int>(0), order, (size_t)B,
                                      0u, (unsigned)bits, stream);
 }

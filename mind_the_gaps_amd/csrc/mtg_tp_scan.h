@@ -77,21 +77,25 @@ static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C, int g)
     return p;
 }
 
-// chunks per evaluation: enough (chunk, evaluation) lanes to fill the 256 CUs at one wave per SIMD
-// (65 536 lanes), at least 64, at most 4096, and no chunk shorter than ~24 samples
+// chunks per evaluation: enough (chunk, evaluation) pairs to fill the GPU ONCE -- the composition kernel gives 64
+// chunks to a workgroup of two waves, one per SIMD, two workgroups to a CU: 512 x 64 = 32 768 chunks in flight --, at
+// least 64, at most 4096, and no chunk shorter than ~24 samples.  (Round 2 asked for 65 536: two rounds of
+// workgroups with chunks half as long take the composition exactly as long, and leave the scan twice the elements.)
 static inline int mtg_tp_big_chunks(int64_t N, int64_t B)
 {
     int C = 64;
-    while (C < 4096 && (int64_t)C * B < 65536 && (int64_t)C * 2 * 24 <= N) C *= 2;
+    while (C < 4096 && (int64_t)C * B < 32768 && (int64_t)C * 2 * 24 <= N) C *= 2;
     return C;
 }
 
-// elements per scan group.  The scan is a chain of dependent J x J operations per group: few, long
-// chains (16) do the least work, many short ones over more levels (4) finish soonest while the GPU is
-// not full -- measured on configs[4]: 1.46 -> 1.05 ms at 32 evaluations, no gain at 256.
+// elements per scan group.  A group is one wave's chain of g - 1 dependent combinations (6.5 us each when the wave
+// has a SIMD to itself, ~1 us of LDS traffic per CU when the GPU is full): the number of combinations of the whole
+// scan is the number of elements whatever g is, so the short chains of g = 4 cost nothing but a launch per level
+// (~5 us) and cut the depth from 15 to 3 combinations per level.
 static inline int mtg_tp_big_gsize(int64_t B, int C)
 {
-    return B * C >= 65536 ? 16 : 4;
+    (void)B; (void)C;
+    return 4;
 }
 
 // up-sweep; kappa != 0: every group (the last one's total too) and the likelihood records
@@ -417,4 +421,345 @@ template <int J> __device__ __forceinline__ void store_first(const Lds<J> &L, do
 }
 
 }  // namespace tpg
+
+// ---------------------------------------------------------------------------------------------------------------
+// One WAVE per combination (round 3).  The 16-lane groups above leave a combination 13 us long -- a chain of ~1100
+// dependent FP64 instructions per lane and 7.9 KB of LDS per group, four groups to a wave, five waves to a CU -- and
+// the up-sweep is a chain of such combinations: 0.37 ms of a 0.85 ms half-step at 32 evaluations.  Here lane (r, q) of
+// a wave owns the column PAIR (2q, 2q + 1) of row r of whatever J x J matrix is being computed (J = 10: 50 lanes at
+// work, the other 14 repeat lane 49), so that a product costs a lane 2 J multiply-adds instead of J^2, the elimination
+// J steps of 4 instead of 2 J, and a wave's 8.8 KB of LDS let eighteen of them share a CU.  Operands are read from
+// LDS as before -- row r of the left factor (the same address for the five lanes of a row), pairs of the right factor's
+// rows (the same address for the ten lanes of a column pair).  There is one wave, so every "barrier" is the wave's own
+// LDS ordering (tpg::wsync).
+namespace tpw {
+
+using tpg::wsync;
+
+template <int J> struct alignas(16) Lds {
+    static_assert(J % 2 == 0, "column pairs");
+    static constexpr int M = J * J;
+    double A1[M], eta1[J], b1[J], C1[M], J1[M];   // running element (b1 | C1 contiguous: the state of `apply`)
+    double A2[M], b2[J], eta2[J], C2[M], J2[M];   // the next element, in the order of the global layout
+    double T1[M], T2[M], T3[M], T4[M];
+    double v1[J], v2[J], v3[J], v4[J], v5[J];
+    double kq[J], kl[J];
+};
+
+struct Lane {
+    int r, c0, q;
+};
+template <int J> __device__ __forceinline__ Lane lane_of(int l64)
+{
+    constexpr int NQ = J / 2, LAST = J * NQ - 1;
+    const int l = l64 < LAST ? l64 : LAST;
+    Lane w;
+    w.r = l / NQ;
+    w.q = l - w.r * NQ;
+    w.c0 = 2 * w.q;
+    return w;
+}
+
+// Pairs travel as 16-byte LDS accesses (rows are J = even doubles long and every array of Lds starts on a 16-byte
+// boundary): ds_read_b128 / ds_write_b128 take a 16-bit immediate offset, where the compiler's ds_read2_b64 of two
+// neighbouring doubles reaches 2 KB only and pays a v_add for every other base address.
+__device__ __forceinline__ double2 ld2(const double *p) { return *(const double2 *)p; }
+__device__ __forceinline__ void st2(double *p, double a, double b) { *(double2 *)p = make_double2(a, b); }
+
+template <int J> __device__ __forceinline__ void row(const double *X, int r, double (&x)[J])
+{
+#pragma unroll
+    for (int k = 0; k < J; k += 2) {
+        const double2 v = ld2(X + r * J + k);
+        x[k] = v.x; x[k + 1] = v.y;
+    }
+}
+template <int J> __device__ __forceinline__ void col(const double *X, int r, double (&x)[J])
+{
+#pragma unroll
+    for (int k = 0; k < J; ++k) x[k] = X[k * J + r];
+}
+// o += x Y, columns c0 and c0 + 1
+template <int J> __device__ __forceinline__ void mm2(const double (&x)[J], const double *Y, int c0, double (&o)[2])
+{
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+        const double2 y = ld2(Y + k * J + c0);
+        o[0] = fma(x[k], y.x, o[0]);
+        o[1] = fma(x[k], y.y, o[1]);
+    }
+}
+// o += x Y^T, columns c0 and c0 + 1
+template <int J> __device__ __forceinline__ void mmT2(const double (&x)[J], const double *Y, int c0, double (&o)[2])
+{
+#pragma unroll
+    for (int k = 0; k < J; k += 2) {
+        const double2 ya = ld2(Y + c0 * J + k), yb = ld2(Y + (c0 + 1) * J + k);
+        o[0] = fma(x[k], ya.x, o[0]); o[0] = fma(x[k + 1], ya.y, o[0]);
+        o[1] = fma(x[k], yb.x, o[1]); o[1] = fma(x[k + 1], yb.y, o[1]);
+    }
+}
+template <int J> __device__ __forceinline__ void put2(double *X, int r, int c0, const double (&o)[2])
+{
+    st2(X + r * J + c0, o[0], o[1]);
+}
+template <int J> __device__ __forceinline__ double dot(const double (&x)[J], const double *v)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; k += 2) {
+        const double2 y = ld2(v + k);
+        s = fma(x[k], y.x, s); s = fma(x[k + 1], y.y, s);
+    }
+    return s;
+}
+template <int J> __device__ __forceinline__ double sum(const double *v)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; k += 2) {
+        const double2 y = ld2(v + k);
+        s += y.x; s += y.y;
+    }
+    return s;
+}
+// 1 / d to the last bit or so: v_rcp_f64 and two Newton steps (the IEEE division sequence is ~30 instructions)
+__device__ __forceinline__ double rcp2(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-d, x, 1.0);
+    return __builtin_fma(x, e, x);
+}
+
+// Columns (c0, c0 + 1) of row r of (I + X Y)^-1 by Gauss-Jordan without pivoting (I + C J is similar to a symmetric
+// positive definite matrix); xr = row r of X.  Both halves of the augmented matrix [G | Gi] live in registers, two
+// entries each per lane; at every step all lanes publish theirs (T2, T3: free during the elimination -- no
+// predicated store, no branch), read back the pivot, their row's entry of the pivot column and their column pair of
+// the pivot row, scale that row themselves and eliminate -- row p included, with the multiplier (pivot - 1), which
+// leaves it the scaled pivot row.  One LDS round trip per step.  1 / det = dm 2^de (single pivots may be negative,
+// only their product is a sign test).
+template <int J>
+__device__ __forceinline__ void inv_ipxy(Lds<J> &L, const double (&xr)[J], const double *Y, const Lane w, double (&gi)[2],
+                                         double &dm, int &de)
+{
+    double g[2];
+    g[0] = w.c0 == w.r ? 1.0 : 0.0;
+    g[1] = w.c0 + 1 == w.r ? 1.0 : 0.0;
+    gi[0] = g[0]; gi[1] = g[1];
+    mm2<J>(xr, Y, w.c0, g);
+    dm = 1.0; de = 0;
+    double *Gm = L.T2, *GIm = L.T3;
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+        put2<J>(Gm, w.r, w.c0, g);
+        put2<J>(GIm, w.r, w.c0, gi);
+        wsync();
+        const double pv = Gm[p * J + p];
+        const double fr = Gm[w.r * J + p];
+        const double2 pg = ld2(Gm + p * J + w.c0), pgi = ld2(GIm + p * J + w.c0);
+        const double ip = rcp2(pv);
+        const double fs = (w.r == p ? pv - 1.0 : fr) * ip;
+        g[0] = fma(-fs, pg.x, g[0]);
+        g[1] = fma(-fs, pg.y, g[1]);
+        gi[0] = fma(-fs, pgi.x, gi[0]);
+        gi[1] = fma(-fs, pgi.y, gi[1]);
+        const double pr = dm * ip;
+        dm = __builtin_amdgcn_frexp_mant(pr);
+        de += __builtin_amdgcn_frexp_exp(pr);
+    }
+}
+
+// running element (A1, b1, eta1, C1, J1) <- (running) o (A2, b2, eta2, C2, J2), the running one earlier in time
+// (the formulas of tpg::combine; J2 G^-1 A1 is taken as J2 (G^-1 A1), so that G^-T J2 is never formed).
+template <int J, bool KAPPA = false>
+__device__ __forceinline__ void combine(Lds<J> &L, const Lane w, double (&kap)[2], double &dm, int &de)
+{
+    const int r = w.r, c0 = w.c0;
+    double gi[2];
+    // w = b1 + C1 eta2 -> v1 ; t = eta2 - J2 b1 -> v2 ; u = C1 t needs t of every row: after the elimination
+    double c1r[J];
+    row<J>(L.C1, r, c1r);
+    {
+        double x[J];
+        L.v1[r] = L.b1[r] + dot<J>(c1r, L.eta2);
+        row<J>(L.J2, r, x);
+        L.v2[r] = L.eta2[r] - dot<J>(x, L.b1);
+    }
+    inv_ipxy<J>(L, c1r, L.J2, w, gi, dm, de);
+    put2<J>(L.T1, r, c0, gi);   // Gi -> T1
+    if (KAPPA) L.v5[r] = dot<J>(c1r, L.v2);   // C1 t (t of every row has been visible since the elimination's first step)
+    wsync();
+    // XA = Gi A1 -> T2 ; XC = Gi C1 -> T3 ; xb = Gi w -> v3 ; yeta = Gi^T t -> v4 ; quad = 1/2 t^T XC t, lin = 1/2 b1^T (eta2 + t)
+    {
+        double gr[J], o[2];
+        row<J>(L.T1, r, gr);
+        o[0] = 0.0; o[1] = 0.0;
+        mm2<J>(gr, L.A1, c0, o);
+        put2<J>(L.T2, r, c0, o);
+        o[0] = 0.0; o[1] = 0.0;
+        mm2<J>(gr, L.C1, c0, o);
+        put2<J>(L.T3, r, c0, o);
+        L.v3[r] = dot<J>(gr, L.v1);
+        if (KAPPA) {
+            const double ct = dot<J>(gr, L.v5);   // (XC t)_r = Gi_r . (C1 t)
+            const double tr = L.v2[r];
+            L.kq[r] = 0.5 * tr * ct;
+            L.kl[r] = 0.5 * L.b1[r] * (L.eta2[r] + tr);
+        }
+        double gc[J];
+        col<J>(L.T1, r, gc);
+        L.v4[r] = dot<J>(gc, L.v2);
+    }
+    wsync();
+    // Z = J2 XA -> T1 ; A = A2 XA ; Y = A2 XC -> T4 ; b = b2 + A2 xb
+    double a_new[2], b_new;
+    {
+        double x[J], o[2];
+        row<J>(L.J2, r, x);
+        o[0] = 0.0; o[1] = 0.0;
+        mm2<J>(x, L.T2, c0, o);
+        row<J>(L.A2, r, x);
+        a_new[0] = 0.0; a_new[1] = 0.0;
+        mm2<J>(x, L.T2, c0, a_new);
+        double y[2] = {0.0, 0.0};
+        mm2<J>(x, L.T3, c0, y);
+        b_new = L.b2[r] + dot<J>(x, L.v3);
+        if (KAPPA) { kap[0] = sum<J>(L.kl); kap[1] = sum<J>(L.kq); }
+        put2<J>(L.T1, r, c0, o);    // (every lane has read its row and column of Gi in the phase before)
+        put2<J>(L.T4, r, c0, y);
+    }
+    wsync();
+    // eta = eta1 + A1^T yeta ; J = J1 + A1^T Z ; C = C2 + Y A2^T
+    double eta_new, j_new[2], c_new[2];
+    {
+        double x[J];
+        col<J>(L.A1, r, x);
+        eta_new = L.eta1[r] + dot<J>(x, L.v4);
+        { const double2 v = ld2(L.J1 + r * J + c0); j_new[0] = v.x; j_new[1] = v.y; }
+        mm2<J>(x, L.T1, c0, j_new);
+        row<J>(L.T4, r, x);
+        { const double2 v = ld2(L.C2 + r * J + c0); c_new[0] = v.x; c_new[1] = v.y; }
+        mmT2<J>(x, L.A2, c0, c_new);
+    }
+    wsync();                       // all reads of the old running element are done
+    put2<J>(L.A1, r, c0, a_new);
+    put2<J>(L.C1, r, c0, c_new);
+    put2<J>(L.J1, r, c0, j_new);
+    L.b1[r] = b_new; L.eta1[r] = eta_new;
+    wsync();
+}
+
+// state (m in b1, P in C1) <- element (A2, b2, eta2, C2, J2) applied to it (tpg::apply): CORR also returns the element's
+// chunk likelihood given that state relative to kappa; UPDATE = false: only that number.
+template <int J, bool CORR = false, bool UPDATE = true> __device__ __forceinline__ double apply(Lds<J> &L, const Lane w)
+{
+    const int r = w.r, c0 = w.c0;
+    double gi[2], dm;
+    int de;
+    double t = 0.0, mr = 0.0, er = 0.0;
+    double c1r[J];
+    row<J>(L.C1, r, c1r);
+    L.v1[r] = L.b1[r] + dot<J>(c1r, L.eta2);
+    if (CORR) {
+        double x[J];
+        row<J>(L.J2, r, x);
+        mr = L.b1[r]; er = L.eta2[r];
+        t = er - dot<J>(x, L.b1);
+        L.v2[r] = t;
+    }
+    inv_ipxy<J>(L, c1r, L.J2, w, gi, dm, de);
+    put2<J>(L.T1, r, c0, gi);
+    if (CORR) L.v5[r] = dot<J>(c1r, L.v2);
+    wsync();
+    double corr = 0.0;
+    {
+        double gr[J], o[2] = {0.0, 0.0};
+        row<J>(L.T1, r, gr);
+        mm2<J>(gr, L.C1, c0, o);
+        put2<J>(L.T3, r, c0, o);
+        L.v3[r] = dot<J>(gr, L.v1);
+        if (CORR) {
+            const double ct = dot<J>(gr, L.v5);
+            // this row's share of eta^T m - 1/2 m^T J m + 1/2 t^T X t   (J m = eta - t)
+            L.kq[r] = fma(er, mr, 0.5 * fma(t, ct, -mr * (er - t)));
+            wsync();
+            const double s = sum<J>(L.kq);
+            corr = dm > 0.0 ? s + 0.5 * (log(dm) + (double)de * 0.69314718055994530942) : __builtin_nan("");
+        }
+    }
+    if (!UPDATE) { wsync(); return corr; }
+    wsync();
+    double b_new;
+    {
+        double x[J], y[2] = {0.0, 0.0};
+        row<J>(L.A2, r, x);
+        mm2<J>(x, L.T3, c0, y);
+        b_new = L.b2[r] + dot<J>(x, L.v3);
+        put2<J>(L.T4, r, c0, y);
+    }
+    wsync();
+    double c_new[2];
+    {
+        double x[J];
+        row<J>(L.T4, r, x);
+        { const double2 v = ld2(L.C2 + r * J + c0); c_new[0] = v.x; c_new[1] = v.y; }
+        mmT2<J>(x, L.A2, c0, c_new);
+    }
+    wsync();
+    put2<J>(L.C1, r, c0, c_new);
+    L.b1[r] = b_new;
+    wsync();
+    return corr;
+}
+
+// copy n doubles global <-> LDS by the 64 lanes of the wave
+__device__ __forceinline__ void gcopy(double *dst, const double *src, int n, int l64)
+{
+    for (int i = l64; i < n; i += 64) dst[i] = src[i];
+}
+
+// The next element travels global memory -> registers (issued before the current combination, whose arithmetic
+// hides the latency) -> LDS (after it): MTG_TPB_ELEM(J) / 64 doubles per lane.
+template <int J> struct Pre { double v[(MTG_TPB_ELEM(J) + 63) / 64]; };
+template <int J> __device__ __forceinline__ void fetch(Pre<J> &p, const double *e, int l64)
+{
+    constexpr int N = MTG_TPB_ELEM(J), Q = (N + 63) / 64;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = l64 + 64 * q;
+        p.v[q] = e[i < N ? i : N - 1];
+    }
+}
+template <int J> __device__ __forceinline__ void put_second(Lds<J> &L, const Pre<J> &p, int l64)
+{
+    constexpr int N = MTG_TPB_ELEM(J), Q = (N + 63) / 64;
+    double *dst = L.A2;  // A2 | b2 | eta2 | C2 | J2 are contiguous and in the global order
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = l64 + 64 * q;
+        if (i < N) dst[i] = p.v[q];
+    }
+}
+template <int J> __device__ __forceinline__ void load_first(Lds<J> &L, const double *e, int l64)
+{
+    constexpr int M = J * J;
+    gcopy(L.A1, e, M, l64);
+    gcopy(L.b1, e + M, J, l64);
+    gcopy(L.eta1, e + M + J, J, l64);
+    gcopy(L.C1, e + M + 2 * J, M, l64);
+    gcopy(L.J1, e + 2 * M + 2 * J, M, l64);
+}
+template <int J> __device__ __forceinline__ void store_first(const Lds<J> &L, double *e, int l64)
+{
+    constexpr int M = J * J;
+    gcopy(e, L.A1, M, l64);
+    gcopy(e + M, L.b1, J, l64);
+    gcopy(e + M + J, L.eta1, J, l64);
+    gcopy(e + M + 2 * J, L.C1, M, l64);
+    gcopy(e + 2 * M + 2 * J, L.J1, M, l64);
+}
+
+}  // namespace tpw
 #endif  // __HIPCC__

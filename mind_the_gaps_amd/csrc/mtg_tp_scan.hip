@@ -9,12 +9,12 @@
 
 namespace {
 
-constexpr int GROUPS = 4;  // lane groups per workgroup (one wave)
+constexpr int GROUPS = 1;  // one wave = one workgroup = one group of elements (namespace tpw: a wave per combination)
 
 // group -> (evaluation, group index inside the evaluation); false = nothing to do
 __device__ __forceinline__ bool tpb_group(const MtgSolveArgs &a, int groups_per_eval, int64_t &ev, int &k)
 {
-    const int64_t gid = (int64_t)blockIdx.x * GROUPS + (threadIdx.x >> 4);
+    const int64_t gid = (int64_t)blockIdx.x;
     const int64_t i = gid / groups_per_eval;
     k = (int)(gid % groups_per_eval);
     const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
@@ -29,37 +29,36 @@ __device__ __forceinline__ bool tpb_group(const MtgSolveArgs &a, int groups_per_
 // array, whose fourth entry is not a magnitude) and every group is reduced; otherwise only prefixes are ever
 // applied and the last group's total is not needed.
 template <int J, bool KAPPA>
-__global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_LANES */, 1) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
+__global__ void __launch_bounds__(64, KAPPA ? 4 : 3) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
                                                                                            double *out, int n_in, int g,
                                                                                            const double *rec_in, double *rec_out,
                                                                                            int level0)
 {
-    __shared__ tpg::Lds<J> lds[GROUPS];
+    __shared__ tpw::Lds<J> L;
     const int gpe = n_in / g;
     int64_t ev;
     int k;
     if (!tpb_group(a, gpe, ev, k)) return;
     if (!KAPPA && k == gpe - 1) return;
-    tpg::Lds<J> &L = lds[threadIdx.x >> 4];
-    const int l16 = threadIdx.x & 15;
-    const int r = l16 < J ? l16 : J - 1;
+    const int l64 = threadIdx.x;
+    const tpw::Lane w = tpw::lane_of<J>(l64);
     const int64_t first = ev * n_in + (int64_t)k * g;
     const double *e = in + first * MTG_TPB_ELEM(J);
-    tpg::load_first<J>(L, e, l16);
-    tpg::Pre<J> pre;
-    tpg::fetch<J>(pre, e + MTG_TPB_ELEM(J), l16);
+    tpw::load_first<J>(L, e, l64);
+    tpw::Pre<J> pre;
+    tpw::fetch<J>(pre, e + MTG_TPB_ELEM(J), l64);
     // the group's record: (dot, mag) as they come; the determinants as a product (pm 2^pe = prod 1 / det G)
     double dot = 0.0, mag = 0.0, pm = 1.0;
     int pe = 0;
     bool positive = true;
 #pragma unroll 1
     for (int i = 1; i < g; ++i) {
-        tpg::put_second<J>(L, pre, l16);
-        if (i + 1 < g) tpg::fetch<J>(pre, e + (int64_t)(i + 1) * MTG_TPB_ELEM(J), l16);
-        tpg::wsync();
+        tpw::put_second<J>(L, pre, l64);
+        if (i + 1 < g) tpw::fetch<J>(pre, e + (int64_t)(i + 1) * MTG_TPB_ELEM(J), l64);
+        tpw::wsync();
         double kap[2], dm;
         int de;
-        tpg::combine<J, KAPPA>(L, r, kap, dm, de);
+        tpw::combine<J, KAPPA>(L, w, kap, dm, de);
         if (KAPPA) {
             dot -= 2.0 * (kap[0] + kap[1]);
             mag += fabs(kap[0]) + fabs(kap[1]);
@@ -69,8 +68,8 @@ __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_LANES */, 1) mtg_tpb_
             pe += de + __builtin_amdgcn_frexp_exp(pr);
         }
     }
-    tpg::store_first<J>(L, out + (ev * gpe + k) * MTG_TPB_ELEM(J), l16);
-    if (KAPPA && l16 == 0) {
+    tpw::store_first<J>(L, out + (ev * gpe + k) * MTG_TPB_ELEM(J), l64);
+    if (KAPPA && l64 == 0) {
         double ld = positive ? -(log(pm) + (double)pe * 0.69314718055994530942) : __builtin_nan("");
         double dmin = positive ? INFINITY : -1.0;
         for (int i = 0; i < g; ++i) {
@@ -85,16 +84,17 @@ __global__ void __launch_bounds__(64 /* = GROUPS * MTG_TPB_LANES */, 1) mtg_tpb_
 // The filtered state after sample 0 (update of the stationary prior) into (b1 | C1) of the group's LDS region, that
 // sample's terms of the likelihood into head[ev]; false: the evaluation's light curve index is out of range.
 template <int J>
-__device__ __forceinline__ bool tpb_head_state(const MtgSolveArgs &a, int64_t ev, tpg::Lds<J> &L, int l16, int r, double *head)
+__device__ __forceinline__ bool tpb_head_state(const MtgSolveArgs &a, int64_t ev, tpw::Lds<J> &L, int l64, const tpw::Lane w, double *head)
 {
     constexpr int M = J * J;
     const int64_t lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
     if (lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes) return false;
     const int nover = a.sig ? a.sig[ev] : 0, nr = a.tp_nr0 + 2 * nover, nc = a.tp_nc0 - nover;  // structure of this evaluation
-    if (l16 == 0) {  // stationary covariance P_inf and P_inf h, rank by rank
+    for (int i = l64; i < M; i += 64) L.C1[i] = 0.0;
+    tpw::wsync();
+    if (l64 == 0) {  // stationary covariance P_inf and P_inf h, rank by rank
         const double *cf = a.coef + ev;
         const int64_t cs = a.cstride;
-        for (int i = 0; i < M; ++i) L.C1[i] = 0.0;
         double D0 = 0.0;
         for (int j = 0; j < nr; ++j) {
             const double aj = cf[a.lay.ar(j) * cs];
@@ -114,17 +114,18 @@ __device__ __forceinline__ bool tpb_head_state(const MtgSolveArgs &a, int64_t ev
         double *h = head + ev * 4;
         h[0] = z0 * z0 / D0; h[1] = log(D0); h[2] = D0;
     }
-    tpg::wsync();
+    tpw::wsync();
     {
-        const double chr = L.v1[r];
-        double prow[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) prow[j] = L.C1[r * J + j] - chr * L.v1[j] * L.v2[1];
-        tpg::wsync();   // lanes J .. 15 duplicate row J - 1: everybody reads before anybody writes
-        L.b1[r] = chr * L.v2[0];
-        tpg::put<J>(L.C1, r, prow);
+        const double chr = L.v1[w.r];
+        double prow[2];
+        prow[0] = L.C1[w.r * J + w.c0] - chr * L.v1[w.c0] * L.v2[1];
+        prow[1] = L.C1[w.r * J + w.c0 + 1] - chr * L.v1[w.c0 + 1] * L.v2[1];
+        const double m = chr * L.v2[0];
+        tpw::wsync();   // (lanes beyond the last pair repeat it: everybody reads before anybody writes)
+        L.b1[w.r] = m;
+        tpw::put2<J>(L.C1, w.r, w.c0, prow);
     }
-    tpg::wsync();
+    tpw::wsync();
     return true;
 }
 
@@ -139,32 +140,31 @@ template <int J>
 __global__ void __launch_bounds__(64, 2) mtg_tpb_top_direct_kernel(MtgSolveArgs a, const double *elems, const double *recs,
                                                                 double *head, int n, int *redo_list, int *redo_count)
 {
-    __shared__ tpg::Lds<J> lds[GROUPS];
+    __shared__ tpw::Lds<J> L;
     int64_t ev;
     int k;
     if (!tpb_group(a, 1, ev, k)) return;
-    tpg::Lds<J> &L = lds[threadIdx.x >> 4];
-    const int l16 = threadIdx.x & 15;
-    const int r = l16 < J ? l16 : J - 1;
-    if (!tpb_head_state<J>(a, ev, L, l16, r, head)) {
-        if (l16 == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
+    const int l64 = threadIdx.x;
+    const tpw::Lane w = tpw::lane_of<J>(l64);
+    if (!tpb_head_state<J>(a, ev, L, l64, w, head)) {
+        if (l64 == 0) { a.out[ev] = -INFINITY; a.status[ev] = MTG_ST_NONFINITE; }
         return;
     }
     const int64_t first = ev * n;
-    tpg::Pre<J> pre;
-    tpg::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l16);
+    tpw::Pre<J> pre;
+    tpw::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l64);
     double corr = 0.0, mag = 0.0, dot = 0.0, ld = 0.0, dmin = INFINITY;
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
-        tpg::put_second<J>(L, pre, l16);
-        if (i + 1 < n) tpg::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l16);
-        tpg::wsync();
-        const double c = i + 1 < n ? tpg::apply<J, true, true>(L, r) : tpg::apply<J, true, false>(L, r);
+        tpw::put_second<J>(L, pre, l64);
+        if (i + 1 < n) tpw::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l64);
+        tpw::wsync();
+        const double c = i + 1 < n ? tpw::apply<J, true, true>(L, w) : tpw::apply<J, true, false>(L, w);
         const double *q = recs + (first + i) * 4;
         corr += c; mag += fabs(c) + q[3];
         dot += q[0]; ld += q[1]; dmin = fmin(dmin, q[2]);
     }
-    if (l16 == 0) {
+    if (l64 == 0) {
         const double *h = head + ev * 4;
         mag += 0.5 * h[0];
         dot += h[0]; ld += h[1]; dmin = fmin(dmin, h[2]);
@@ -193,31 +193,30 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, con
                                                           double *states, double *head, int n, int gsize)
 {
     constexpr int M = J * J;
-    __shared__ tpg::Lds<J> lds[GROUPS];
+    __shared__ tpw::Lds<J> L;
     const int gpe = n / gsize;
     int64_t ev;
     int k;
     if (!tpb_group(a, gpe, ev, k)) return;
-    tpg::Lds<J> &L = lds[threadIdx.x >> 4];
-    const int l16 = threadIdx.x & 15;
-    const int r = l16 < J ? l16 : J - 1;
+    const int l64 = threadIdx.x;
+    const tpw::Lane w = tpw::lane_of<J>(l64);
     if (up) {
-        tpg::gcopy(L.b1, up + (ev * gpe + k) * MTG_TPB_STATE(J), J + M, l16);  // b1 | C1 are contiguous
-        tpg::wsync();
-    } else if (!tpb_head_state<J>(a, ev, L, l16, r, head)) {
+        tpw::gcopy(L.b1, up + (ev * gpe + k) * MTG_TPB_STATE(J), J + M, l64);  // b1 | C1 are contiguous
+        tpw::wsync();
+    } else if (!tpb_head_state<J>(a, ev, L, l64, w, head)) {
         return;
     }
     const int64_t first = ev * n + (int64_t)k * gsize;
-    tpg::Pre<J> pre;
-    tpg::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l16);
+    tpw::Pre<J> pre;
+    tpw::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l64);
 #pragma unroll 1
     for (int i = 0; i < gsize; ++i) {
-        tpg::gcopy(states + (first + i) * MTG_TPB_STATE(J), L.b1, J + M, l16);
+        tpw::gcopy(states + (first + i) * MTG_TPB_STATE(J), L.b1, J + M, l64);
         if (i + 1 == gsize) break;
-        tpg::put_second<J>(L, pre, l16);
-        if (i + 1 < gsize) tpg::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l16);
-        tpg::wsync();
-        tpg::apply<J>(L, r);
+        tpw::put_second<J>(L, pre, l64);
+        if (i + 1 < gsize) tpw::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l64);
+        tpw::wsync();
+        tpw::apply<J>(L, w);
     }
 }
 

@@ -40,26 +40,16 @@ class GPModelling:
 
     def __init__(self, lightcurve: GappyLightcurve, kernel, mean_model: str = None, device: int = 0,
                  quiet: bool = False):
-        """
-        Parameters
-        ----------
-        lightcurve
-            An instance of a lightcurve
-        kernel: mind_the_gaps_amd.terms.Term
-            The model to be fitted to the lightcurve
-        mean_model
-            Mean model. If given it will be fitted, otherwise assumed the mean value.
-            Available implementations are Constant, Linear and Gaussian.
-        device
-            GPU ordinal (new, optional).
-        quiet
-            Return -inf instead of raising ``LinAlgError`` for a non positive-definite
-            covariance (new, optional; the reference raises, gpmodelling.py:152).
-        """
+        """GP of ``kernel`` (a ``mind_the_gaps_amd.terms.Term``) on ``lightcurve``, factorised once with
+        ``yerr = dy + 1e-12`` as the reference does (gpmodelling.py:54).
+
+        ``mean_model``: None keeps the mean frozen at the light curve's average; "constant", "linear" or
+        "gaussian" name a mean that is fitted along with the kernel (the table in ``_build_mean_model``).
+        New and optional: ``device`` = GPU ordinal; ``quiet`` = a covariance that is not positive definite gives
+        -inf instead of ``LinAlgError`` (the reference raises, gpmodelling.py:152)."""
         self._lightcurve = lightcurve
         meanmodel, fit_mean = self._build_mean_model(mean_model)
         self.gp = GP(kernel, mean=meanmodel, fit_mean=fit_mean, device=device)
-        # gpmodelling.py:54 -- celerite squares yerr = dy + 1e-12
         self.gp.compute(self._lightcurve.times, np.asarray(self._lightcurve.dy, dtype=np.float64) + 1e-12)
         self.initial_params = self.gp.get_parameter_vector()
         self._ndim = len(self.initial_params)
@@ -70,31 +60,38 @@ class GPModelling:
         self._fit_evaluations = 1   # fit() resets it: only the first evaluation of a fit may raise LinAlgError
         self._y = np.asarray(self._lightcurve.y, dtype=np.float64)
 
+    # mean kind -> (model factory taking the light curve, fitted?).  The contract of gpmodelling.py:62-124: without a
+    # name the mean is a ConstantModel frozen at the light curve's average, boxed by the data's range; a name selects a
+    # fitted mean -- "constant" the same model, "linear" LinearModel(slope 0, intercept 1.5) without bounds (the
+    # reference works slope estimates out and then does not use them), "gaussian" a bump centred on the middle epoch,
+    # half the duration wide.  The reference hands GaussianModel three values for its four parameters, so that branch
+    # raises ValueError there and here -- kept, not fixed.
+    @staticmethod
+    def _constant_mean(lc):
+        return ConstantModel(lc.mean, bounds=[(np.min(lc.y), np.max(lc.y))])
+
+    @staticmethod
+    def _linear_mean(lc):
+        return LinearModel(0, 1.5, bounds=[(-np.inf, np.inf)] * 2)
+
+    @staticmethod
+    def _gaussian_mean(lc):
+        span, top, root2pi = lc.duration, np.max(lc.y), np.sqrt(2 * np.pi)
+        width = span / 2
+        return GaussianModel(lc.times[len(lc.times) // 2], width, (top - np.min(lc.y)) * root2pi * width,
+                             bounds=[(lc.times[0], lc.times[-1]), (0, span), (top * root2pi * span, 50 * top * root2pi * span)])
+
+    _MEAN_KINDS = {None: ("_constant_mean", False), "constant": ("_constant_mean", True),
+                   "linear": ("_linear_mean", True), "gaussian": ("_gaussian_mean", True)}
+
     def _build_mean_model(self, meanmodel: str = None):
-        """Mean model from the light-curve properties (gpmodelling.py:62-124)."""
-        maxy = np.max(self._lightcurve.y)
-        if meanmodel is None:
-            meanmodel = ConstantModel(self._lightcurve.mean, bounds=[(np.min(self._lightcurve.y), maxy)])
-            return meanmodel, False
-        elif meanmodel.lower() not in GPModelling.meanmodels:
+        """(mean model, fit_mean) for a mean kind (see the table above)."""
+        kind = meanmodel if meanmodel is None else meanmodel.lower()
+        if kind not in self._MEAN_KINDS:
             raise ValueError("Input mean model %s not implemented! Only \n %s \n are available"
                              % (meanmodel, "\t".join(GPModelling.meanmodels)))
-        elif meanmodel.lower() == "constant":
-            meanmodel = ConstantModel(self._lightcurve.mean, bounds=[(np.min(self._lightcurve.y), maxy)])
-            return meanmodel, True
-        elif meanmodel.lower() == "linear":
-            meanmodel = LinearModel(0, 1.5, bounds=[(-np.inf, np.inf), (-np.inf, np.inf)])
-        elif meanmodel.lower() == "gaussian":
-            # as in the reference this builds a 4-parameter model from 3 values and
-            # raises ValueError (SURVEY.md Appendix C.2)
-            sigma_guess = (self._lightcurve.duration) / 2
-            amplitude_guess = (maxy - np.min(self._lightcurve.y)) * np.sqrt(2 * np.pi) * sigma_guess
-            mean_guess = self._lightcurve.times[len(self._lightcurve.times) // 2]
-            norm = maxy * np.sqrt(2 * np.pi) * self._lightcurve.duration
-            meanmodel = GaussianModel(mean_guess, sigma_guess, amplitude_guess,
-                                      bounds=[(self._lightcurve.times[0], self._lightcurve.times[-1]),
-                                              (0, self._lightcurve.duration), (norm, 50 * norm)])
-        return meanmodel, True
+        factory, fitted = self._MEAN_KINDS[kind]
+        return getattr(self, factory)(self._lightcurve), fitted
 
     # -- the hot path --------------------------------------------------------------
     def _batch(self, params, add_prior):
