@@ -439,7 +439,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     if (small_ok && Jmodel > 6) {  // rank 10: every structure in one sequence of launches (mtg_tp_big.h)
         sa.list = nullptr;
         sa.count_ptr = nullptr;
-        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tpb_compose2_kernel (+ mtg_tpb_reduce_kernel<10>, C = %d)", sa.tp_chunks);
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "%s (+ mtg_tpb_reduce_kernel<10>, C = %d)",
+                 mtg_tpb_compose_waves() == 2 ? "mtg_tpb_compose2_kernel" : "mtg_tpb_compose4_kernel", sa.tp_chunks);
         mtg_launch_tp_big(sa, B, s);
     } else if (fused) {  // every signature in one launch
         sa.list = bank_lists(ctx);

@@ -407,6 +407,404 @@ __device__ __forceinline__ void tpb2_compose_eval(const MtgSolveArgs &a, int64_t
     else tpb2_filter<NR, NC>(a, M, jitter, slope, icpt, lc, ring, slot, parts + (ev * C + c) * 4, lo, hi, per);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Composition by FOUR waves per 64 chunks (mtg_tpb_compose4_kernel), round 3.
+//
+// What the two-wave kernel above pays: its waves hold 200 / 260 VGPRs of state plus temporaries, i.e. 434 registers
+// with the accumulation half, ONE wave per SIMD -- and a lone wave is handed one instruction of ANY kind per issue
+// slot: the ~290 v_accvgpr copies, ~150 LDS instructions and ~60 scalar ones of an interval cost as much as its
+// 991 FP64 ones (1498 slots, 3400 cycles per interval, profiles/r02_tp_pmc.txt).  Here the element of a chunk is
+// shared by the same lane of FOUR waves, each below 256 registers, two workgroups = eight waves per CU, two waves
+// per SIMD: nothing lives in accumulation registers and one wave's LDS / scalar / wait instructions issue under the
+// other's arithmetic.  Roles (wave = threadIdx.x >> 6):
+//   0 "columns, low"   columns 0..4 of A, eta[0..4], the transition of the first terms
+//   1 "columns, high"  columns 5..9 of A, eta[5..9], the transition of the other terms, the mean b and the residual z
+//   2, 3 "filter"      the symmetric matrices Dv and Jm, cut block by block of the term structure into two halves of
+//                      equal work (tpb_owner): prediction, gain and update of the own blocks.  The gain needs
+//                      (P_inf + Dv) h, a sum over all blocks: each wave sums its own, they exchange the partial sums.
+// One workgroup barrier per tick; a step travels through the waves in five ticks (s = step, t = tick):
+//   t = s      waves 0, 1   transition F(s)                                        -> ring F[s & 3]
+//   t = s + 1  waves 2, 3   part A: predict own blocks with F(s), partial (Dv h)    -> ring part[wave][s & 1]
+//   t = s + 2  waves 2, 3   part B: sum the partials, pivot D, 1 / D, update own blocks;  wave 2 -> ring ch[s & 1]
+//   t = s + 3  waves 0, 1   A <- (I - K h) F A for the own columns, g = h F A      -> ring g[s & 1];  wave 1: b, z,
+//                           z / D -> ring zi[s & 1], eta[5..9]
+//   t = s + 4  waves 2, 3   Jm += g g^T / D on the own blocks;  wave 0: eta[0..4]
+// A workgroup is EIGHT waves: two such quartets (two blocks of 64 chunks, each with its own rings), the second with
+// its roles rotated by two.  Waves w and w + 4 of a workgroup share a SIMD (scripts/micro/simd_probe.hip), so every
+// SIMD runs one "columns" and one "filter" wave: whatever the imbalance between the two kinds, the four SIMDs carry the
+// same load, and a wave deep in LDS traffic shares its SIMD with one deep in arithmetic.  (Two four-wave workgroups
+// per CU pair their waves at random, role for role as often as not: 2.79 ms against 2.84 for the two-wave kernel.)
+// Every hand-over crosses exactly one barrier and part A of step s + 1 follows part B of step s in the same
+// tick of the same wave (the only true recurrence, Dv, never waits for another wave inside a tick).  Chunks shorter
+// than `per` steps run the rest as no-ops exactly as above (dx = 0, measurement variance 1e300).
+// (measurements only: -DMTG_TPB4_NOSYNC times the arithmetic without its barriers -- the results are then wrong)
+#ifdef MTG_TPB4_NOSYNC
+#define TPB4_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TPB4_SYNC() __syncthreads()
+#endif
+template <int J> struct TpbRing4 {
+    double F[4][J][64];
+    double ch[2][J + 1][64];
+    double g[2][J][64];
+    double zi[2][64];
+    double part[2][2][J][64];
+};
+
+// term of state row i, first row of term a, rows of term a
+template <int NR> __host__ __device__ constexpr int tpb_term(int i) { return i < NR ? i : NR + (i - NR) / 2; }
+template <int NR> __host__ __device__ constexpr int tpb_row0(int a) { return a < NR ? a : NR + 2 * (a - NR); }
+// which filter wave owns block (a, b), a >= b, of the symmetric matrices: alternating along the triangle -- within 6 %
+// of an even split of the work for all six structures
+__host__ __device__ constexpr int tpb_owner(int a, int b) { return (a * (a + 1) / 2 + b) & 1; }
+template <int NR> __host__ __device__ constexpr bool tpb_owns(int f, int i, int j)
+{
+    return tpb_owner(tpb_term<NR>(i > j ? i : j), tpb_term<NR>(i > j ? j : i)) == f;
+}
+// terms whose transition wave 0 computes (the others: wave 1, which also has b and z): real ~14 instructions, complex ~37
+template <int NR, int NC> __host__ __device__ constexpr int tpb_trans_split()
+{
+    const int total = 14 * NR + 37 * NC, target = (total + 30) / 2;
+    int n = 0, c = 0;
+    while (n < NR + NC && c < target) { c += n < NR ? 14 : 37; ++n; }
+    return n;
+}
+
+// transition of terms [T0, T1) of one step straight into a ring slot (tpb_transition, term by term)
+template <int NR, int NC, int T0, int T1, class Tab>
+__device__ __forceinline__ void tpb_transition_part(const TpModel<NR, NC> &M, double dx, double (*F)[64], int lane, const Tab *tab,
+                                                    bool fast)
+{
+    constexpr int NTP = T1 - T0 > 0 ? T1 - T0 : 1;
+    constexpr int C0 = T0 > NR ? T0 - NR : 0, C1 = T1 > NR ? T1 - NR : 0, NCP = C1 - C0 > 0 ? C1 - C0 : 1;
+    const double dxs = dx * MTG_EXP_CSCALE;
+    const double magic = 0x1.8p+55;
+    double er[NTP], et[NTP];
+    int ek[NTP];
+#pragma unroll
+    for (int i = T0; i < T1; ++i) {
+        const double c = i < NR ? M.cr[i < NR ? i : 0] : M.cc[i < NR ? 0 : i - NR];
+        const double w = __builtin_fma(-c, dxs, magic);
+        const double q8 = w - magic;
+        const int i8 = (int)q8;
+        et[i - T0] = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+        er[i - T0] = __builtin_fma(-c, dx, q8 * -MTG_EXP_C1);
+        ek[i - T0] = i8 >> (3 + MTG_EXP_BITS);
+    }
+    double pr[NCP];
+    double2 pj[NCP];
+#pragma unroll
+    for (int k = C0; k < C1; ++k) {
+        double dk = M.dc[k], xk = dx;
+        if (!fast) {  // uniform over the workgroup (one evaluation)
+            const double x = dk * dx, xl = fma(dk, dx, -x);
+            const double n = rint(x * 0x1.45f306dc9c883p-3);
+            const double r = fma(-n, 0x1.921fb54442d18p+2, x);
+            xk = fma(-n, 0x1.1a62633145c07p-52, r) + xl;
+            dk = 1.0;
+        }
+        const double tm = 0x1.8p+56;
+        const double x = dk * xk;
+        const double w = __builtin_fma(x, 0x1.45f306dc9c883p+1 * MTG_TRIG_N, tm);
+        const double md16 = w - tm;
+        pr[k - C0] = __builtin_fma(md16, -(0x1.921fb54442d18p-2 / MTG_TRIG_N), x);
+        pj[k - C0] = *(const double2 *)((const char *)tab->cis + ((__double2loint(w) << 4) & ((MTG_TRIG_N - 1) * 16)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = T0; i < T1; ++i) {
+        const double p = mtg_expm1_small(er[i - T0]);
+        const double e = __builtin_ldexp(__builtin_fma(et[i - T0], p, et[i - T0]), ek[i - T0]);
+        if (i < NR) {
+            F[i][lane] = e;
+        } else {
+            const int k = i < NR ? 0 : i - NR;
+            double sn, cs;
+            mtg_sincos_small(pr[k - C0], &sn, &cs);
+            const double2 t = pj[k - C0];
+            const double s = __builtin_fma(t.x, sn, t.y * cs), c = __builtin_fma(-t.y, sn, t.x * cs);
+            F[NR + 2 * k][lane] = e * c;
+            F[NR + 2 * k + 1][lane] = e * s;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NR, int NC> __device__ __forceinline__ void tpb4_read_F(const double (*F)[64], int lane, TpTrans<NR, NC> &T)
+{
+#pragma unroll
+    for (int j = 0; j < NR; ++j) T.phi[j] = F[j][lane];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { T.ec[q] = F[NR + 2 * q][lane]; T.es[q] = F[NR + 2 * q + 1][lane]; }
+}
+
+// waves 0 and 1: HALF = 0 / 1
+template <int NR, int NC, int HALF, class Tab>
+__device__ __forceinline__ void tpb4_columns(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double slope, double icpt, int64_t lc,
+                                             const Tab *tab, bool fast, TpbRing4<NR + 2 * NC> &ring, double *slot, double *part,
+                                             uint32_t lo, uint32_t hi, uint32_t per)
+{
+    constexpr int J = NR + 2 * NC, H = J / 2, C0 = HALF * H, NT = NR + NC, NT0 = tpb_trans_split<NR, NC>();
+    constexpr int T0 = HALF ? NT0 : 0, T1 = HALF ? NT : NT0;
+    const int lane = threadIdx.x & 63;
+    const double2 *dxt = a.dxt + lc * a.t_stride, *yv = a.yv + lc * a.N;
+    double A[J][H];   // columns C0 .. C0 + H - 1
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < H; ++j) A[i][j] = i == C0 + j ? 1.0 : 0.0;
+    double eta[H], gk[H], b[J];
+#pragma unroll
+    for (int j = 0; j < H; ++j) { eta[j] = 0.0; gk[j] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < J; ++i) b[i] = 0.0;
+    double dot = 0.0;
+    const uint32_t last = ((uint32_t)a.N - 1u) * 16u;
+    // sample of the transition (step t) and, wave 1, of the residual (step t - 3), each with its prefetch
+    uint32_t off = lo * 16u, offz = lo * 16u;
+    double dxn = tpb_sample(dxt, off < last ? off : last).x;
+    double2 yn = tpb_sample(yv, offz < last ? offz : last);
+    double tn = tpb_sample(dxt, offz < last ? offz : last).y;
+    for (uint32_t t = 0; t < per + 4u; ++t) {
+        if (t < per) {
+            const double dx = off < hi * 16u ? dxn : 0.0;
+            off += 16u;
+            dxn = tpb_sample(dxt, off < last ? off : last).x;
+            tpb_transition_part<NR, NC, T0, T1>(M, dx, ring.F[t & 3u], lane, tab, fast);
+        }
+        if (HALF == 0 && t >= 4u && t < per + 4u) {   // eta of step t - 4 with last tick's g
+            const double zi = ring.zi[(t - 4u) & 1u][lane];
+#pragma unroll
+            for (int j = 0; j < H; ++j) eta[j] = fma(gk[j], zi, eta[j]);
+        }
+        if (t >= 3u && t < per + 3u) {
+            const uint32_t s = t - 3u;
+            TpTrans<NR, NC> T;
+            tpb4_read_F<NR, NC>(ring.F[s & 3u], lane, T);
+            const double(*G)[64] = ring.ch[s & 1u];
+            double ch[J];
+#pragma unroll
+            for (int i = 0; i < J; ++i) ch[i] = G[i][lane];
+            const double inv = G[J][lane];
+            double zi = 0.0;
+            if (HALF == 1) {   // mean of the filter-from-zero and residual of step s
+                const bool valid = offz < hi * 16u;
+                const double r = valid ? fma(-slope, tn, yn.x - icpt) : 0.0;
+                offz += 16u;
+                yn = tpb_sample(yv, offz < last ? offz : last);
+                tn = tpb_sample(dxt, offz < last ? offz : last).y;
+                tp_apply_F<NR, NC>(T, b);
+                const double z = r - tp_h_dot<NR, NC>(b);
+                zi = z * inv;
+                ring.zi[s & 1u][lane] = zi;
+                dot = fma(z, zi, dot);
+#pragma unroll
+                for (int i = 0; i < J; ++i) b[i] = fma(ch[i], zi, b[i]);
+            }
+            double(*gout)[64] = ring.g[s & 1u];
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                double col[J];
+#pragma unroll
+                for (int i = 0; i < J; ++i) col[i] = A[i][j];
+                tp_apply_F<NR, NC>(T, col);
+                const double gj = tp_h_dot<NR, NC>(col);
+                const double gs = gj * inv;
+#pragma unroll
+                for (int i = 0; i < J; ++i) A[i][j] = fma(-ch[i], gs, col[i]);
+                gout[C0 + j][lane] = gj;
+                if (HALF == 1) eta[j] = fma(gj, zi, eta[j]);
+                else gk[j] = gj;
+            }
+        }
+        TPB4_SYNC();
+    }
+    constexpr int MM = J * J;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < H; ++j) slot[i * J + C0 + j] = A[i][j];
+#pragma unroll
+    for (int j = 0; j < H; ++j) slot[MM + J + C0 + j] = eta[j];
+    if (HALF == 1) {
+#pragma unroll
+        for (int i = 0; i < J; ++i) slot[MM + i] = b[i];
+        part[0] = dot;
+    }
+}
+
+// waves 2 and 3: FW = 0 / 1 (FW = 0 also publishes ch, 1 / D and keeps the pivot statistics)
+template <int NR, int NC, int FW>
+__device__ __forceinline__ void tpb4_filter(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, int64_t lc,
+                                            TpbRing4<NR + 2 * NC> &ring, double *slot, double *part, uint32_t lo, uint32_t hi,
+                                            uint32_t per)
+{
+    constexpr int J = NR + 2 * NC, MM = J * J, NT = NR + NC;
+    const int lane = threadIdx.x & 63;
+    const double2 *yv = a.yv + lc * a.N;
+    Sym<J> Dv, Jm;   // only the entries of the own blocks are ever touched (the others never become registers)
+#pragma unroll
+    for (int i = 0; i < J * (J + 1) / 2; ++i) { Dv.v[i] = 0.0; Jm.v[i] = 0.0; }
+    tp_sub_pinf<NR, NC, J>(M, Dv);  // C - P_inf, C = 0
+    double chp[J];                  // own partial sums of Dv h of the step in flight
+    double kap1 = 1.0, kap2 = INFINITY;
+    int kexp = 0;
+    double inv_b = 0.0, inv_1 = 0.0, inv_2 = 0.0;   // 1 / D of the steps t - 2 (part B of this tick), t - 3, t - 4
+    const uint32_t last = ((uint32_t)a.N - 1u) * 16u;
+    uint32_t off = lo * 16u;
+    double vn = tpb_sample(yv, off < last ? off : last).y;
+    for (uint32_t t = 0; t < per + 4u; ++t) {
+        inv_2 = inv_1; inv_1 = inv_b;
+        if (t >= 4u && t < per + 4u) {   // Jm of step t - 4
+            const double(*G)[64] = ring.g[(t - 4u) & 1u];
+            double g[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) g[j] = G[j][lane];
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                const double gi = g[i] * inv_2;
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    if (tpb_owns<NR>(FW, i, j)) Jm(i, j) = fma(gi, g[j], Jm(i, j));
+            }
+        }
+        if (t >= 2u && t < per + 2u) {   // part B of step t - 2
+            const uint32_t s = t - 2u;
+            const bool valid = off < hi * 16u;
+            const double R = valid ? vn + jitter : 1.0e300;
+            off += 16u;
+            vn = tpb_sample(yv, off < last ? off : last).y;
+            const double(*P)[64] = ring.part[1 - FW][s & 1u];
+            double ch[J];
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                const double pinf_h = i < NR ? M.ar[i < NR ? i : 0] : ((i - NR) & 1 ? -M.bc[i < NR ? 0 : (i - NR) / 2] : M.ac[i < NR ? 0 : (i - NR) / 2]);
+                ch[i] = (chp[i] + P[i][lane]) + pinf_h;
+            }
+            const double D = tp_h_dot<NR, NC>(ch) + R;
+            const double inv = mtg_rcp(D);
+            inv_b = inv;
+            if (FW == 0) {
+                double(*G)[64] = ring.ch[s & 1u];
+#pragma unroll
+                for (int i = 0; i < J; ++i) G[i][lane] = ch[i];
+                G[J][lane] = inv;
+                const double pr = kap1 * (valid ? D : 1.0);
+                kexp += __builtin_amdgcn_frexp_exp(pr);
+                kap1 = __builtin_amdgcn_frexp_mant(pr);
+                kap2 = fmin(kap2, D);
+            }
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+                const double ki = ch[i] * inv;
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    if (tpb_owns<NR>(FW, i, j)) Dv(i, j) = fma(-ki, ch[j], Dv(i, j));
+            }
+        } else {
+            inv_b = 0.0;
+        }
+        if (t >= 1u && t < per + 1u) {   // part A of step t - 1
+            const uint32_t s = t - 1u;
+            TpTrans<NR, NC> T;
+            tpb4_read_F<NR, NC>(ring.F[s & 3u], lane, T);
+            // Dv <- F Dv F^T on the own blocks (tpb_predict_dev, block by block)
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+                for (int tb = 0; tb <= ta; ++tb) {
+                    if (tpb_owner(ta, tb) != FW) continue;
+                    const int oa = tpb_row0<NR>(ta), ob = tpb_row0<NR>(tb);
+                    const bool ca = ta >= NR, cb = tb >= NR;
+                    const int ka = ca ? ta - NR : 0, kb = cb ? tb - NR : 0;
+                    if (!ca) {          // real x real (ta >= tb: tb is real too)
+                        Dv(oa, ob) = (Dv(oa, ob) * T.phi[ca ? 0 : ta]) * T.phi[cb ? 0 : tb];
+                    } else if (!cb) {   // complex x real
+                        const double x0 = Dv(oa, ob) * T.phi[cb ? 0 : tb], x1 = Dv(oa + 1, ob) * T.phi[cb ? 0 : tb];
+                        Dv(oa, ob) = T.ec[ka] * x0 - T.es[ka] * x1;
+                        Dv(oa + 1, ob) = T.es[ka] * x0 + T.ec[ka] * x1;
+                    } else if (ta != tb) {
+                        const double b00 = Dv(oa, ob), b01 = Dv(oa, ob + 1), b10 = Dv(oa + 1, ob), b11 = Dv(oa + 1, ob + 1);
+                        const double y00 = T.ec[ka] * b00 - T.es[ka] * b10, y01 = T.ec[ka] * b01 - T.es[ka] * b11;
+                        const double y10 = T.es[ka] * b00 + T.ec[ka] * b10, y11 = T.es[ka] * b01 + T.ec[ka] * b11;
+                        Dv(oa, ob) = y00 * T.ec[kb] - y01 * T.es[kb];
+                        Dv(oa, ob + 1) = y00 * T.es[kb] + y01 * T.ec[kb];
+                        Dv(oa + 1, ob) = y10 * T.ec[kb] - y11 * T.es[kb];
+                        Dv(oa + 1, ob + 1) = y10 * T.es[kb] + y11 * T.ec[kb];
+                    } else {
+                        const double d00 = Dv(oa, oa), d10 = Dv(oa + 1, oa), d11 = Dv(oa + 1, oa + 1);
+                        const double y00 = T.ec[ka] * d00 - T.es[ka] * d10, y01 = T.ec[ka] * d10 - T.es[ka] * d11;
+                        const double y10 = T.es[ka] * d00 + T.ec[ka] * d10, y11 = T.es[ka] * d10 + T.ec[ka] * d11;
+                        Dv(oa, oa) = y00 * T.ec[ka] - y01 * T.es[ka];
+                        Dv(oa + 1, oa) = y10 * T.ec[ka] - y11 * T.es[ka];
+                        Dv(oa + 1, oa + 1) = y10 * T.es[ka] + y11 * T.ec[ka];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // own share of Dv h: h picks the first row of every term; entry (i, j), i >= j, feeds row i when j is such a
+            // row and -- off the diagonal -- row j when i is
+#pragma unroll
+            for (int i = 0; i < J; ++i) chp[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < J; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    if (!tpb_owns<NR>(FW, i, j)) continue;
+                    const bool hj = j < NR || ((j - NR) & 1) == 0, hi_ = i < NR || ((i - NR) & 1) == 0;
+                    if (hj) chp[i] += Dv(i, j);
+                    if (hi_ && i != j) chp[j] += Dv(i, j);
+                }
+            double(*P)[64] = ring.part[FW][s & 1u];
+#pragma unroll
+            for (int i = 0; i < J; ++i) P[i][lane] = chp[i];
+        }
+        TPB4_SYNC();
+    }
+    // the own entries of C = Dv + P_inf and of Jm, both triangles of the full matrices
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            if (!tpb_owns<NR>(FW, i, j)) continue;
+            double c = Dv(i, j);
+            if (i == j) c += i < NR ? M.ar[i < NR ? i : 0] : ((i - NR) & 1 ? M.pc[i < NR ? 0 : (i - NR) / 2] : M.ac[i < NR ? 0 : (i - NR) / 2]);
+            if (i >= NR && ((i - NR) & 1) && j == i - 1) c -= M.bc[i < NR ? 0 : (i - NR) / 2];
+            slot[MM + 2 * J + i * J + j] = c;
+            slot[MM + 2 * J + j * J + i] = c;
+            slot[2 * MM + 2 * J + i * J + j] = Jm(i, j);
+            slot[2 * MM + 2 * J + j * J + i] = Jm(i, j);
+        }
+    if (FW == 0) {
+        part[1] = log(kap1) + (double)kexp * 0.69314718055994530942;
+        part[2] = kap2;
+    }
+}
+
+// 64 chunks (block cb) of one evaluation of structure <NR, NC> by four waves: lane & 63 = chunk, `role` uniform per wave
+template <int NR, int NC>
+__device__ __forceinline__ void tpb4_compose_eval(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
+                                                  TpbRing4<NR + 2 * NC> &ring, const MtgMathTables *tab, uint32_t cb, int role)
+{
+    constexpr int J = NR + 2 * NC;
+    TpModel<NR, NC> M;
+    double jitter, slope, icpt;
+    int64_t lc;
+    bool fast;
+    if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;  // the finish kernel reports it
+    const uint32_t c = cb * 64u + (threadIdx.x & 63u);
+    uint32_t lo, hi;
+    tpb_chunk_range(a.N, C, c, lo, hi);
+    const uint32_t per = ((uint32_t)a.N - 1u + (uint32_t)C - 1u) / (uint32_t)C;
+    double *slot = elems + (ev * C + c) * MTG_TPB_ELEM(J), *part = parts + (ev * C + c) * 4;
+    switch (role) {
+    case 0: tpb4_columns<NR, NC, 0>(a, M, slope, icpt, lc, tab, fast, ring, slot, part, lo, hi, per); break;
+    case 1: tpb4_columns<NR, NC, 1>(a, M, slope, icpt, lc, tab, fast, ring, slot, part, lo, hi, per); break;
+    case 2: tpb4_filter<NR, NC, 0>(a, M, jitter, lc, ring, slot, part, lo, hi, per); break;
+    default: tpb4_filter<NR, NC, 1>(a, M, jitter, lc, ring, slot, part, lo, hi, per); break;
+    }
+}
+
 template <int NR, int NC>
 __device__ __forceinline__ void tpb_filter_body(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope,
                                                 double icpt, int64_t lc, const MtgMathTables *tab, bool fast, const double *st,
@@ -493,6 +891,13 @@ template <int NR, int NC> struct TpbComposeF {
         tpb2_compose_eval<NR, NC>(a, ev, elems, parts, C, ring, tab);
     }
 };
+template <int NR, int NC> struct TpbCompose4F {
+    static __device__ __forceinline__ void run(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
+                                               TpbRing4<10> &ring, const MtgMathTables *tab, uint32_t cb, int role)
+    {
+        tpb4_compose_eval<NR, NC>(a, ev, elems, parts, C, ring, tab, cb, role);
+    }
+};
 template <int NR, int NC> struct TpbFilterF {
     static __device__ __forceinline__ void run(const MtgSolveArgs &a, int64_t ev, const double *states, double *parts, int C,
                                                const MtgMathTables *tab)
@@ -510,4 +915,5 @@ void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const dou
                            hipStream_t stream);
 // mtg_tp_big_compose.hip / mtg_tp_big_filter.hip: the two kernels that hold all six structures
 void mtg_launch_tpb_compose(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
+void mtg_launch_tpb_compose4(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
 void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *parts, int C, int64_t nevals, hipStream_t stream);

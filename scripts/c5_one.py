@@ -16,6 +16,8 @@ full = np.concatenate([th, [0.0]])
 bounds = np.vstack([synth.bounds_for(kinds), [(-np.inf, np.inf)]])
 eng.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
 eng.set_model(kinds, full, np.arange(15, dtype=np.int32), bounds)
+if os.environ.get('MTG_C5_DIRECT'):
+    eng.set_tp_direct(int(os.environ['MTG_C5_DIRECT']))   # 2: never take the filter pass (timing of broken variants)
 rng = np.random.default_rng(5)
 theta = th + 0.05 * np.abs(th) * rng.standard_normal((B, len(th)))
 ms = []
