@@ -3,7 +3,7 @@
 #   bash scripts/profile_chains.sh r02     (on the GPU box, via gpurun)
 # -> gpurun_out/<tag>_small_{1,2}_{stats.csv,trace.txt}, <tag>_tp_kernel_stats.csv, <tag>_tp_halfstep_trace.txt,
 #    <tag>_c5_sweep.txt; copy the ones to keep into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$PWD
 OUT=$REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -25,7 +25,7 @@ c5)
   done
   cat $OUT/${TAG}_c5_breakdown.txt ;;
 chains)
-  bash $REPO/scripts/profile_chains.sh $TAG ;;
+  cd $REPO && bash scripts/profile_chains.sh $TAG ;;
 pmc)
   for k in 1 2; do
     for c in FETCH_SIZE WRITE_SIZE; do
