@@ -24,8 +24,32 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
+
+
+def head_commit():
+    """The commit the profiled tree was at: `git rev-parse HEAD` here, or the .git_head file written before the tree
+    travelled to the GPU box (which has no .git)."""
+    import subprocess
+    try:
+        return subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        try:
+            return open(os.path.join(root, ".git_head")).read().strip()
+        except OSError:
+            return "unknown"
+
+
+HEAD = head_commit()
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
-shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as fh:   # (every summary says which commit it measured)
+    fh.write("# HEAD %s\n" % HEAD)
+    for line in open(stats):   # rocPRIM's kernel names run to two thousand characters: keep what tells them apart
+        if line.startswith('"void rocprim::'):
+            name, rest = line[1:].split('",', 1)
+            what = name.split("detail::wrapped_")[1].split("<")[0] if "detail::wrapped_" in name else "kernel"
+            step = "iteration" if "onesweep_iteration" in name else "global_offsets" if "global_offsets" in name else ""
+            line = '"rocprim::%s %s (the sweep\'s sort by structure, light curve)",%s' % (what, step, rest)
+        fh.write(line)
 
 
 def mean_counter(sub, counter):
@@ -46,6 +70,7 @@ for k in sorted(set(fetch) | set(write)):
     rows.append({"kernel": k, "launches": max(nf, nw), "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w,
                  "hbm_read_bytes_corrected": 2.0 * f * 1024.0, "hbm_write_bytes": w * 1024.0})
 with open(os.path.join(dst, tag + "_pmc_hbm.csv"), "w", newline="") as fh:
+    fh.write("# HEAD %s\n" % HEAD)
     wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
     wr.writeheader()
     wr.writerows(rows)
@@ -56,7 +81,7 @@ known_write = (L * N + N) * 16.0            # interleaved (y, var) and (dx, t) p
 solve = max((r for r in rows if "mtg_solve_kernel" in r["kernel"]),
             key=lambda r: r["hbm_read_bytes_corrected"])
 rec = {
-    "tag": tag, "round": "round " + tag[1:3].lstrip("0") if tag[:1] == "r" and tag[1:3].isdigit() else tag,
+    "tag": tag, "head": HEAD, "round": "round " + tag[1:3].lstrip("0") if tag[:1] == "r" and tag[1:3].isdigit() else tag,
     "N": N, "B": L * W, "kernel": solve["kernel"],
     "hbm_bytes_per_launch": solve["hbm_read_bytes_corrected"] + solve["hbm_write_bytes"],
     "hbm_read_bytes_per_launch": solve["hbm_read_bytes_corrected"],
