@@ -117,8 +117,8 @@ def _seed_rocfft_cache():
     of a node must not share one, and the tracked file must not change under a run), removed at exit; the seed is
     skipped when it was made with another rocFFT build (version stamp next to it) or when the user chose a file."""
     global rocfft_cache_seeded, _rocfft_cache_copy
+    rocfft_cache_seeded = False
     if "ROCFFT_RTC_CACHE_PATH" in os.environ:
-        rocfft_cache_seeded = False
         return
     if not os.path.exists(ROCFFT_CACHE_SEED):
         return

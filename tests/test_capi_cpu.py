@@ -64,3 +64,33 @@ def test_sharding_entry_points_check_their_arguments_without_a_gpu():
     assert lib.mtg_ensemble_shard_rccl(None, ctypes.create_string_buffer(128), 0, 1) == engine.E_ARG
     assert lib.mtg_ensemble_unshard(None) == engine.E_ARG
     assert lib.mtg_rccl_unique_id(None) == engine.E_ARG
+
+
+def test_rocfft_seed_cache_is_copied_per_process(monkeypatch, tmp_path):
+    """rocFFT writes to the cache file it is given: the tracked seed must never be that file.  The loader hands
+    rocFFT a private copy in the temporary directory -- if the seed was made with the librocfft this process will
+    load (version stamp next to it) -- and leaves a path chosen by the user alone."""
+    import os
+    from mind_the_gaps_amd import engine
+    monkeypatch.delenv("ROCFFT_RTC_CACHE_PATH", raising=False)
+    monkeypatch.setattr(engine, "rocfft_cache_seeded", False)
+    engine._seed_rocfft_cache()
+    stamp_ok = os.path.exists(engine.ROCFFT_CACHE_STAMP) and \
+        open(engine.ROCFFT_CACHE_STAMP).read().strip() == engine.rocfft_library_version()
+    if stamp_ok:
+        copy = os.environ["ROCFFT_RTC_CACHE_PATH"]
+        assert engine.rocfft_cache_seeded and os.path.abspath(copy) != os.path.abspath(engine.ROCFFT_CACHE_SEED)
+        assert os.path.getsize(copy) == os.path.getsize(engine.ROCFFT_CACHE_SEED) and str(os.getpid()) in os.path.basename(copy)
+        os.remove(copy)
+    else:
+        assert not engine.rocfft_cache_seeded and "ROCFFT_RTC_CACHE_PATH" not in os.environ
+    # a seed made with another rocFFT build is skipped
+    monkeypatch.delenv("ROCFFT_RTC_CACHE_PATH", raising=False)
+    monkeypatch.setattr(engine, "ROCFFT_CACHE_STAMP", str(tmp_path / "other.version"))
+    (tmp_path / "other.version").write_text("librocfft.so.0.0.0:1\n")
+    engine._seed_rocfft_cache()
+    assert not engine.rocfft_cache_seeded and "ROCFFT_RTC_CACHE_PATH" not in os.environ
+    # the user's own choice wins
+    monkeypatch.setenv("ROCFFT_RTC_CACHE_PATH", str(tmp_path / "mine.db"))
+    engine._seed_rocfft_cache()
+    assert os.environ["ROCFFT_RTC_CACHE_PATH"] == str(tmp_path / "mine.db") and not engine.rocfft_cache_seeded

@@ -338,6 +338,9 @@ def _host_exchange_worker(rank, world, port, out_dir):
         ok = ok and np.array_equal(lnp, truth_lnp) and np.array_equal(st, truth_st)
     p0, seed = broadcast_start(np.full((4, 2), float(rank)), 100 + rank)
     ok = ok and np.all(p0 == 0.0) and seed == 100
+    from mind_the_gaps_amd.distributed import broadcast_array
+    tau = broadcast_array(np.array([[1.5 + rank, 2.0], [np.nan, 7.0 - rank]]))     # rank 0's autocorrelation times win
+    ok = ok and tau.shape == (2, 2) and tau[0, 0] == 1.5 and tau[1, 1] == 7.0 and np.isnan(tau[1, 0])
     open(os.path.join(out_dir, "hx%d.txt" % rank), "w").write("ok" if ok else "bad")
     dist.barrier()
     dist.destroy_process_group()
