@@ -440,7 +440,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         sa.list = nullptr;
         sa.count_ptr = nullptr;
         snprintf(ctx->last_solver, sizeof ctx->last_solver, "%s (+ mtg_tpb_reduce_kernel<10>, C = %d)",
-                 mtg_tpb_compose_waves() == 2 ? "mtg_tpb_compose2_kernel" : "mtg_tpb_compose4_kernel", sa.tp_chunks);
+                 mtg_tpb_compose_waves() == 2 ? "mtg_tpb_compose2_kernel" : mtg_tpb_compose_waves() == 8 ? "mtg_tpb_compose4_kernel" : "mtg_tpb_compose4q_kernel", sa.tp_chunks);
         mtg_launch_tp_big(sa, B, s);
     } else if (fused) {  // every signature in one launch
         sa.list = bank_lists(ctx);

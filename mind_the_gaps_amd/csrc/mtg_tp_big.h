@@ -916,4 +916,5 @@ void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const dou
 // mtg_tp_big_compose.hip / mtg_tp_big_filter.hip: the two kernels that hold all six structures
 void mtg_launch_tpb_compose(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
 void mtg_launch_tpb_compose4(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
+void mtg_launch_tpb_compose4q(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
 void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *parts, int C, int64_t nevals, hipStream_t stream);

@@ -33,8 +33,8 @@ void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *
 // from one wave, 4.5 from two, 4.3 from four).  MTG_TPB_COMPOSE=2 selects the two-wave kernel for side-by-side runs.
 int mtg_tpb_compose_waves(void)
 {
-    static const int waves = getenv("MTG_TPB_COMPOSE") && atoi(getenv("MTG_TPB_COMPOSE")) == 2 ? 2 : 4;
-    return waves;
+    static const int waves = !getenv("MTG_TPB_COMPOSE") ? 4 : atoi(getenv("MTG_TPB_COMPOSE")) == 2 ? 2 : atoi(getenv("MTG_TPB_COMPOSE")) == 8 ? 8 : 4;
+    return waves;   // 4: quartets as workgroups of their own (compose4q); 8: two quartets per workgroup (compose4); 2: round 2
 }
 
 // Every prepared evaluation of a rank-10 model (status OK; its structure in a.sig) in one sequence of
@@ -50,7 +50,8 @@ void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
     const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C, a.tp_gsize);
     double *ws = a.tp_ws;
     if (mtg_tpb_compose_waves() == 2) mtg_launch_tpb_compose(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
-    else mtg_launch_tpb_compose4(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
+    else if (mtg_tpb_compose_waves() == 8) mtg_launch_tpb_compose4(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
+    else mtg_launch_tpb_compose4q(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
     mtg_launch_tpb_up(J, a, plan, nevals, a.tp_direct, s);
     MtgSolveArgs f = a;
     if (a.tp_direct) {

@@ -17,6 +17,6 @@ for k,v in rows.items():
     print("%-46s VGPR %3d AGPR %3d SGPR %3d scratch %5d B/lane  LDS %6d B  waves/SIMD %d"%(name,v.get("VGPRs",0),v.get("AGPRs",0),v.get("TotalSGPRs",0),v.get("ScratchSize",0),v.get("LDS",0),v.get("Occupancy",0)))
 '
 }
-for f in mtg_tp_big_compose mtg_tp_big_compose4 mtg_tp_big_filter mtg_tp_scan; do
+for f in mtg_tp_big_compose mtg_tp_big_compose4 mtg_tp_big_compose4q mtg_tp_big_filter mtg_tp_scan; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f.hip -o /tmp/tpb_res.o -Rpass-analysis=kernel-resource-usage 2>&1 | report
 done
