@@ -503,9 +503,11 @@ def main():
         raise SystemExit("bench: non-finite log-likelihoods in the timed batch")
 
     extras = {}
-    if world > 1:
+    if grouped:
         extras["rccl_ranks"] = {"torch_distributed_world": dist.get_world_size(), "backend": dist.get_backend()}
-        if not args.no_extras:
+        if not args.no_extras and (world > 1 or os.environ.get("MTG_SHARD_ONE_RANK") == "1"):
+            # (MTG_BENCH_FORCE_DIST=1 MTG_SHARD_ONE_RANK=1 on a one-GPU box: the whole multi-rank path -- process group over
+            # RCCL, broadcasts, the library's communicator, the all-gather pair of every half-step -- with one rank)
             extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
     if world == 1 and not args.no_extras:
         # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status

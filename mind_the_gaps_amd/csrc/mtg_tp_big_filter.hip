@@ -52,11 +52,10 @@ void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
     if (mtg_tpb_compose_waves() == 2) mtg_launch_tpb_compose(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
     else if (mtg_tpb_compose_waves() == 8) mtg_launch_tpb_compose4(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
     else mtg_launch_tpb_compose4q(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
-    mtg_launch_tpb_up(J, a, plan, nevals, a.tp_direct, s);
+    int *redo_list = (int *)(ws + plan.redo_off), *redo_count = redo_list + a.B;
+    mtg_launch_tpb_up(J, a, plan, nevals, a.tp_direct, a.tp_direct ? redo_count : nullptr, s);
     MtgSolveArgs f = a;
     if (a.tp_direct) {
-        int *redo_list = (int *)(ws + plan.redo_off), *redo_count = redo_list + a.B;
-        (void)hipMemsetAsync(redo_count, 0, sizeof(int), s);
         mtg_launch_tpb_top_direct(J, a, plan, nevals, redo_list, redo_count, s);
         f.list = redo_list;
         f.count_ptr = redo_count;

@@ -98,8 +98,10 @@ static inline int mtg_tp_big_gsize(int64_t B, int C)
     return 4;
 }
 
-// up-sweep; kappa != 0: every group (the last one's total too) and the likelihood records
-void mtg_launch_tpb_up(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int kappa, hipStream_t stream);
+// up-sweep; kappa != 0: every group (the last one's total too) and the likelihood records; zero_me: an int the first
+// level's first workgroup clears (the redo counter), or NULL
+void mtg_launch_tpb_up(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int kappa, int *zero_me,
+                       hipStream_t stream);
 // lnL from the top-level elements and their records; suspects are appended to the redo list
 void mtg_launch_tpb_top_direct(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int *redo_list,
                                int *redo_count, hipStream_t stream);

@@ -32,8 +32,11 @@ template <int J, bool KAPPA>
 __global__ void __launch_bounds__(64, KAPPA ? 4 : 3) mtg_tpb_reduce_kernel(MtgSolveArgs a, const double *in,
                                                                                            double *out, int n_in, int g,
                                                                                            const double *rec_in, double *rec_out,
-                                                                                           int level0)
+                                                                                           int level0, int *zero_me)
 {
+    // (the redo counter of the evaluation's batch: its readers of the previous half-step are done, the top kernel that
+    // appends to it comes after the up-sweep -- one memset launch less per half-step)
+    if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;
     __shared__ tpw::Lds<J> L;
     const int gpe = n_in / g;
     int64_t ev;
@@ -185,36 +188,59 @@ __global__ void __launch_bounds__(64, 2) mtg_tpb_top_direct_kernel(MtgSolveArgs 
     }
 }
 
-// states[ev][k gsize + i] = start state of element k gsize + i, i = 0 .. gsize - 1, from the start state
-// of the group: up[ev][k] (the level above), or -- at the top, up == NULL, one group per evaluation --
-// the filtered state after sample 0 (which also leaves that sample's terms of the likelihood in head[ev]).
+// Start states of the chunks, for the evaluations that go through the filter pass: ONE launch, one wave per group of
+// chunks at the bottom level.  The wave starts from the filtered state after sample 0 (which also leaves that sample's
+// terms of the likelihood in head[ev]) and walks down the tree to its first chunk: at the top level it applies the
+// elements before its ancestor, at every level below the elements of its ancestor's group that come before the next
+// ancestor -- at most (top - 1) + (g - 1) per level applications, ~16 for 1024 chunks --, then writes the start state of
+// each of its own chunks, applying them in turn.  (Round 2 swept down level by level, one launch per level, each
+// reading the states the level above had written: as many launches as levels in every half-step, for a list that is
+// empty as a rule.  Evaluations on the list pay ~5 x the applications here; they are rare, and one launch it is.)
 template <int J>
-__global__ void __launch_bounds__(64, 2) mtg_tpb_down_kernel(MtgSolveArgs a, const double *elems, const double *up,
-                                                          double *states, double *head, int n, int gsize)
+__global__ void __launch_bounds__(64, 2) mtg_tpb_descend_kernel(MtgSolveArgs a, MtgTpBigPlan p, double *ws)
 {
     constexpr int M = J * J;
     __shared__ tpw::Lds<J> L;
-    const int gpe = n / gsize;
+    const int g0 = p.gl[0] > 0 ? p.gl[0] : p.n[0];   // (a single level: the chunks themselves are the top)
+    const int gpe = p.n[0] / g0;
     int64_t ev;
     int k;
     if (!tpb_group(a, gpe, ev, k)) return;
     const int l64 = threadIdx.x;
     const tpw::Lane w = tpw::lane_of<J>(l64);
-    if (up) {
-        tpw::gcopy(L.b1, up + (ev * gpe + k) * MTG_TPB_STATE(J), J + M, l64);  // b1 | C1 are contiguous
-        tpw::wsync();
-    } else if (!tpb_head_state<J>(a, ev, L, l64, w, head)) {
-        return;
-    }
-    const int64_t first = ev * n + (int64_t)k * gsize;
+    if (!tpb_head_state<J>(a, ev, L, l64, w, ws + p.head_off)) return;
+    // ancestors of the group's first chunk, level by level
+    int idx[MTG_TPB_MAX_LEVELS];
+    idx[0] = k * g0;
+    for (int l = 0; l + 1 < p.nlev; ++l) idx[l + 1] = idx[l] / p.gl[l];
     tpw::Pre<J> pre;
-    tpw::fetch<J>(pre, elems + first * MTG_TPB_ELEM(J), l64);
+    auto run = [&](const double *elems, int64_t from, int64_t to) {   // the state through elements [from, to)
+        if (to <= from) return;
+        tpw::fetch<J>(pre, elems + from * MTG_TPB_ELEM(J), l64);
+        for (int64_t e = from; e < to; ++e) {
+            tpw::put_second<J>(L, pre, l64);
+            if (e + 1 < to) tpw::fetch<J>(pre, elems + (e + 1) * MTG_TPB_ELEM(J), l64);
+            tpw::wsync();
+            tpw::apply<J>(L, w);
+        }
+    };
+    const int top = p.nlev - 1;
+    for (int l = top; l >= 1; --l) {
+        const int64_t base = ev * p.n[l];
+        const int first = l == top ? 0 : idx[l + 1] * p.gl[l];
+        run(ws + p.elem_off[l], base + first, base + idx[l]);
+    }
+    // the group's own chunks
+    const int64_t first = ev * p.n[0] + idx[0];
+    double *states = ws + p.state_off[0];
+    const double *elems0 = ws + p.elem_off[0];
+    tpw::fetch<J>(pre, elems0 + first * MTG_TPB_ELEM(J), l64);
 #pragma unroll 1
-    for (int i = 0; i < gsize; ++i) {
+    for (int i = 0; i < g0; ++i) {
         tpw::gcopy(states + (first + i) * MTG_TPB_STATE(J), L.b1, J + M, l64);
-        if (i + 1 == gsize) break;
+        if (i + 1 == g0) break;
         tpw::put_second<J>(L, pre, l64);
-        if (i + 1 < gsize) tpw::fetch<J>(pre, elems + (first + i + 1) * MTG_TPB_ELEM(J), l64);
+        tpw::fetch<J>(pre, elems0 + (first + i + 1) * MTG_TPB_ELEM(J), l64);
         tpw::wsync();
         tpw::apply<J>(L, w);
     }
@@ -255,7 +281,7 @@ __global__ void __launch_bounds__(64) mtg_tpb_finish_kernel(MtgSolveArgs a, cons
 }
 
 template <int J>
-void launch_up(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int kappa, hipStream_t s)
+void launch_up(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int kappa, int *zero_me, hipStream_t s)
 {
     double *ws = a.tp_ws;
     auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
@@ -263,10 +289,11 @@ void launch_up(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, int
         const double *rec_in = ws + (l == 0 ? p.part_off : p.rec_off[l]);
         if (kappa)
             hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J, true>), blocks(p.n[l] / p.gl[l]), dim3(64), 0, s, a, ws + p.elem_off[l],
-                               ws + p.elem_off[l + 1], p.n[l], p.gl[l], rec_in, ws + p.rec_off[l + 1], l == 0 ? 1 : 0);
+                               ws + p.elem_off[l + 1], p.n[l], p.gl[l], rec_in, ws + p.rec_off[l + 1], l == 0 ? 1 : 0,
+                               l == 0 ? zero_me : (int *)nullptr);
         else
             hipLaunchKernelGGL((mtg_tpb_reduce_kernel<J, false>), blocks(p.n[l] / p.gl[l]), dim3(64), 0, s, a, ws + p.elem_off[l],
-                               ws + p.elem_off[l + 1], p.n[l], p.gl[l], (const double *)nullptr, (double *)nullptr, 0);
+                               ws + p.elem_off[l + 1], p.n[l], p.gl[l], (const double *)nullptr, (double *)nullptr, 0, (int *)nullptr);
     }
 }
 
@@ -282,21 +309,17 @@ void launch_top_direct(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nev
 template <int J>
 void launch_down(const MtgSolveArgs &a, const MtgTpBigPlan &p, int64_t nevals, hipStream_t s)
 {
-    double *ws = a.tp_ws;
-    auto blocks = [&](int64_t groups_per_eval) { return dim3((unsigned)((nevals * groups_per_eval + GROUPS - 1) / GROUPS)); };
-    const int top = p.nlev - 1;
-    hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(1), dim3(64), 0, s, a, ws + p.elem_off[top], (const double *)nullptr,
-                       ws + p.state_off[top], ws + p.head_off, p.n[top], p.n[top]);
-    for (int l = top - 1; l >= 0; --l)
-        hipLaunchKernelGGL((mtg_tpb_down_kernel<J>), blocks(p.n[l] / p.gl[l]), dim3(64), 0, s, a, ws + p.elem_off[l],
-                           ws + p.state_off[l + 1], ws + p.state_off[l], ws + p.head_off, p.n[l], p.gl[l]);
+    const int g0 = p.gl[0] > 0 ? p.gl[0] : p.n[0];
+    const int64_t groups = nevals * (p.n[0] / g0);
+    hipLaunchKernelGGL((mtg_tpb_descend_kernel<J>), dim3((unsigned)groups), dim3(64), 0, s, a, p, a.tp_ws);
 }
 
 }  // namespace
 
-void mtg_launch_tpb_up(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int kappa, hipStream_t stream)
+void mtg_launch_tpb_up(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int kappa, int *zero_me,
+                       hipStream_t stream)
 {
-    if (J == 10) launch_up<10>(a, plan, nevals, kappa, stream);
+    if (J == 10) launch_up<10>(a, plan, nevals, kappa, zero_me, stream);
 }
 
 void mtg_launch_tpb_top_direct(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, int *redo_list,

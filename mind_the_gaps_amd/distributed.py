@@ -220,9 +220,14 @@ def shard_device_ensemble(engine, group=None, transport=None):
     broadcasts over ``group``.  "host": the library stages this rank's rows on the host and the exchange runs
     over ``group``'s own backend (gloo in the CPU-side tests; also the way for processes that share one GPU,
     which RCCL refuses).  Default: "rccl" when ``group``'s backend is nccl, else "host"."""
+    import os
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return "none"
+    # MTG_SHARD_ONE_RANK=1 (rehearsals on a one-GPU box): a group of ONE rank still goes through the transport -- unique
+    # id, broadcast, ncclCommInitRank, the all-gather pair of every half-step
+    if dist.get_world_size(group) == 1 and os.environ.get("MTG_SHARD_ONE_RANK") != "1":
         return "none"
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if transport is None:
