@@ -975,7 +975,8 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lc_half.p, lc_half.data(), (size_t)EH * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ens_naccept.p, 0, (size_t)EW * 4, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ens_notpd.p, 0, 4, s));
-    // log-probability of the initial state (emcee evaluates p0 once)
+    // log-probability of the initial state (emcee evaluates p0 once); the rows are grouped by ensemble, hence by light curve
+    ctx->lc_grouped_hint = 1;
     rc = run_model_batch(ctx, EW, ctx->ens_coords.as<double>(), ctx->ens_lc_full.as<int32_t>(), 1,
                          ctx->ens_lnp.as<double>(), ctx->ens_st.as<int32_t>(), s);
     if (rc) return rc;
