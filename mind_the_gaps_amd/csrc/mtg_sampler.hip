@@ -151,15 +151,19 @@ __device__ __forceinline__ void mtg_accept_part(const MtgEnsembleArgs &g, int ha
                 if (cand > my_best) { my_best = cand; my_idx = (int)i; }
             }
         }
-    if (worker) { s_best[threadIdx.x] = my_best; s_idx[threadIdx.x] = my_idx; }
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s && s_best[threadIdx.x + s] > s_best[threadIdx.x]) {
-            s_best[threadIdx.x] = s_best[threadIdx.x + s];
-            s_idx[threadIdx.x] = s_idx[threadIdx.x + s];
-        }
-        __syncthreads();
+    // best accepted proposal of the ensemble: inside each of the four worker waves by shuffles, then one barrier instead
+    // of the nine of a tree over 256 LDS slots (measured: no difference -- this kernel's ~14 us are a chain of about ten
+    // dependent global-memory round trips: split -> partner -> coordinates -> proposal -> expansion -> list append)
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(my_best, off);
+        const int oi = __shfl_down(my_idx, off);
+        if (ob > my_best) { my_best = ob; my_idx = oi; }
     }
+    if (worker && (threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = my_best; s_idx[threadIdx.x >> 6] = my_idx; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int wv = 1; wv < 4; ++wv)
+            if (s_best[wv] > s_best[0]) { s_best[0] = s_best[wv]; s_idx[0] = s_idx[wv]; }
     if (threadIdx.x == 0 && s_idx[0] >= 0 && s_best[0] > g.best_lnp[e]) {
         g.best_lnp[e] = s_best[0];
         for (int d = 0; d < P; ++d) g.best_coords[(int64_t)e * P + d] = q[(int64_t)s_idx[0] * P + d];
