@@ -39,6 +39,8 @@ The JSON line also carries
   workflow_config3: (N = 1) the other SURVEY 8(d) figures: the null model's sweep beside the alternative's,
                     the raw kernel at B = 65 536 for DRW+SHO (J = 3 and zero-padded J = 4), the
                     single-light-curve chains, configs[3] as a whole workflow (scripts/config3_probe.py);
+  workflow_config3_sharded: (N > 1) ppp.protassov_test(sharded=True): every rank simulates and refits its block
+                    of the 2000 light curves, one all-gather of the maxima per model; time = max over ranks;
   cpu_baseline    : oracle/celerite_ref.c (a plain-C port of celerite's algorithm, fused one-sweep
                     variant, built -O3 -march=native on this host) single thread and on all usable
                     cores, bounded sample (rank 0, N = 1 only).
@@ -334,6 +336,14 @@ def raw_kernel_config2(dev):
     return out
 
 
+def workflow_probe():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("config3_probe", os.path.join(ROOT, "scripts", "config3_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    return probe
+
+
 def walker_sharded_configs(rank, world, local_dev, oversubscribed):
     """configs[2] and configs[4] (ONE light curve each) with every half-step's proposals split over the ranks: the
     device-resident sampler of GPModelling.derive_posteriors(device_sampler=True, shard_walkers=True) --
@@ -509,6 +519,16 @@ def main():
             # (MTG_BENCH_FORCE_DIST=1 MTG_SHARD_ONE_RANK=1 on a one-GPU box: the whole multi-rank path -- process group over
             # RCCL, broadcasts, the library's communicator, the all-gather pair of every half-step -- with one rank)
             extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
+            if not args.no_workflow:
+                # configs[3] as a whole workflow, its simulated light curves cut into one block per rank
+                dist.barrier()
+                t1 = time.perf_counter()
+                wf = workflow_probe().run(sharded=True, device=local_dev)
+                wall = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+                wf["whole_test_s_max_over_ranks"] = float(wall.item())
+                wf["ranks"] = world
+                extras["workflow_config3_sharded"] = wf
     if world == 1 and not args.no_extras:
         # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status
         reps = max(3, min(args.steps, 10))
@@ -639,11 +659,7 @@ def main():
             line["config2_raw_kernel"] = raw_kernel_config2(local_dev)
             line["other_configs"] = single_lightcurve_configs()
             if not args.no_workflow:
-                import importlib.util
-                spec = importlib.util.spec_from_file_location("config3_probe", os.path.join(ROOT, "scripts", "config3_probe.py"))
-                probe = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(probe)
-                line["workflow_config3"] = probe.run()
+                line["workflow_config3"] = workflow_probe().run()
         print(json.dumps(line), flush=True)
 
     eng.close()

@@ -453,16 +453,27 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         // as one holding 250 (J = 10: ~10 ms each), and one after the other on the same stream they
         // add up.  The structures work on disjoint evaluations, so each gets its own stream: forked
         // after the expansion, joined before whatever follows on `s`.
-        const bool fan_out = small_ok && nsig > 1 && nsig - 1 <= MTG_MAX_J / 2;
+        // The serial sweep is latency bound in the same way -- N dependent steps, ~0.4 us each, whatever the number of
+        // rows -- and a sampler's half-step of 256 000 walkers with a handful of them over-damped paid 14.9 ms for
+        // the first structure and 3.2-4.3 ms more for those few (profiles/r03_c3_halfstep_trace.txt).  On their own
+        // stream they take wave slots as the big launch frees them and finish under it.
+        static const bool sweep_fan_out = !(getenv("MTG_SWEEP_FANOUT") && atoi(getenv("MTG_SWEEP_FANOUT")) == 0);
+        const bool fan_out = (small_ok || sweep_fan_out) && nsig > 1 && nsig - 1 <= MTG_MAX_J / 2;
         if (fan_out) {
             if (!ctx->fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming));
+            int prio_low = 0, prio_high = 0;
+            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
             for (int k = 0; k + 1 < nsig; ++k) {
-                if (!ctx->side[k]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+                // (above the caller's stream: the few rows of a rare structure should not queue behind the common one)
+                if (!ctx->side[k]) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, prio_high));
                 if (!ctx->side_done[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_done[k], hipEventDisableTiming));
             }
             HIP_TRY(ctx, hipEventRecord(ctx->fork, s));
         }
-        for (int k = 0; k < nsig; ++k) {
+        // the side streams first: their (usually few) waves are resident before the common structure's launch fills
+        // every slot its registers allow (J = 6: two waves of 204 VGPRs leave no room for a third of 166)
+        for (int kk = 0; kk < nsig; ++kk) {
+            const int k = fan_out ? nsig - 1 - kk : kk;
             const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
             mtg_solve_launcher fn = mtg_find_solver(nr, nc, m.last_b0);
             if (!fn) continue;
@@ -489,11 +500,11 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
                 const int rc = sweep_launch(ctx, fn, sa, B, k, sk);
                 if (rc) return rc;
             }
-            if (sk != s) {
-                HIP_TRY(ctx, hipEventRecord(ctx->side_done[k - 1], sk));
-                HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->side_done[k - 1], 0));
-            }
+            if (sk != s) HIP_TRY(ctx, hipEventRecord(ctx->side_done[k - 1], sk));
         }
+        if (fan_out)
+            for (int k = 1; k < nsig; ++k)
+                if (mtg_find_solver(m.nr0 + 2 * k, m.nc0 - k, m.last_b0)) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->side_done[k - 1], 0));
     }
     HIP_TRY(ctx, hipGetLastError());
     return MTG_OK;

@@ -298,9 +298,12 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     if not model.device_terms:
         raise ValueError("the lock-step driver needs device-expandable terms")
     model.y_offset = None                         # offsets are per light curve, owned by the evaluator
+    import time
+    clock = [("start", time.perf_counter())]
     ev = None
     if evaluate is None:
         ev = LogProbEvaluator(times, Y, DY + 1e-12, device=device, y_offset=Y.mean(axis=1))
+        clock.append(("upload", time.perf_counter()))
 
         def evaluate(theta, lc, add_prior):
             return ev.evaluate(model, theta, lc, add_prior=add_prior)
@@ -319,8 +322,10 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     if fit:
         fit_x, fit_f, _ = batched_minimize(lambda x, lc: -checked(x, lc, False), centers, lower, upper)
         centers, fit_f = fit_x, -fit_f
+        clock.append(("fit", time.perf_counter()))
     rng = np.random.default_rng(seed)
     p0 = _spread(rng, centers, lower, upper, walkers)
+    clock.append(("spread", time.perf_counter()))
     if device_sampler and ev is not None:
         from .device_sampler import DeviceEnsembleSampler
         dev = DeviceEnsembleSampler(lambda: ev._bind(model), walkers, P, n_ensembles=L,
@@ -333,6 +338,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
         sampler = EnsembleBatchSampler(L, walkers, P, lambda x, lc: checked(x, lc, True), seed=rng,
                                        store_chain=store_chain)
         sampler.run(p0, max_steps)
+    clock.append(("sample", time.perf_counter()))
     if store_chain:
         tau = sampler.get_autocorr_time(tol=0)
         mean_tau = np.mean(tau, axis=1)
@@ -344,11 +350,15 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
         thin = np.ones(L, dtype=int)
         discard = np.zeros(L, dtype=int)
     names = tuple("kernel:" + n for n in kernel.get_parameter_names())
-    return BatchPosteriors(sampler, tau, discard, thin, fit_x, fit_f, names)
+    res = BatchPosteriors(sampler, tau, discard, thin, fit_x, fit_f, names)
+    clock.append(("collect", time.perf_counter()))
+    res.seconds = {b[0]: b[1] - a[1] for a, b in zip(clock[:-1], clock[1:])}   # wall time of each phase
+    return res
 
 
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
-                   sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False):
+                   sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
+                   sharded=False, group=None):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -358,7 +368,16 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     3. both kernels refitted to every simulated light curve in lock-step;
     4. p-value of ``T_obs`` in the simulated distribution.
 
-    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves).
+    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves, seconds) -- ``seconds``:
+    wall time of the observed chains, the simulation and the two refits on this process.
+
+    ``sharded`` (inside a ``torch.distributed`` job, one process per GPU, every rank calling with the same
+    arguments and its own ``device``; BASELINE configs[3]): steps 2 and 3 -- the loop over simulated light curves
+    of tutorial_ppp.ipynb:326-343 -- are cut into contiguous blocks, one per rank (``distributed.LightcurveShard``):
+    rank r simulates and refits only its block, nothing is exchanged meanwhile, and ONE all-gather per model of the
+    maxima of lnL (8 bytes per light curve) gives every rank the whole ``T_sim``.  Step 1 runs on every rank; rank
+    0's posterior samples and ``T_obs`` are broadcast so that all ranks test the same thing.  ``sim_null``,
+    ``sim_alt`` and ``lightcurves`` then hold the rank's own block.
     """
     from .gpmodelling import GPModelling
     from .simulator import Simulator
@@ -376,29 +395,51 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
             np.random.set_state(state)
         return g
 
+    import time
+    clock = [time.perf_counter()]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         null, alt = observed(null_kernel), observed(alt_kernel)
+    clock.append(time.perf_counter())
     # one estimator on both sides of the test: the largest log-posterior over everything the chains
     # visited (the refits below store no chains and keep exactly that; the maximum over the burned-in,
     # thinned chain is systematically smaller, the more so the more parameters a model has)
     t_obs = float(lrt_statistic(null.best_loglikelihood, alt.best_loglikelihood))
     samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
-    sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
-                    lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
-                    extension_factor=extension_factor, random_state=int(rng.integers(0, 2 ** 31 - 1)), device=device)
-    out = sim.simulate(samples[:, :null_kernel.vector_size])
+    sim_seed, fit_seeds = int(rng.integers(0, 2 ** 31 - 1)), [int(rng.integers(0, 2 ** 62)) for _ in range(2)]
+    lo, hi, shard = 0, nsims, None
+    if sharded:
+        from .distributed import LightcurveShard, broadcast_array
+        shard = LightcurveShard(nsims, group=group)
+        head = broadcast_array(np.concatenate([[t_obs], samples.ravel()]), group)   # rank 0's test, everybody's test
+        t_obs, samples = float(head[0]), head[1:].reshape(samples.shape)
+        lo, hi = shard.lo, shard.hi
+        sim_seed = (sim_seed + 7919 * shard.rank) % (2 ** 31 - 1)                    # independent noise on every rank
+        fit_seeds = [f + 7919 * shard.rank for f in fit_seeds]
     sw = sim_walkers or walkers
-    fits = []
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        for kernel in (null_kernel, alt_kernel):
-            fits.append(derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
-                                                max_steps=sim_steps, fit=True, seed=int(rng.integers(0, 2 ** 62)),
-                                                device=device, store_chain=False, quiet=True))
-    t_sim = lrt_statistic(fits[0].max_loglikelihood, fits[1].max_loglikelihood)
+    out, fits, best = None, [None, None], [np.empty(0), np.empty(0)]
+    if hi > lo:
+        sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
+                        lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
+                        extension_factor=extension_factor, random_state=sim_seed, device=device)
+        out = sim.simulate(samples[lo:hi, :null_kernel.vector_size])
+        clock.append(time.perf_counter())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for k, kernel in enumerate((null_kernel, alt_kernel)):
+                fits[k] = derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
+                                                  max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
+                                                  store_chain=False, quiet=True)
+                best[k] = fits[k].max_loglikelihood
+                clock.append(time.perf_counter())
+    if sharded:   # the only exchange of the loop: the maxima of lnL, one all-gather per model
+        best = [shard.gather(b) for b in best]
+    t_sim = lrt_statistic(best[0], best[1])
+    clock.append(time.perf_counter())
+    seconds = dict(zip(("observed_chains", "simulate", "refit_null", "refit_alt", "gather"), np.diff(clock))) \
+        if len(clock) == 6 else {"observed_chains": clock[1] - clock[0]}
     return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
-                sim_null=fits[0], sim_alt=fits[1], lightcurves=out)
+                sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds)
 
 
 def derive_posteriors_sharded(times, Y, DY, kernel, group=None, device=None, **kwargs):

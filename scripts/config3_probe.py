@@ -18,8 +18,9 @@ from mind_the_gaps_amd.simulator import Simulator
 AMP, OTHER = (-10, 50), (-10, 10)
 
 
-def run(nsims=2000, N=10000, W=256, steps=500):
-    """-> dict (the JSON line of this script).  bench.py calls it for its `workflow_config3` entry."""
+def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0):
+    """-> dict (the JSON line of this script).  bench.py calls it for its `workflow_config3` entry; ``sharded``: inside
+    a torch.distributed job, the simulated light curves split over the ranks (ppp.protassov_test(sharded=True))."""
     th = synth.truth(synth.ALT_MODEL)
     rng = np.random.default_rng(20250704 + 3)
     times = synth.make_times(N, rng)
@@ -35,7 +36,8 @@ def run(nsims=2000, N=10000, W=256, steps=500):
 
     # the "observed" light curve: one realisation of the null process on the irregular sampling
     t0 = time.perf_counter()
-    sim = Simulator(null_kernel(), times, exposure, mean, "Gaussian", sigma_noise=1.0, extension_factor=2, random_state=3)
+    sim = Simulator(null_kernel(), times, exposure, mean, "Gaussian", sigma_noise=1.0, extension_factor=2, random_state=3,
+                    device=device)
     rates = sim.generate_lightcurve()
     noisy, dy = sim.add_noise(rates)
     lc = GappyLightcurve(times, noisy, dy, exposures=exposure)
@@ -45,13 +47,14 @@ def run(nsims=2000, N=10000, W=256, steps=500):
         warnings.simplefilter("ignore")
         t0 = time.perf_counter()
         res = protassov_test(lc, null_kernel(), alt_kernel(), nsims=nsims, walkers=W, max_steps=1000, sim_walkers=W,
-                             sim_steps=steps, sigma_noise=1.0, extension_factor=2, seed=1)
+                             sim_steps=steps, sigma_noise=1.0, extension_factor=2, seed=1, device=device, sharded=sharded)
         el = time.perf_counter() - t0
     evals = 2 * nsims * W * (steps + 1)
     return {
-        "workflow": "protassov_test, BASELINE configs[3] on one GPU",
+        "workflow": "protassov_test, BASELINE configs[3]" + (", simulated light curves sharded over the ranks" if sharded else " on one GPU"),
         "nsims": nsims, "N": N, "walkers": W, "refit_steps": steps, "fft_points_per_simulation": sim.fftndatapoints,
         "observed_lightcurve_s": t_obs_sim, "whole_test_s": el,
+        "seconds": {k: float(v) for k, v in res["seconds"].items()},
         "refit_evaluations": evals, "refit_evaluations_per_s_end_to_end": evals / el,
         "T_obs": res["T_obs"], "p_value": res["p_value"],
         "T_sim_quantiles_50_90_99": [float(q) for q in np.quantile(res["T_sim"], [0.5, 0.9, 0.99])],

@@ -308,6 +308,62 @@ def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
     assert np.isfinite(float(r0["best"]))
 
 
+# ---- the Protassov test with its simulated light curves sharded (BASELINE configs[3] as a workflow) ---------
+
+def _protassov_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    guard = _watchdog(out_dir, "ppp%d_%d" % (world, rank))
+    import warnings
+    import torch.distributed as dist
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
+    from mind_the_gaps_amd.ppp import protassov_test
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
+    th = synth.truth(synth.ALT_MODEL)
+    t, y, dy = synth.make_lightcurves(200, 1, seed=43)
+    lc = GappyLightcurve(t, y[0] + 50.0, dy[0], exposures=0.5 * np.diff(t).min())
+    null = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)])
+    alt = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)]) + Lorentzian(
+        th[5], th[6], th[7], bounds=[(-10, 50), (-10, 10), (-10, 10)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = protassov_test(lc, null, alt, nsims=5, walkers=16, max_steps=60, sim_steps=40, seed=11, sharded=world > 1)
+    n_local = 0 if res["lightcurves"] is None else len(res["lightcurves"]["rates"])
+    local = (np.empty(0) if res["sim_null"] is None else
+             -2.0 * (res["sim_null"].max_loglikelihood - res["sim_alt"].max_loglikelihood))
+    np.savez(os.path.join(out_dir, "pt%d_%d.npz" % (world, rank)), T_obs=res["T_obs"], T_sim=res["T_sim"],
+             p=res["p_value"], n_local=n_local, local=local)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+    guard.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
+    """ppp.protassov_test(sharded=True) on two ranks (sharing the box's GPU, gloo): both end with the same T_obs,
+    T_sim and p-value; T_sim is rank 0's block of 3 followed by rank 1's block of 2, each the rank's own refits."""
+    world = 2
+    _spawn(_protassov_worker, (world, _free_port(), str(tmp_path)), world, tmp_path)
+    r0, r1 = (np.load(tmp_path / ("pt2_%d.npz" % r)) for r in range(world))
+    assert float(r0["T_obs"]) == float(r1["T_obs"]) and float(r0["p"]) == float(r1["p"])
+    assert np.array_equal(r0["T_sim"], r1["T_sim"]) and r0["T_sim"].shape == (5,)
+    assert (int(r0["n_local"]), int(r1["n_local"])) == (3, 2)
+    assert np.allclose(r0["T_sim"][:3], r0["local"], rtol=1e-12) and np.allclose(r0["T_sim"][3:], r1["local"], rtol=1e-12)
+    assert np.all(np.isfinite(r0["T_sim"])) and 0.0 <= float(r0["p"]) <= 1.0
+    # one rank alone holds everything and the unsharded call is untouched by the new arguments
+    _spawn(_protassov_worker, (1, _free_port(), str(tmp_path)), 1, tmp_path)
+    single = np.load(tmp_path / "pt1_0.npz")
+    assert int(single["n_local"]) == 5 and np.all(np.isfinite(single["T_sim"]))
+    assert np.isclose(float(single["T_obs"]), float(r0["T_obs"]), rtol=1e-9)      # same seed, same observed chains
+
+
 # ---- the device-resident sampler, walker-sharded (mtg_ensemble_shard_*) -------------------------------------
 
 class _FakeShardEngine:
