@@ -41,6 +41,9 @@ The JSON line also carries
                     single-light-curve chains, configs[3] as a whole workflow (scripts/config3_probe.py);
   workflow_config3_sharded: (N > 1) ppp.protassov_test(sharded=True): every rank simulates and refits its block
                     of the 2000 light curves, one all-gather of the maxima per model; time = max over ranks;
+                    (both N > 1 extras run after the timed region under --extras-timeout: if one of them fails or
+                    hangs on some rank, rank 0 still prints the line, with `multi_rank_extras_error` saying what
+                    happened; MTG_BENCH_FAIL_EXTRAS=<rank> rehearses that)
   cpu_baseline    : oracle/celerite_ref.c (a plain-C port of celerite's algorithm, fused one-sweep
                     variant, built -O3 -march=native on this host) single thread and on all usable
                     cores, bounded sample (rank 0, N = 1 only).
@@ -82,6 +85,9 @@ def parse():
                     help="default: strong when --gpus > 1 (the light curves are split over the ranks)")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-workflow", action="store_true", help="skip configs[3] as a workflow (~30 s)")
+    ap.add_argument("--extras-timeout", type=int, default=300,
+                    help="N > 1: seconds the walker-sharded configs and the sharded workflow may take after the timed "
+                         "region before the line is printed without them")
     return ap.parse_args()
 
 
@@ -513,81 +519,11 @@ def main():
         raise SystemExit("bench: non-finite log-likelihoods in the timed batch")
 
     extras = {}
-    if grouped:
-        extras["rccl_ranks"] = {"torch_distributed_world": dist.get_world_size(), "backend": dist.get_backend()}
-        if not args.no_extras and (world > 1 or os.environ.get("MTG_SHARD_ONE_RANK") == "1"):
-            # (MTG_BENCH_FORCE_DIST=1 MTG_SHARD_ONE_RANK=1 on a one-GPU box: the whole multi-rank path -- process group over
-            # RCCL, broadcasts, the library's communicator, the all-gather pair of every half-step -- with one rank)
-            extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
-            if not args.no_workflow:
-                # configs[3] as a whole workflow, its simulated light curves cut into one block per rank
-                dist.barrier()
-                t1 = time.perf_counter()
-                wf = workflow_probe().run(sharded=True, device=local_dev)
-                wall = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-                dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-                wf["whole_test_s_max_over_ranks"] = float(wall.item())
-                wf["ranks"] = world
-                extras["workflow_config3_sharded"] = wf
-    if world == 1 and not args.no_extras:
-        # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status
-        reps = max(3, min(args.steps, 10))
-        eng.loglike(theta, lc, add_prior=True)
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            eng.loglike(theta, lc, add_prior=True)
-        e2e = (time.perf_counter() - t1) / reps
-        extras["end_to_end"] = {"value": B / e2e, "unit": "evals/s", "ms_per_step": e2e * 1e3,
-                                "what": "mtg_loglike_batch: pageable host theta [B][P] + light-curve index up, kernels, "
-                                        "lnP + status down, every step (%d MB + %d MB over PCIe)"
-                                        % (theta.nbytes // 2**20 + lc.nbytes // 2**20, (B * 12) // 2**20)}
-        # (b) the share one GPU gets of the 2000 light curves at 8 GPUs: is a 1/8 batch still efficient?
-        L8 = max(1, L // 8)
-        B8 = L8 * W
-        for _ in range(3):
-            sweep(B8)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(4 * reps):
-            sweep(B8)
-        torch.cuda.synchronize(dev)
-        dt8 = (time.perf_counter() - t1) / (4 * reps)
-        extras["strong_shard_8"] = {"lightcurves": L8, "evals_per_step": B8, "ms_per_step": dt8 * 1e3,
-                                    "evals_per_s": B8 / dt8,
-                                    "per_gpu_factor": (B8 / dt8) / (B * args.steps / elapsed),
-                                    "what": "one MI355X sweeping 1/8 of the light curves (its share at 8 GPUs, ~1 wave per "
-                                            "SIMD); 8 x per_gpu_factor is the strong-scaling speed-up the kernels allow "
-                                            "before the all-gather of 2000 doubles"}
-        # (c) the NULL model's sweep over the same light curves (configs[3] fits both models; SURVEY 8(d) Config 4)
-        nkinds = synth.NULL_MODEL
-        nfull, nfree, nbounds = synth.model_spec(nkinds, y, per_lc_mean=True)
-        eng.set_model(nkinds, nfull, nfree, nbounds)
-        d_theta0 = torch.from_numpy(synth.draw_thetas(nkinds, B, seed=20250704 + 41)).to(dev)
-        for _ in range(2):
-            sweep(B, d_theta0)
-        torch.cuda.synchronize(dev)
-        eng.profile_begin(reps)
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            sweep(B, d_theta0)
-        torch.cuda.synchronize(dev)
-        dt0 = (time.perf_counter() - t1) / reps
-        _, solve0 = eng.profile_read()
-        n_ok0 = int((d_status.cpu().numpy() == 0).sum())
-        k0 = eng.last_solver
-        s0 = float(np.mean(solve0)) * 1e-3
-        flop0 = FLOP_PER_SAMPLE.get(k0)
-        extras["null_model_sweep"] = {
-            "model": "DRW+SHO (J=3, P=5)", "evals_per_step": B, "ms_per_step": dt0 * 1e3, "evals_per_s": B / dt0,
-            "kernel": k0, "kernel_ms": s0 * 1e3,
-            "algorithmic_hbm_frac": n_ok0 * (24 * N + 8 * 5 + 12) / s0 / 1e9 / HBM_PEAK_GBS,
-            "fp64_valu_frac": None if flop0 is None else n_ok0 * N * flop0 / s0 / 1e12 / FP64_PEAK_TFLOPS,
-            "both_models_evals_per_s": 2 * B / (dt0 + elapsed / args.steps)}
-        eng.set_model(kinds, full, free, bounds)
+    solve_s = float(np.mean(solve_ms)) * 1e-3
 
-    if rank == 0:
+    def headline_line():
+        """The contract's JSON line from the timed region alone (+ whatever `extras` holds by now)."""
         bytes_eval = 24 * N + 8 * P + 12
-        solve_s = float(np.mean(solve_ms)) * 1e-3
         achieved = n_ok * bytes_eval / solve_s / 1e9
         flop = FLOP_PER_SAMPLE.get(kernel_name)
         traffic, traffic_source = None, None
@@ -650,6 +586,114 @@ def main():
         line.update(extras)
         if oversubscribed:
             line["oversubscribed"] = "%d ranks on %d GPU(s): rehearsal of the multi-rank path, not a scaling number" % (world, ndev)
+        line.setdefault("cpu_baseline", None)
+        return line
+
+    if grouped:
+        extras["rccl_ranks"] = {"torch_distributed_world": dist.get_world_size(), "backend": dist.get_backend()}
+        if not args.no_extras and (world > 1 or os.environ.get("MTG_SHARD_ONE_RANK") == "1"):
+            # (MTG_BENCH_FORCE_DIST=1 MTG_SHARD_ONE_RANK=1 on a one-GPU box: the whole multi-rank path -- process group over
+            # RCCL, broadcasts, the library's communicator, the all-gather pair of every half-step -- with one rank)
+            # The timed region is over and agreed on by every rank.  What follows runs collectives that no one-GPU box
+            # can rehearse with more than one RCCL rank: a failure or a hang in them must not take the scaling number
+            # with it.  A rank that fails says so in the line ("error") and on stderr; a rank that hangs is ended by
+            # the timer below, rank 0 printing the line with what it has.
+            import threading
+            import traceback
+
+            def bail():
+                sys.stderr.write("bench: rank %d: multi-rank extras still running after %d s, giving up on them\n"
+                                 % (rank, args.extras_timeout))
+                if rank == 0:
+                    extras["multi_rank_extras_error"] = "timed out after %d s" % args.extras_timeout
+                    print(json.dumps(headline_line()), flush=True)
+                sys.stdout.flush()
+                os._exit(0)
+
+            timer = threading.Timer(args.extras_timeout, bail)
+            timer.daemon = True
+            timer.start()
+            try:
+                if os.environ.get("MTG_BENCH_FAIL_EXTRAS") == str(rank):     # rehearsal of this guard
+                    raise RuntimeError("injected failure (MTG_BENCH_FAIL_EXTRAS)")
+                extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
+                if not args.no_workflow:
+                    # configs[3] as a whole workflow, its simulated light curves cut into one block per rank
+                    dist.barrier()
+                    t1 = time.perf_counter()
+                    wf = workflow_probe().run(sharded=True, device=local_dev)
+                    wall = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=gdev)
+                    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+                    wf["whole_test_s_max_over_ranks"] = float(wall.item())
+                    wf["ranks"] = world
+                    extras["workflow_config3_sharded"] = wf
+                dist.barrier()        # every rank got through: nobody is left inside a collective
+                timer.cancel()
+            except BaseException as exc:     # this rank failed: the others find out at the timer
+                traceback.print_exc()
+                extras["multi_rank_extras_error"] = "rank %d: %r" % (rank, exc)
+                if rank == 0:
+                    print(json.dumps(headline_line()), flush=True)
+                    os._exit(0)
+                timer.join()                 # (rank 0 may be waiting for this rank inside a collective: let its timer print)
+    if world == 1 and not args.no_extras:
+        # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status
+        reps = max(3, min(args.steps, 10))
+        eng.loglike(theta, lc, add_prior=True)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.loglike(theta, lc, add_prior=True)
+        e2e = (time.perf_counter() - t1) / reps
+        extras["end_to_end"] = {"value": B / e2e, "unit": "evals/s", "ms_per_step": e2e * 1e3,
+                                "what": "mtg_loglike_batch: pageable host theta [B][P] + light-curve index up, kernels, "
+                                        "lnP + status down, every step (%d MB + %d MB over PCIe)"
+                                        % (theta.nbytes // 2**20 + lc.nbytes // 2**20, (B * 12) // 2**20)}
+        # (b) the share one GPU gets of the 2000 light curves at 8 GPUs: is a 1/8 batch still efficient?
+        L8 = max(1, L // 8)
+        B8 = L8 * W
+        for _ in range(3):
+            sweep(B8)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(4 * reps):
+            sweep(B8)
+        torch.cuda.synchronize(dev)
+        dt8 = (time.perf_counter() - t1) / (4 * reps)
+        extras["strong_shard_8"] = {"lightcurves": L8, "evals_per_step": B8, "ms_per_step": dt8 * 1e3,
+                                    "evals_per_s": B8 / dt8,
+                                    "per_gpu_factor": (B8 / dt8) / (B * args.steps / elapsed),
+                                    "what": "one MI355X sweeping 1/8 of the light curves (its share at 8 GPUs, ~1 wave per "
+                                            "SIMD); 8 x per_gpu_factor is the strong-scaling speed-up the kernels allow "
+                                            "before the all-gather of 2000 doubles"}
+        # (c) the NULL model's sweep over the same light curves (configs[3] fits both models; SURVEY 8(d) Config 4)
+        nkinds = synth.NULL_MODEL
+        nfull, nfree, nbounds = synth.model_spec(nkinds, y, per_lc_mean=True)
+        eng.set_model(nkinds, nfull, nfree, nbounds)
+        d_theta0 = torch.from_numpy(synth.draw_thetas(nkinds, B, seed=20250704 + 41)).to(dev)
+        for _ in range(2):
+            sweep(B, d_theta0)
+        torch.cuda.synchronize(dev)
+        eng.profile_begin(reps)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sweep(B, d_theta0)
+        torch.cuda.synchronize(dev)
+        dt0 = (time.perf_counter() - t1) / reps
+        _, solve0 = eng.profile_read()
+        n_ok0 = int((d_status.cpu().numpy() == 0).sum())
+        k0 = eng.last_solver
+        s0 = float(np.mean(solve0)) * 1e-3
+        flop0 = FLOP_PER_SAMPLE.get(k0)
+        extras["null_model_sweep"] = {
+            "model": "DRW+SHO (J=3, P=5)", "evals_per_step": B, "ms_per_step": dt0 * 1e3, "evals_per_s": B / dt0,
+            "kernel": k0, "kernel_ms": s0 * 1e3,
+            "algorithmic_hbm_frac": n_ok0 * (24 * N + 8 * 5 + 12) / s0 / 1e9 / HBM_PEAK_GBS,
+            "fp64_valu_frac": None if flop0 is None else n_ok0 * N * flop0 / s0 / 1e12 / FP64_PEAK_TFLOPS,
+            "both_models_evals_per_s": 2 * B / (dt0 + elapsed / args.steps)}
+        eng.set_model(kinds, full, free, bounds)
+
+    if rank == 0:
+        line = headline_line()
         if world == 1 and args.cpu_seconds > 0 and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds, bounds, out, status)
         else:
