@@ -201,8 +201,14 @@ def batched_minimize(fun, x0, lower, upper, max_iter=60, history=8, fd_step=1e-6
         active &= ~todo                                                   # line search failed: stop there
         f_old = f
         g_old = g
-        moved = np.any(x_new != x, axis=1)
         f_try, g_try = value_and_grad(x_new)
+        # The line search and the gradient batch differ in size and may run on different solver families (time-parallel
+        # scan / serial sweep), which can disagree on positive-definiteness at the very edge: a point the line search
+        # accepted and the gradient batch rejects is not taken.
+        lost = ~np.isfinite(f_try) | ~np.all(np.isfinite(g_try), axis=1)
+        if lost.any():
+            x_new[lost], f_try[lost], g_try[lost] = x[lost], f[lost], g[lost]
+        moved = np.any(x_new != x, axis=1)
         s_vec, y_vec = x_new - x, g_try - g_old
         good = np.einsum("lp,lp->l", s_vec, y_vec) > 1e-12
         S.append(np.where(good[:, None], s_vec, 0.0))

@@ -69,3 +69,22 @@ def test_batched_minimize_box_constrained_quadratics():
     want = np.clip(centers, lower, upper)                      # separable: the box solution is the clip
     assert np.allclose(x, want, atol=2e-4)
     assert np.allclose(f, fun(want, np.arange(L)), atol=1e-6) and it < 60
+
+
+def test_batched_minimize_keeps_the_last_good_point_when_the_gradient_batch_rejects_a_step():
+    """The line search (L rows) and the gradient batch (L (P + 1) rows) may run on different solver families on the
+    device; a point accepted by the first and found unfactorisable by the second must not be adopted."""
+    L, P = 5, 2
+    centers = np.arange(L * P, dtype=float).reshape(L, P) / 5.0 + 0.3
+
+    def fun(x, lc):
+        f = np.sum((x - centers[lc]) ** 2, axis=1) + 1.0
+        if len(x) == L * (P + 1):                                # the gradient batch: problem 3 fails away from 0
+            f = np.where((lc == 3) & np.any(np.abs(x) > 1e-3, axis=1), np.inf, f)
+        return f
+
+    x, f, _ = batched_minimize(fun, np.zeros((L, P)), np.full(P, -5.0), np.full(P, 5.0))
+    assert np.all(np.isfinite(f)) and np.all(np.isfinite(x))
+    assert np.array_equal(x[3], np.zeros(P)) and np.isclose(f[3], 1.0 + np.sum(centers[3] ** 2))
+    keep = np.arange(L) != 3
+    assert np.allclose(x[keep], centers[keep], atol=2e-4)
