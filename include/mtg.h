@@ -160,7 +160,10 @@ MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, cons
  * swept in the order of a stable sort by (structure, light curve) of the library's own making, whatever
  * order the caller's rows have (results are per row and do not depend on it); mtg_set_sort: 0 = keep the
  * caller's order, 1 = always sort, 2 (default) = sort unless the host-pointer entry point sees that the
- * rows are grouped by light curve already.
+ * rows are grouped by light curve already.  A model whose rows fall into more than one structure (an SHO
+ * term on either side of Q = 1/2) is always swept in sorted order under 1 and 2: the per-structure lists
+ * are filled with atomics, and only the sort makes the assignment of rows to waves -- on which the last
+ * bits of a row can depend, see MTG_TRIG_FAST_MAX -- the same in every run, as a seeded chain needs it.
  */
 #define MTG_STREAM_CONTEXT ((void *)(intptr_t)-1)
 MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_theta,

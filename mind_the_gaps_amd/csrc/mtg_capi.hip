@@ -422,9 +422,14 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
     // The serial sweep reads each lane's own light curve: sort the evaluations by (structure, light curve) unless the
     // caller's order is known to be grouped (mtg_sort.hip).  One light curve, or no index at all: nothing to sort.
+    // More than one structure: the per-structure lists are appended to with one atomic per wave, so their order -- which
+    // rows share a wave -- changes from run to run, and a row's last bits may depend on its wave (a lane with a huge
+    // d dx sends the whole wave through the libm sincos).  A seeded chain has to be reproducible: the stable sort gives
+    // the lanes of every structure the caller's order, whatever the arrival order of the waves was.
     const int *sorted = nullptr;
-    if (may_sort && !small_ok && d_lc && ctx->L > 1 && B > 64 && (uint64_t)ctx->L * (uint64_t)nsig < 0x7fffffffull &&
-        (ctx->sort_mode == 1 || (ctx->sort_mode == 2 && !ctx->lc_grouped_hint))) {
+    const bool for_order = may_sort && d_lc && ctx->L > 1 && (ctx->sort_mode == 1 || (ctx->sort_mode == 2 && !ctx->lc_grouped_hint));
+    const bool for_determinism = nsig > 1 && ctx->sort_mode != 0;
+    if ((for_order || for_determinism) && !small_ok && B > 64 && (uint64_t)ctx->L * (uint64_t)nsig < 0x7fffffffull) {
         mtg_trace::Range range("mtg:sort (evaluations by structure, light curve)");
         const size_t tmp = mtg_sort_temp_bytes(B, mtg_sort_key_bits(ctx->L, nsig));
         HIP_TRY(ctx, ctx->sort_keys.reserve((size_t)B * 4));

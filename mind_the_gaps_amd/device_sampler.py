@@ -92,7 +92,8 @@ class DeviceEnsembleSampler:
 
     def run_mcmc(self, initial_state, nsteps):
         eng = self._bind()
-        eng.start_fft_warmup()   # the convergence checks may want the device (see _autocorr_time_where_it_is_cheapest)
+        if self.store_chain:         # the convergence checks may want the device (see _autocorr_time_where_it_is_cheapest)
+            eng.start_fft_warmup()
         if initial_state is not None:
             p0 = np.asarray(initial_state, dtype=np.float64)
             if p0.ndim == 2:

@@ -267,10 +267,29 @@ def _iptr(a):
     return a.ctypes.data_as(_ip) if a is not None else None
 
 
+def _one_thread_at_a_time(method):
+    """An ``mtg_ctx`` is not re-entrant: a second thread that re-uploads light curves while the first one's kernels are
+    in flight ends in a GPU memory fault.  Calls from another thread while one is inside the library are refused."""
+    import functools
+
+    @functools.wraps(method)
+    def guarded(self, *args, **kwargs):
+        if not self._busy.acquire(blocking=False):
+            raise EngineError(E_STATE, "this Engine is inside a call made by another thread; an mtg_ctx serves one "
+                                       "thread at a time -- give every thread its own Engine")
+        try:
+            return method(self, *args, **kwargs)
+        finally:
+            self._busy.release()
+    return guarded
+
+
 class Engine:
     """One MI355X with resident light curves and a model (an ``mtg_ctx``)."""
 
     def __init__(self, device=0):
+        import threading
+        self._busy = threading.RLock()
         self._lib = load_library()
         self._ctx = self._lib.mtg_create(int(device))
         if not self._ctx:
@@ -650,3 +669,10 @@ class Engine:
     @property
     def last_kernel_ms(self):
         return float(self._lib.mtg_last_kernel_ms(self._ctx))
+
+
+for _name in ("set_lightcurves", "set_lightcurves_device", "set_model", "loglike", "loglike_device", "loglike_coeffs",
+              "ensemble_init", "ensemble_run", "ensemble_restore", "ensemble_state", "chain_autocorr", "simulate_tk95",
+              "tk95_observe_series", "predict", "apply_inverse", "math_probe"):
+    setattr(Engine, _name, _one_thread_at_a_time(getattr(Engine, _name)))
+del _name

@@ -110,9 +110,11 @@ class LogProbEvaluator:
     (gpmodelling.py:54); the device squares it.
     """
 
-    def __init__(self, t, y, yerr, device=0, y_offset=None):
+    def __init__(self, t, y, yerr, device=0, y_offset=None, own_engine=False):
         """``y_offset``: [L] frozen per-light-curve means; when None a model with a frozen
-        constant mean supplies its value for every light curve."""
+        constant mean supplies its value for every light curve.  ``own_engine``: a context of its own instead of
+        the process-wide one of ``get_engine`` (for work that runs beside other work on the same GPU, from another
+        host thread; ``close()`` frees it)."""
         self.t = np.ascontiguousarray(t, dtype=np.float64)
         self.y = np.atleast_2d(np.ascontiguousarray(y, dtype=np.float64))
         self.yerr = np.atleast_2d(np.ascontiguousarray(yerr, dtype=np.float64))
@@ -123,6 +125,15 @@ class LogProbEvaluator:
         self._model_sig = None
         self._bound_offset = None
         self._token = object()
+        self._own = None
+        if own_engine:
+            self._own = _engine.Engine(device)
+            self._own.bound_to = None
+
+    def close(self):
+        if self._own is not None:
+            self._own.close()
+            self._own = None
 
     @property
     def n_lightcurves(self):
@@ -135,7 +146,7 @@ class LogProbEvaluator:
         return self._bind(_NoModel())
 
     def _bind(self, model):
-        eng = get_engine(self.device)
+        eng = self._own if self._own is not None else get_engine(self.device)
         offset = self.y_offset if self.y_offset is not None else getattr(model, "y_offset", None)
         key = None if offset is None else np.asarray(offset, dtype=np.float64).tobytes()
         if eng.bound_to is not self._token or key != self._bound_offset:

@@ -18,7 +18,7 @@ from mind_the_gaps_amd.simulator import Simulator
 AMP, OTHER = (-10, 50), (-10, 10)
 
 
-def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0):
+def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurrent_refits=False):
     """-> dict (the JSON line of this script).  bench.py calls it for its `workflow_config3` entry; ``sharded``: inside
     a torch.distributed job, the simulated light curves split over the ranks (ppp.protassov_test(sharded=True))."""
     th = synth.truth(synth.ALT_MODEL)
@@ -47,7 +47,8 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0):
         warnings.simplefilter("ignore")
         t0 = time.perf_counter()
         res = protassov_test(lc, null_kernel(), alt_kernel(), nsims=nsims, walkers=W, max_steps=1000, sim_walkers=W,
-                             sim_steps=steps, sigma_noise=1.0, extension_factor=2, seed=1, device=device, sharded=sharded)
+                             sim_steps=steps, sigma_noise=1.0, extension_factor=2, seed=1, device=device, sharded=sharded,
+                             concurrent_refits=concurrent_refits)
         el = time.perf_counter() - t0
     evals = 2 * nsims * W * (steps + 1)
     return {
@@ -64,4 +65,4 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0):
 
 if __name__ == "__main__":
     args = [int(a) for a in sys.argv[1:5]]
-    print(json.dumps(run(*args)), flush=True)
+    print(json.dumps(run(*args, concurrent_refits=os.environ.get("MTG_C3_CONCURRENT_REFITS") == "1")), flush=True)

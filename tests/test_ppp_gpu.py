@@ -137,6 +137,37 @@ def test_protassov_test_end_to_end():
     assert np.all(res["T_sim"] > -5.0)                             # nested models: alt never much worse
     assert 1 / 25 <= res["p_value"] <= 1.0 and res["p_value"] > 0.04
     assert res["lightcurves"]["rates"].shape == (24, 250)
+    # the two models' refits side by side on two contexts of their own: the same numbers as one after the other
+    both = protassov_test(lc, drw(), alt, nsims=24, walkers=16, max_steps=120, sim_steps=60, sigma_noise=2.0, seed=5,
+                          concurrent_refits=True)
+    assert np.array_equal(both["T_sim"], res["T_sim"]) and both["T_obs"] == res["T_obs"]
+    assert np.array_equal(both["sim_alt"].max_parameters, res["sim_alt"].max_parameters)
+
+
+def test_an_engine_refuses_a_second_thread_while_a_call_is_in_flight(engine):
+    """One mtg_ctx serves one thread at a time (a re-upload under another thread's running kernels is a GPU fault):
+    the Python engine says so instead."""
+    import threading
+    from mind_the_gaps_amd.engine import EngineError
+    t, y, dy = synth.make_lightcurves(50, 1, seed=3)
+    engine.set_lightcurves(t, y, dy + 1e-12)
+    held, release = threading.Event(), threading.Event()
+
+    def holder():                      # stands for a thread that is inside a long library call
+        with engine._busy:
+            held.set()
+            release.wait(30)
+
+    th = threading.Thread(target=holder)
+    th.start()
+    assert held.wait(30)
+    try:
+        with pytest.raises(EngineError, match="another thread"):
+            engine.set_lightcurves(t, y, dy + 1e-12)
+    finally:
+        release.set()
+        th.join()
+    engine.set_lightcurves(t, y, dy + 1e-12)      # free again
 
 
 def test_invariances_at_the_bench_size(engine):

@@ -99,3 +99,32 @@ def test_shard_info_of_an_unsharded_ensemble(engine):
     engine.shard_profile_begin(4)
     engine.ensemble_run(2)
     assert len(engine.shard_profile_read()) == 0        # no exchange without sharding
+
+
+@pytest.mark.gpu
+def test_two_structures_are_swept_reproducibly(engine):
+    """DRW + SHO + Lorentzian with the SHO on both sides of Q = 1/2 and frequencies up to the top of the prior box:
+    the structure lists are filled with atomics and a wave holding one row with a huge d dx takes the libm sincos for
+    all its rows, so the values used to depend on which waves arrived first.  The sweep now runs in sorted order and
+    repeats bit for bit -- also for a batch grouped by light curve, which needs no sort for locality."""
+    kinds = synth.ALT_MODEL
+    N, L, W = 400, 40, 512
+    t, y, dy = synth.make_lightcurves(N, L, seed=77)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    rng = np.random.default_rng(78)
+    lo, hi = bounds[free, 0], bounds[free, 1]
+    theta = synth.draw_thetas(kinds, L * W, seed=79)
+    wild = rng.random(L * W) < 0.3                      # a third of the rows anywhere in the box
+    theta[wild] = rng.uniform(np.maximum(lo, -8.0), np.minimum(hi, 9.0), size=(int(wild.sum()), len(lo)))
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    engine.set_time_parallel(0)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, free, bounds)
+    try:
+        first, st = engine.loglike(theta, lc, add_prior=True)
+        assert engine.last_solver.startswith("mtg_solve_kernel") and (st == 0).sum() > L * W // 2
+        for _ in range(4):
+            again, st2 = engine.loglike(theta, lc, add_prior=True)
+            assert np.array_equal(st, st2) and np.array_equal(first, again, equal_nan=True)
+    finally:
+        engine.set_time_parallel(2)
