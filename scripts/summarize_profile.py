@@ -40,7 +40,7 @@ def head_commit():
 
 
 HEAD = head_commit()
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # the latest run
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as fh:   # (every summary says which commit it measured)
     fh.write("# HEAD %s\n" % HEAD)
     for line in open(stats):   # rocPRIM's kernel names run to two thousand characters: keep what tells them apart
@@ -53,7 +53,7 @@ with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as fh:   # (every s
 
 
 def mean_counter(sub, counter):
-    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
