@@ -302,6 +302,8 @@ int sweep_launch(mtg_ctx *ctx, mtg_solve_launcher fn, MtgSolveArgs sa, int64_t B
     sa.solo = 1;
     sa.list = left_list;
     sa.count_ptr = left_count;
+    sa.seg_counts = nullptr;  // (the left-over list starts at 0, whatever segment of a sorted order it came from)
+    sa.seg_k = 0;
     sa.left_list = nullptr;
     sa.left_count = nullptr;
     fn(sa, B * 64, s);  // one wave per left-over evaluation
@@ -340,6 +342,13 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     }
     ctx->timed = true;
     return MTG_OK;
+}
+
+// MTG_SWEEP_MULTI=0 (measurements): one launch per structure even where the one-launch kernel exists
+bool sweep_multi_enabled()
+{
+    static const bool on = !(getenv("MTG_SWEEP_MULTI") && atoi(getenv("MTG_SWEEP_MULTI")) == 0);
+    return on;
 }
 
 // Launch the solver(s) for B prepared evaluations living in ctx->coef (lists / counts filled).
@@ -453,6 +462,15 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_fused_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig,
                  wide && mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256) ? 256 : 64);
         fused(sa, B, s);
+    } else if (mtg_solve_launcher multi = sorted && nsig > 1 && sa.yv_bytes <= sa.window_bytes && sweep_multi_enabled()
+                                              ? mtg_find_multi_solver(m.nr0, m.nc0, nsig, m.last_b0) : nullptr) {
+        // every structure of the sorted order in one launch of identical workgroups (mtg_kernels_multi.hip)
+        sa.list = sorted;
+        sa.count_ptr = nullptr;
+        sa.seg_counts = bank_counts(ctx);
+        sa.seg_k = 0;
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_solve_kernel_multi<%d,%d,%d,%d>", m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0);
+        multi(sa, B, s);
     } else {
         // A time-parallel launch is latency bound: a structure holding three evaluations takes as long
         // as one holding 250 (J = 10: ~10 ms each), and one after the other on the same stream they

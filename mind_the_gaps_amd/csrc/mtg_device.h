@@ -146,6 +146,9 @@ size_t mtg_sort_temp_bytes(int64_t B, int bits);
 hipError_t mtg_launch_sort_by_lightcurve(int64_t B, const int32_t *status, const int32_t *sig, const int32_t *lc, int64_t L,
                                          int nsig, uint32_t *keys_in, uint32_t *keys_out, int *order, void *temp,
                                          size_t temp_bytes, hipStream_t stream);
+// every structure of a sorted batch in one launch (mtg_kernels_multi.hip): a.list = the sorted order, a.seg_counts =
+// the rows per structure; nullptr when the combination is not compiled
+mtg_solve_launcher mtg_find_multi_solver(int nr0, int nc0, int nsig, int last_b0);
 // does mtg_find_solver(nr, nc, last_b0) return the b = 0 specialisation?
 int mtg_solver_uses_b0(int nr, int nc, int last_b0);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,

@@ -37,7 +37,7 @@ def test_sorted_sweep_matches_the_callers_order_bit_for_bit(sweep, kinds):
     for mode in (0, 1, 2):                     # caller's order, always sorted, automatic (random rows: sorted)
         eng.set_sort(mode)
         results[mode] = eng.loglike(theta, lc, add_prior=True)
-        assert eng.last_solver.startswith("mtg_solve_kernel<")
+        assert eng.last_solver.startswith("mtg_solve_kernel")   # one structure per launch, or all of them in one
     out0, st0 = results[0]
     ok = st0 == 0
     assert np.array_equal(st0, rst) and 0.3 * B < ok.sum() < 0.95 * B
