@@ -67,7 +67,10 @@ FP64_PEAK_TFLOPS = 78.6
 # FP64 operations per sample and lane of the serial sweep's inner loop, mean-free variant (`scripts/loop_stats.py NR NC
 # NB0` on the compiled loop: 2 x fma + mul/add per step)
 FLOP_PER_SAMPLE = {"mtg_solve_kernel<1,2,1>": 2 * 91 + 53, "mtg_solve_kernel<1,1,0>": 2 * 47 + 28,
-                   "mtg_solve_kernel<2,1,0>": 2 * 66 + 39}
+                   "mtg_solve_kernel<2,1,0>": 2 * 66 + 39,
+                   # every structure of the model in one launch (csrc/mtg_kernels_multi.hip): the bench's rows are all
+                   # under-damped, i.e. the same sweep loop as the one-structure kernel's
+                   "mtg_solve_kernel_multi<1,2,2,1>": 2 * 91 + 53, "mtg_solve_kernel_multi<1,1,2,0>": 2 * 47 + 28}
 MAX_RANKS_PER_GPU = 6   # the GPU box's process guard
 
 

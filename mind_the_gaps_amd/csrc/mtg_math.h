@@ -106,10 +106,18 @@ __device__ __forceinline__ void mtg_sincos_small(double r, double *s, double *c)
 #endif
 }
 
-// Largest phase increment d * dx the table sincos reduces exactly: the 24-bit head of
-// 2 pi / (16 N) times md16 = 16 rint(x N / 2 pi) must be an exact product (md16 < 2^29).
+// Largest phase increment x = d * dx handed to mtg_phase_step.  Its reduction is exact for any x whose multiple
+// count k = rint(x N / 2 pi) fits the mantissa trick below (k < 2^51: x < 6.9e12 for N = 2048): the product k C is
+// formed inside an fma, the remainder is rounded once, and the only error is that of the constant C -- the frequency
+// d moved by less than its own rounding, the same at every sample.  What is left is the rounding of x itself,
+// ulp(x) / 2 per step (7e-12 rad at x = 1e5, 6e-5 at 1e12; a random walk over the steps of a sweep) -- against
+// ulp(d t_n) / 2 at EVERY sample for a phase evaluated at the elapsed time, as the libm variant of the sweep does
+// (and celerite, at the absolute time): n times larger at sample n.  Accuracy therefore never argues for the libm
+// variants; they are kept for what the mantissa trick cannot hold.  (Until round 3 the limit was 1e5, a left-over of
+// a two-constant reduction.  A sampler's walkers at the top of the prior box -- omega_0 ~ e^10 per day, gaps of
+// days -- crossed it, and ONE such lane sends its whole wave through libm: 25 % of the configs[3] refits' time.)
 #ifndef MTG_TRIG_FAST_MAX
-#define MTG_TRIG_FAST_MAX 1.0e5
+#define MTG_TRIG_FAST_MAX 1.0e12
 #endif
 
 // ---------------------------------------------------------------------------

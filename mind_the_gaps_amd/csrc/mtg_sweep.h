@@ -12,20 +12,6 @@
 #define MTG_LN_2PI 1.8378770664093454835606594728112
 #define MTG_BLOCK 256
 
-// Largest phase increment x = d * dx per step the sweep hands to mtg_phase_step.  Its reduction is exact for any x
-// whose multiple count k = rint(x N / 2 pi) fits the mantissa trick (k < 2^51, x < 6.9e12 for N = 2048): the product
-// k C is formed inside an fma, the remainder is rounded once, and the only error is that of the constant C -- the
-// frequency d moved by less than its own rounding, the same at every sample.  What is left is the rounding of x
-// itself, ulp(x) / 2 per step: 7e-12 rad at x = 1e5, 6e-5 at 1e12, and a random walk over the steps -- against
-// ulp(d t_n) / 2 at EVERY sample for a phase evaluated at the elapsed time, as the libm variant (and celerite, at the
-// absolute time) does: that is n times larger at sample n.  So accuracy never argues for the libm variant; it is kept
-// for what the mantissa trick cannot hold.  (Until round 3 the limit was 1e5, a left-over of a two-constant
-// reduction; a sampler's walkers at the top of the prior box, omega_0 ~ e^10 per day x gaps of days, crossed it, and
-// ONE such lane sends its whole wave through libm: 25 % of the configs[3] refits' time.)
-#ifndef MTG_SWEEP_FAST_MAX
-#define MTG_SWEEP_FAST_MAX 1.0e12
-#endif
-
 // ---------------------------------------------------------------------------
 // fused factorisation + forward solve, one lane per evaluation
 // ---------------------------------------------------------------------------
@@ -269,8 +255,8 @@ __device__ __forceinline__ void mtg_solve_row(const MtgSolveArgs &a, int64_t e, 
     const uint32_t dxt_rec = a.t_stride ? yv_rec : (uint32_t)lc_bytes;
     const uint32_t toff = a.t_stride ? yoff : 0u;
 
-    // the table sincos of mtg_phase_step serves every lane of the wave while d_k * dx <= MTG_SWEEP_FAST_MAX
-    const bool fast = !__any(!(dmax * *a.dxmax <= MTG_SWEEP_FAST_MAX));
+    // the table sincos of mtg_phase_step serves every lane of the wave while d_k * dx <= MTG_TRIG_FAST_MAX
+    const bool fast = !__any(!(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
     if (fast) {
         if (a.has_mean) mtg_sweep<NR, NC, true, true, NB0>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);
         else mtg_sweep<NR, NC, true, false, NB0>(L, a, yv_base, yv_rec, yoff, dxt_base, dxt_rec, toff, &tab);

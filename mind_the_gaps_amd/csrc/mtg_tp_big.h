@@ -162,7 +162,9 @@ __device__ __forceinline__ bool tpb_load_model(const MtgSolveArgs &a, int64_t ev
     slope = cf[a.lay.mean(0) * cs];
     icpt = cf[a.lay.mean(1) * cs];
     lc = a.lc_index ? (int64_t)a.lc_index[ev] : 0;
-    fast = dmax * *a.dxmax <= MTG_TRIG_FAST_MAX;
+    // (1e5, not MTG_TRIG_FAST_MAX: beyond it tpb_transition's two-part reduction carries the rounding error of
+    // d * dx along, which is more accurate than the plain product and costs four instructions)
+    fast = dmax * *a.dxmax <= 1.0e5;
     return !(lc < 0 || (uint64_t)(lc + 1) * (uint64_t)a.N * 16u > (uint64_t)a.yv_bytes);
 }
 

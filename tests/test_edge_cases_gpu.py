@@ -37,8 +37,9 @@ def test_duplicate_timestamps_and_huge_gaps(engine):
     hip_vs_dense(engine, kinds, t, y, dy, thetas, float(np.mean(y)))
 
 
-def test_large_phase_increments_take_the_ocml_sweep(engine):
-    """d * max(dx) > 1e5 rad: the wave falls back to the OCML sincos sweep variant."""
+def test_large_phase_increments(engine):
+    """d * max(dx) = 3.6e5 rad per step: far beyond the 1e5 that used to send a wave to the OCML sincos variant of the
+    sweep, inside what the table reduction takes exactly (MTG_TRIG_FAST_MAX = 1e12)."""
     rng = np.random.default_rng(2)
     t = np.cumsum(rng.exponential(0.5, 150))
     t[75:] += 40.0
@@ -46,9 +47,37 @@ def test_large_phase_increments_take_the_ocml_sweep(engine):
     kinds = [synth.K_COMPLEX3, synth.K_DRW]
     base = np.array([np.log(2.0), np.log(0.3), np.log(9000.0), np.log(1.5), np.log(0.2)])   # d = 9000 rad/day
     thetas = base + 0.01 * rng.standard_normal((5, 5))
-    # mixed wave: some lanes fast-eligible, some not -> the whole wave takes the OCML variant
     thetas[3:, 2] = np.log(3.0)
     hip_vs_dense(engine, kinds, t, y, dy, thetas, 0.0, tol=1e-8)
+
+
+def test_phase_increments_beyond_the_table_range_take_the_ocml_sweep(engine):
+    """One row with d * max(dx) > 1e12 sends its whole wave through the OCML sincos variant (phases at the elapsed
+    time): its wave-mates, ordinary rows, must come out as they do on the table variant, to rounding."""
+    rng = np.random.default_rng(3)
+    t = np.cumsum(rng.exponential(0.5, 150))
+    t[75:] += 2.0e8                                            # a gap of 2e8 days: d dx = 1.8e12 for d = 9000
+    y, dy = rng.standard_normal(150), rng.uniform(0.2, 0.5, 150)
+    kinds = [synth.K_COMPLEX3, synth.K_DRW]
+    base = np.array([np.log(2.0), np.log(0.3), np.log(3.0), np.log(1.5), np.log(0.2)])
+    full, free = np.concatenate([base, [0.0]]), np.arange(5, dtype=np.int32)
+    bounds = np.tile([-np.inf, np.inf], (6, 1))
+    ordinary = base + 0.01 * rng.standard_normal((40, 5))
+    wild = base.copy()
+    wild[2] = np.log(9000.0)
+    engine.set_time_parallel(0)
+    try:
+        engine.set_lightcurves(t, y, dy + 1e-12)
+        engine.set_model(kinds, full, free, bounds)
+        alone, st0 = engine.loglike(ordinary, add_prior=False)                       # table variant
+        mixed, st1 = engine.loglike(np.vstack([ordinary, wild[None]]), add_prior=False)   # the wave takes OCML
+    finally:
+        engine.set_time_parallel(2)
+    assert np.all(st0 == 0) and np.all(st1[:40] == 0)
+    # the OCML variant evaluates d (t_n - t_0) at the elapsed time, ~6e8 rad behind the gap: ulp / 2 = 6e-8 rad of phase
+    # noise per sample where the table variant has ~1e-16 -- which is what the difference shows
+    assert np.max(np.abs(mixed[:40] - alone) / np.abs(alone)) < 1e-7
+    assert np.any(mixed[:40] != alone)                       # (really another variant: not bit for bit)
 
 
 def test_prior_box_corners_match_oracle(engine):
