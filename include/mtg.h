@@ -265,6 +265,11 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
 /* hipFFT's one-time start-up (~1.4 s: the first plan of a process) paid now, on the context's device; safe to call
  * from a helper thread (HIP's current device is per thread: the call selects ctx's; NULL = the thread's current). */
 MTG_API int mtg_fft_warmup(mtg_ctx *ctx);
+/* The inverse-transform plan mtg_simulate_tk95 needs for series of nfft points, made now and kept by the context
+ * (one plan per length, whatever the number of simulations).  A Bluestein plan -- 1 087 853 points in BASELINE
+ * configs[3] -- takes 0.9 s to build: from a helper thread, while the context samples the observed light curve, it
+ * costs nothing.  Safe beside any other call on the context; mtg_simulate_tk95 waits for it. */
+MTG_API int mtg_simulate_plan(mtg_ctx *ctx, int64_t nfft);
 
 /*
  * Walker sharding of the resident ensembles across the GPUs of a job (one process per GPU; the

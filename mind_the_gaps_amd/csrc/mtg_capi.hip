@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -107,6 +108,16 @@ struct mtg_ctx {
     int64_t acf_n2 = 0, acf_S = 0;
     int64_t acf_P = 0;
     DevBuf acf_chain, acf_x, acf_f, acf_g, acf_r, acf_ss, acf_tmp;
+
+    // mtg_simulate_tk95: the inverse transform's plan (made once per length: a Bluestein plan for the 1 087 853 points
+    // of BASELINE configs[3] takes 0.9 s to build, as long as the 2000 simulations it then runs) and its buffers.
+    // mtg_simulate_plan may build it from a helper thread while the context is busy elsewhere: sim_mu.
+    std::mutex sim_mu;
+    hipfftHandle sim_plan = 0;
+    bool sim_have_plan = false;
+    int64_t sim_nfft = 0;
+    int sim_batch = 0;
+    DevBuf sim_spec, sim_series;
 
     // side streams: the structures (signatures) of a small batch run next to each other
     hipStream_t side[MTG_MAX_J / 2] = {};
@@ -601,6 +612,9 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     shard_release(ctx);
     if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
+    if (ctx->sim_have_plan) (void)hipfftDestroy(ctx->sim_plan);
+    ctx->sim_spec.release();
+    ctx->sim_series.release();
     for (DevBuf *b : {&ctx->acf_chain, &ctx->acf_x, &ctx->acf_f, &ctx->acf_g, &ctx->acf_r, &ctx->acf_ss, &ctx->acf_tmp}) b->release();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->shard_ev) (void)hipEventDestroy(e);
@@ -1456,6 +1470,36 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
     return MTG_OK;
 }
 
+// transforms per execution of the simulator's plan: a function of the length alone, so that one plan serves every
+// call (16 transforms of 10^6 points fill the GPU; short transforms are batched by the hundred)
+static int sim_batch_for(int64_t nfft)
+{
+    int64_t b = ((int64_t)1 << 24) / nfft;
+    return (int)(b < 16 ? 16 : b > 256 ? 256 : b);
+}
+
+// the context's C2R plan of length nfft (made, or remade for another length, under sim_mu); no fail(): may run on a
+// helper thread
+static int sim_plan_get(mtg_ctx *ctx, int64_t nfft)
+{
+    std::lock_guard<std::mutex> lock(ctx->sim_mu);
+    if (ctx->sim_have_plan && ctx->sim_nfft == nfft) return MTG_OK;
+    if (ctx->sim_have_plan) { (void)hipfftDestroy(ctx->sim_plan); ctx->sim_have_plan = false; }
+    const int batch = sim_batch_for(nfft);
+    if (hipfftPlan1d(&ctx->sim_plan, (int)nfft, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS) return MTG_E_HIP;
+    ctx->sim_have_plan = true;
+    ctx->sim_nfft = nfft;
+    ctx->sim_batch = batch;
+    return MTG_OK;
+}
+
+MTG_API int mtg_simulate_plan(mtg_ctx *ctx, int64_t nfft)
+{
+    if (!ctx || nfft < 4 || nfft > ((int64_t)1 << 30)) return MTG_E_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MTG_E_HIP;   // (HIP's current device is per thread)
+    return sim_plan_get(ctx, nfft);
+}
+
 MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, const double *psd_table, int64_t psd_rows,
                               uint64_t seed, int64_t nfft, double sim_dt, double mean_rate, int64_t seg_len,
                               const int32_t *win_lo, const int32_t *win_hi, int noise_kind, double sigma_noise,
@@ -1491,18 +1535,15 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     if (rc) return rc;
     CTX_STREAM(ctx, s);
     const int64_t nk = nfft / 2 + 1;
-    // chunk the simulations so that spectrum + series stay below ~2 GiB
-    int64_t chunk = (int64_t)(2.0e9 / (16.0 * (double)nfft));
-    if (chunk < 1) chunk = 1;
-    if (chunk > S) chunk = S;
-    DevBuf spec, series, d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means, d_psd, d_seg;
-    hipfftHandle plan = 0;
-    bool have_plan = false;
+    // the simulations go through the context's plan `chunk` at a time (the last group may be short: the transforms of
+    // the unused slots run on whatever the buffer holds and are not looked at)
+    const int64_t chunk = sim_batch_for(nfft);
+    DevBuf &spec = ctx->sim_spec, &series = ctx->sim_series;
+    DevBuf d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means, d_psd, d_seg;
     hipError_t e = hipSuccess;
     const char *what = "allocation";
     auto cleanup = [&]() {
-        if (have_plan) (void)hipfftDestroy(plan);
-        DevBuf *bufs[] = {&spec, &series, &d_lo, &d_hi, &d_expo, &d_clean, &d_rates, &d_dy, &d_sig, &d_means, &d_psd, &d_seg};
+        DevBuf *bufs[] = {&d_lo, &d_hi, &d_expo, &d_clean, &d_rates, &d_dy, &d_sig, &d_means, &d_psd, &d_seg};
         for (DevBuf *b : bufs) b->release();
     };
     HIP_TRY(ctx, ctx->theta.reserve((size_t)S * (P > 0 ? P : 1) * 8));
@@ -1535,14 +1576,15 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         mtg_launch_prepare(pa, s);
         e = hipGetLastError();
     }
+    hipfftHandle plan = 0;
     if (e == hipSuccess) {
         what = "hipfftPlan1d";
-        if (hipfftPlan1d(&plan, (int)nfft, HIPFFT_Z2D, (int)chunk) != HIPFFT_SUCCESS || hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
+        if (sim_plan_get(ctx, nfft) != MTG_OK || hipfftSetStream(ctx->sim_plan, s) != HIPFFT_SUCCESS) {
             cleanup();
             return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipFFT plan creation failed (nfft = %lld, batch = %lld)",
                         (long long)nfft, (long long)chunk);
         }
-        have_plan = true;
+        plan = ctx->sim_plan;
     }
     // irfft normalisation (hipFFT C2R is unnormalised) and the reference's power scaling
     const double scale = sqrt((double)nfft * sim_dt * sqrt(2.0 * M_PI)) / (double)nfft;
@@ -1552,6 +1594,9 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         mtg_launch_tk95_spectrum(sc, s0, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
                                  d_sig.as<int32_t>(), psd_table ? d_psd.as<double>() : nullptr, psd_rows, seed,
                                  spec.as<double2>(), s);
+        if (sc < chunk)  // a short last group: the unused slots transform zeros
+            e = hipMemsetAsync((char *)spec.p + (size_t)sc * nk * 16, 0, (size_t)(chunk - sc) * nk * 16, s);
+        if (e != hipSuccess) break;
         if (hipfftExecZ2D(plan, (hipfftDoubleComplex *)spec.p, series.as<double>()) != HIPFFT_SUCCESS) {
             cleanup();
             return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");  // (the resident set is untouched so far)

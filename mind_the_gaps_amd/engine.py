@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_ensemble_restore", "mtg_set_sort", "mtg_last_solver",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_last_solver",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
 
@@ -212,6 +212,8 @@ def load_library():
     lib.mtg_ensemble_unshard.argtypes = [c_vp]
     lib.mtg_fft_warmup.restype = c_int
     lib.mtg_fft_warmup.argtypes = [c_vp]
+    lib.mtg_simulate_plan.restype = c_int
+    lib.mtg_simulate_plan.argtypes = [c_vp, c_i64]
     lib.mtg_set_sort.restype = c_int
     lib.mtg_set_sort.argtypes = [c_vp, c_int]
     lib.mtg_last_solver.restype = ctypes.c_char_p
@@ -524,9 +526,22 @@ class Engine:
         self._fft_thread.start()
 
     def _join_fft_warmup(self):
-        thread = getattr(self, "_fft_thread", None)
+        for name in ("_fft_thread", "_sim_plan_thread"):
+            thread = getattr(self, name, None)
+            if thread is not None and thread.is_alive():
+                thread.join()
+
+    def start_simulate_warmup(self, nfft):
+        """The plan ``simulate_tk95`` needs for series of ``nfft`` points, built on a helper thread (mtg_simulate_plan):
+        0.9 s for the Bluestein plan of BASELINE configs[3], hidden behind whatever the context does meanwhile."""
+        import threading
+        thread = getattr(self, "_sim_plan_thread", None)
         if thread is not None and thread.is_alive():
-            thread.join()
+            return
+        ctx, nfft = self._ctx, int(nfft)
+        self._sim_plan_thread = threading.Thread(target=lambda: self._lib.mtg_simulate_plan(ctx, nfft),
+                                                 name="mtg-simulate-plan", daemon=True)
+        self._sim_plan_thread.start()
 
     def chain_autocorr(self, chain):
         """chain [n_t][W][P] -> walker-averaged normalised autocorrelation function [n_t][P] (emcee's

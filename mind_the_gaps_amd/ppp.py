@@ -410,6 +410,11 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
 
     import time
     clock = [time.perf_counter()]
+    # the simulator's transform plan is built beside the observed chains (its grid depends on the sampling alone)
+    sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
+                    lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
+                    extension_factor=extension_factor, random_state=0, device=device)
+    sim.warm_up()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         null, alt = observed(null_kernel), observed(alt_kernel)
@@ -432,9 +437,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     sw = sim_walkers or walkers
     out, fits, best = None, [None, None], [np.empty(0), np.empty(0)]
     if hi > lo:
-        sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
-                        lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
-                        extension_factor=extension_factor, random_state=sim_seed, device=device)
+        sim.random_state = np.random.RandomState(sim_seed)
         out = sim.simulate(samples[lo:hi, :null_kernel.vector_size])
         clock.append(time.perf_counter())
         def refit(k):

@@ -191,6 +191,13 @@ class Simulator:
             raise ValueError("the device simulator needs device-expandable terms")
         return self._evaluator._bind(model), model
 
+    def warm_up(self):
+        """Start building the inverse-transform plan of this simulator's grid on a helper thread (the engine keeps one
+        plan per length): call it before work that does not need the simulator yet, e.g. the chains of the observed
+        light curve."""
+        from .gp import get_engine
+        get_engine(self.device).start_simulate_warmup(self.fftndatapoints)
+
     def _psd_table(self):
         """The callable PSD on the grid's angular frequencies; the k = 0 entry is not used (the mean of
         the series is set afterwards) and a power law would be infinite there."""
