@@ -269,6 +269,28 @@ def _iptr(a):
     return a.ctypes.data_as(_ip) if a is not None else None
 
 
+_live_engines = None
+
+
+def _register_for_exit(engine):
+    """Helper threads (hipFFT start-up, the simulator's plan) are daemons: at interpreter exit one of them may still be
+    inside plan creation, and being killed there takes the process down with it.  They are joined first."""
+    global _live_engines
+    if _live_engines is None:
+        import atexit
+        import weakref
+        _live_engines = weakref.WeakSet()
+
+        def join_all():
+            for eng in list(_live_engines):
+                try:
+                    eng._join_fft_warmup()
+                except Exception:
+                    pass
+        atexit.register(join_all)
+    _live_engines.add(engine)
+
+
 def _one_thread_at_a_time(method):
     """An ``mtg_ctx`` is not re-entrant: a second thread that re-uploads light curves while the first one's kernels are
     in flight ends in a GPU memory fault.  Calls from another thread while one is inside the library are refused."""
@@ -301,6 +323,7 @@ class Engine:
         self.N = 0
         self.L = 0
         self.P = None
+        _register_for_exit(self)
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
