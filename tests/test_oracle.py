@@ -207,3 +207,16 @@ def test_fused_sweep_equals_the_two_sweep_restatement():
     a, sa = oc.logprob_batch(t, y, dy, kinds, full, nthreads=4)
     b, sb = oc.logprob_batch(t, y, dy, kinds, full, nthreads=4, fused=True)
     assert np.array_equal(sa, sb) and np.max(np.abs(a - b) / np.abs(a)) < 1e-13
+
+
+def test_celerite_restatement_on_the_high_frequency_fixture():
+    """tests/golden/highfreq_golden.json (50-digit dense values, phase steps up to 2e6 rad): over the fixture's 200 days
+    celerite's algorithm with cos(d t_n) at the absolute times is still good to a few 1e-12."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "highfreq_golden.json")))
+    t, y, dy = (np.array(fx[k]) for k in ("t", "y", "dy"))
+    for case in fx["cases"]:
+        full = np.concatenate([case["theta"], [fx["mean"]]])[None, :]
+        out, st = oc.logprob_batch(t, y, dy, case["kinds"], full, bounds=None, add_prior=False)
+        assert st[0] == 0
+        assert abs(out[0] - case["lnL_mpmath50"]) / abs(case["lnL_mpmath50"]) < 1e-10, (case["name"], case["omega"])
