@@ -619,9 +619,10 @@ def main():
             try:
                 if os.environ.get("MTG_BENCH_FAIL_EXTRAS") == str(rank):     # rehearsal of this guard
                     raise RuntimeError("injected failure (MTG_BENCH_FAIL_EXTRAS)")
-                extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
                 if not args.no_workflow:
-                    # configs[3] as a whole workflow, its simulated light curves cut into one block per rank
+                    # configs[3] as a whole workflow, its simulated light curves cut into one block per rank (first: it
+                    # needs torch.distributed's collectives only, the walker-sharded configs bring the library's own
+                    # RCCL communicator up)
                     dist.barrier()
                     t1 = time.perf_counter()
                     wf = workflow_probe().run(sharded=True, device=local_dev)
@@ -630,6 +631,7 @@ def main():
                     wf["whole_test_s_max_over_ranks"] = float(wall.item())
                     wf["ranks"] = world
                     extras["workflow_config3_sharded"] = wf
+                extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
                 dist.barrier()        # every rank got through: nobody is left inside a collective
                 timer.cancel()
             except BaseException as exc:     # this rank failed: the others find out at the timer
