@@ -22,6 +22,11 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// hipFFT plans are made from helper threads too (mtg_fft_warmup, mtg_simulate_plan) while another thread may be making
+// or destroying one for a convergence check: plan creation and destruction go through one process-wide lock
+// (executions do not).
+std::mutex g_fft_plan_mu;
+
 struct DevBuf {  // owning device allocation; locals free themselves on every return path
     void *p = nullptr;
     size_t cap = 0;
@@ -611,8 +616,11 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
                       &ctx->ens_lnp_chain};
     for (DevBuf *b : bufs) b->release();
     shard_release(ctx);
-    if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
-    if (ctx->sim_have_plan) (void)hipfftDestroy(ctx->sim_plan);
+    {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
+        if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
+        if (ctx->sim_have_plan) (void)hipfftDestroy(ctx->sim_plan);
+    }
     ctx->sim_spec.release();
     ctx->sim_series.release();
     for (DevBuf *b : {&ctx->acf_chain, &ctx->acf_x, &ctx->acf_f, &ctx->acf_g, &ctx->acf_r, &ctx->acf_ss, &ctx->acf_tmp}) b->release();
@@ -1413,6 +1421,7 @@ MTG_API int mtg_fft_warmup(mtg_ctx *ctx)
     if (ctx && hipSetDevice(ctx->device) != hipSuccess) return MTG_E_HIP;
     // hipFFT needs ~1.4 s the first time a plan is made in a process (rocFFT loads its kernels): callers that will
     // need mtg_chain_autocorr or mtg_simulate_tk95 later can pay that early, from another thread
+    std::lock_guard<std::mutex> plans(g_fft_plan_mu);
     hipfftHandle plan = 0;
     if (hipfftPlan1d(&plan, 64, HIPFFT_D2Z, 1) != HIPFFT_SUCCESS) return MTG_E_HIP;
     (void)hipfftDestroy(plan);
@@ -1445,6 +1454,7 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
     mtg_launch_acf_transpose(n2, S, d_x.as<double>(), d_chain.as<double>(), s);
     // contiguous batched transforms (stock kernels: no run-time compilation inside rocFFT)
     if (!ctx->acf_plans || ctx->acf_n2 != n2 || ctx->acf_S != S || ctx->acf_P != EP) {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
         if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); ctx->acf_plans = false; }
         int len = (int)n2;
         if (hipfftPlanMany(&ctx->acf_fwd, 1, &len, nullptr, 1, (int)n2, nullptr, 1, (int)nk, HIPFFT_D2Z, (int)S) != HIPFFT_SUCCESS)
@@ -1484,6 +1494,7 @@ static int sim_plan_get(mtg_ctx *ctx, int64_t nfft)
 {
     std::lock_guard<std::mutex> lock(ctx->sim_mu);
     if (ctx->sim_have_plan && ctx->sim_nfft == nfft) return MTG_OK;
+    std::lock_guard<std::mutex> plans(g_fft_plan_mu);
     if (ctx->sim_have_plan) { (void)hipfftDestroy(ctx->sim_plan); ctx->sim_have_plan = false; }
     const int batch = sim_batch_for(nfft);
     if (hipfftPlan1d(&ctx->sim_plan, (int)nfft, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS) return MTG_E_HIP;
