@@ -29,7 +29,7 @@ big.set_model(kinds, full, free, bounds)
 out = {"L": L, "N": N, "resident_bytes": int(L) * N * 16 + N * 16, "upload_s": upload_s}
 for name, lc in (("grouped", np.repeat(np.arange(L, dtype=np.int32), 8)),
                  ("random order", rng.integers(0, L, 40000).astype(np.int32))):
-    theta = synth.draw_thetas(kinds, len(lc), seed=3)
+    theta = synth.draw_thetas(kinds, len(lc), seed=3, percent=0.6)     # SHO on both sides of Q = 1/2: two structures
     for eng in (small, big):
         eng.set_time_parallel(0)
     got, st = big.loglike(theta, lc, add_prior=True)
