@@ -34,6 +34,7 @@ The JSON line also carries
                     half-step's proposals split over the ranks, ncclAllGather pair on the launch stream
                     (mtg_ensemble_shard_rccl): iterations/s, rows per rank, half-step ms, exchange us;
   end_to_end      : (N = 1) the same sweep through the host-pointer entry point (H2D, kernels, D2H);
+  clock_under_load: (N = 1) sclk and socket power from rocm-smi while sweeps are queued (the FP64 peak is quoted at 2.4 GHz);
   strong_shard_8  : (N = 1) one GPU on the share it gets of the 2000 light curves at 8 GPUs (250);
   null_model_sweep, config2_raw_kernel, other_configs (configs[0], [1], [2] + T_LRT, [4]),
   workflow_config3: (N = 1) the other SURVEY 8(d) figures: the null model's sweep beside the alternative's,
@@ -131,6 +132,31 @@ def launch_ranks(args):
                     children[other].terminate()
         time.sleep(0.05)
     raise SystemExit(worst)
+
+
+def clock_under_load(queue_work, wait):
+    """{"sclk_mhz", "socket_power_w", "fp64_peak_tflops_at_sclk"} read through rocm-smi while `queue_work()` keeps the GPU
+    busy; None when rocm-smi is missing, slow or says something this does not understand (a side reading, never fatal)."""
+    import re
+    import shutil
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    queue_work()
+    try:
+        out = subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        out = ""
+    finally:
+        wait()
+    sclk = re.search(r"sclk clock level: *\d+: *\((\d+)Mhz\)", out)
+    power = re.search(r"Power \(W\): *([0-9.]+)", out)
+    if not sclk:
+        return None
+    mhz = float(sclk.group(1))
+    return {"sclk_mhz": mhz, "socket_power_w": float(power.group(1)) if power else None,
+            "fp64_peak_tflops_at_sclk": FP64_PEAK_TFLOPS * mhz / 2400.0,
+            "what": "rocm-smi --showclocks --showpower while 40 sweeps are queued; the nominal FP64 vector peak is quoted at 2400 MHz"}
 
 
 def usable_cores():
@@ -653,6 +679,11 @@ def main():
                                 "what": "mtg_loglike_batch: pageable host theta [B][P] + light-curve index up, kernels, "
                                         "lnP + status down, every step (%d MB + %d MB over PCIe)"
                                         % (theta.nbytes // 2**20 + lc.nbytes // 2**20, (B * 12) // 2**20)}
+        # (a') the clock the card holds under this load (the 78.6 TFLOP/s FP64 vector peak assumes 2.4 GHz; the sweep is
+        # power limited): rocm-smi read while ~1 s of sweeps is queued.  A reading that fails is left out.
+        clock = clock_under_load(lambda: [sweep() for _ in range(40)], lambda: torch.cuda.synchronize(dev))
+        if clock:
+            extras["clock_under_load"] = clock
         # (b) the share one GPU gets of the 2000 light curves at 8 GPUs: is a 1/8 batch still efficient?
         L8 = max(1, L // 8)
         B8 = L8 * W
