@@ -367,7 +367,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
 
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
                    sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
-                   sharded=False, group=None, concurrent_refits=False):
+                   sharded=False, group=None, concurrent_refits=False, split="auto"):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -390,7 +390,10 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     rank r simulates and refits only its block, nothing is exchanged meanwhile, and ONE all-gather per model of the
     maxima of lnL (8 bytes per light curve) gives every rank the whole ``T_sim``.  Step 1 runs on every rank; rank
     0's posterior samples and ``T_obs`` are broadcast so that all ranks test the same thing.  ``sim_null``,
-    ``sim_alt`` and ``lightcurves`` then hold the rank's own block.
+    ``sim_alt`` and ``lightcurves`` then hold the rank's own block.  ``split``: "lightcurves" as just described,
+    "models" -- the first half of the ranks refits the null model, the second half the alternative, each over all the
+    light curves (a rank then holds ``sim_null`` or ``sim_alt``, not both; with two ranks the result equals the
+    unsharded one bit for bit) --, "auto" picks by the rows a half-step leaves each rank (``_split_by_model``).
     """
     from .gpmodelling import GPModelling
     from .simulator import Simulator
@@ -425,16 +428,28 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     t_obs = float(lrt_statistic(null.best_loglikelihood, alt.best_loglikelihood))
     samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
     sim_seed, fit_seeds = int(rng.integers(0, 2 ** 31 - 1)), [int(rng.integers(0, 2 ** 62)) for _ in range(2)]
-    lo, hi, shard = 0, nsims, None
+    sw = sim_walkers or walkers
+    lo, hi, shard, models = 0, nsims, None, (0, 1)
     if sharded:
-        from .distributed import LightcurveShard, broadcast_array
+        from .distributed import LightcurveShard, all_gather_rows, block_bounds, broadcast_array
         shard = LightcurveShard(nsims, group=group)
         head = broadcast_array(np.concatenate([[t_obs], samples.ravel()]), group)   # rank 0's test, everybody's test
         t_obs, samples = float(head[0]), head[1:].reshape(samples.shape)
-        lo, hi = shard.lo, shard.hi
-        sim_seed = (sim_seed + 7919 * shard.rank) % (2 ** 31 - 1)                    # independent noise on every rank
-        fit_seeds = [f + 7919 * shard.rank for f in fit_seeds]
-    sw = sim_walkers or walkers
+        if _split_by_model(split, nsims, sw, shard.world):
+            # half of the ranks refit the null model, the other half the alternative, each half over ALL the light
+            # curves: twice the rows per rank and one model's half-steps instead of both one after the other
+            half = shard.world // 2
+            models = (0,) if shard.rank < half else (1,)
+            block = shard.rank % half
+            bounds = block_bounds(nsims, half)
+            lo, hi = int(bounds[block]), int(bounds[block + 1])
+            if shard.rank >= 2 * half:                           # an odd rank out takes no part in the refits
+                models, lo, hi = (), 0, 0
+        else:
+            block, bounds = shard.rank, shard.bounds
+            lo, hi = shard.lo, shard.hi
+        sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)       # independent noise on every block (the two ranks
+        fit_seeds = [f + 7919 * block for f in fit_seeds]           # of a block under the model split draw the same)
     out, fits, best = None, [None, None], [np.empty(0), np.empty(0)]
     if hi > lo:
         sim.random_state = np.random.RandomState(sim_seed)
@@ -448,7 +463,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
 
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            if concurrent_refits:
+            if concurrent_refits and len(models) == 2:
                 # The two models' refits are independent: each on its own context and stream, driven by its own host
                 # thread (the library calls release the GIL).  Measured at configs[3]'s sizes: 26.30 s side by side
                 # against 8.40 + 17.96 s one after the other -- both sweeps are bound by FP64 issue and a half-step
@@ -459,17 +474,43 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                 clock += [time.perf_counter()] * 2
             else:
                 for k in (0, 1):
-                    fits[k] = refit(k)
+                    if k in models:
+                        fits[k] = refit(k)
                     clock.append(time.perf_counter())
-            best = [f.max_loglikelihood for f in fits]
+            best = [np.empty(0) if f is None else f.max_loglikelihood for f in fits]
     if sharded:   # the only exchange of the loop: the maxima of lnL, one all-gather per model
-        best = [shard.gather(b) for b in best]
+        if len(models) == 2:
+            best = [shard.gather(b) for b in best]
+        else:
+            half, sizes = shard.world // 2, np.diff(bounds)
+            counts = [np.concatenate([sizes, 0 * sizes]), np.concatenate([0 * sizes, sizes])]
+            if shard.world % 2:                                  # an odd rank out takes no part in the refits
+                counts = [np.append(c, 0) for c in counts]
+            best = [all_gather_rows(best[k] if k in models else np.empty(0), counts[k], group) for k in (0, 1)]
     t_sim = lrt_statistic(best[0], best[1])
     clock.append(time.perf_counter())
     seconds = dict(zip(("observed_chains", "simulate", "refit_null", "refit_alt", "gather"), np.diff(clock))) \
         if len(clock) == 6 else {"observed_chains": clock[1] - clock[0]}
     return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
                 sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds)
+
+
+def _split_by_model(split, nsims, walkers, world):
+    """How protassov_test(sharded=True) divides the refits: by light curve (every rank refits both models on its block)
+    or by model (half of the ranks each).  A half-step of the serial sweep costs one wave's latency over the N samples
+    until a rank has about one wave per SIMD (65 536 rows), so with many ranks and few rows each, two half-steps of
+    both models one after the other take twice as long as one half-step of one model on twice the rows.  By model:
+    when asked for, or -- "auto" -- when the rows of a half-step per rank stay under that mark either way."""
+    if split == "models":
+        if world < 2:
+            raise ValueError("split='models' needs at least two ranks")
+        return True
+    if split == "lightcurves" or world < 2:
+        return False
+    if split != "auto":
+        raise ValueError("split must be 'auto', 'lightcurves' or 'models'")
+    rows_by_model = -(-nsims // (world // 2)) * (walkers // 2)
+    return rows_by_model <= 70000
 
 
 def derive_posteriors_sharded(times, Y, DY, kernel, group=None, device=None, **kwargs):

@@ -310,7 +310,7 @@ def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
 
 # ---- the Protassov test with its simulated light curves sharded (BASELINE configs[3] as a workflow) ---------
 
-def _protassov_worker(rank, world, port, out_dir):
+def _protassov_worker(rank, world, port, out_dir, split="lightcurves"):
     sys.path.insert(0, ROOT)
     guard = _watchdog(out_dir, "ppp%d_%d" % (world, rank))
     import warnings
@@ -330,12 +330,14 @@ def _protassov_worker(rank, world, port, out_dir):
         th[5], th[6], th[7], bounds=[(-10, 50), (-10, 10), (-10, 10)])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        res = protassov_test(lc, null, alt, nsims=5, walkers=16, max_steps=60, sim_steps=40, seed=11, sharded=world > 1)
+        res = protassov_test(lc, null, alt, nsims=5, walkers=16, max_steps=60, sim_steps=40, seed=11, sharded=world > 1,
+                             split=split)
     n_local = 0 if res["lightcurves"] is None else len(res["lightcurves"]["rates"])
-    local = (np.empty(0) if res["sim_null"] is None else
-             -2.0 * (res["sim_null"].max_loglikelihood - res["sim_alt"].max_loglikelihood))
-    np.savez(os.path.join(out_dir, "pt%d_%d.npz" % (world, rank)), T_obs=res["T_obs"], T_sim=res["T_sim"],
-             p=res["p_value"], n_local=n_local, local=local)
+    both = res["sim_null"] is not None and res["sim_alt"] is not None
+    local = (-2.0 * (res["sim_null"].max_loglikelihood - res["sim_alt"].max_loglikelihood)) if both else np.empty(0)
+    np.savez(os.path.join(out_dir, "pt%s%d_%d.npz" % (split[0], world, rank)), T_obs=res["T_obs"], T_sim=res["T_sim"],
+             p=res["p_value"], n_local=n_local, local=local, has_null=res["sim_null"] is not None,
+             has_alt=res["sim_alt"] is not None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -351,7 +353,7 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     T_sim and p-value; T_sim is rank 0's block of 3 followed by rank 1's block of 2, each the rank's own refits."""
     world = 2
     _spawn(_protassov_worker, (world, _free_port(), str(tmp_path)), world, tmp_path)
-    r0, r1 = (np.load(tmp_path / ("pt2_%d.npz" % r)) for r in range(world))
+    r0, r1 = (np.load(tmp_path / ("ptl2_%d.npz" % r)) for r in range(world))
     assert float(r0["T_obs"]) == float(r1["T_obs"]) and float(r0["p"]) == float(r1["p"])
     assert np.array_equal(r0["T_sim"], r1["T_sim"]) and r0["T_sim"].shape == (5,)
     assert (int(r0["n_local"]), int(r1["n_local"])) == (3, 2)
@@ -359,9 +361,17 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     assert np.all(np.isfinite(r0["T_sim"])) and 0.0 <= float(r0["p"]) <= 1.0
     # one rank alone holds everything and the unsharded call is untouched by the new arguments
     _spawn(_protassov_worker, (1, _free_port(), str(tmp_path)), 1, tmp_path)
-    single = np.load(tmp_path / "pt1_0.npz")
+    single = np.load(tmp_path / "ptl1_0.npz")
     assert int(single["n_local"]) == 5 and np.all(np.isfinite(single["T_sim"]))
     assert np.isclose(float(single["T_obs"]), float(r0["T_obs"]), rtol=1e-9)      # same seed, same observed chains
+    # split by model: rank 0 refits the null model, rank 1 the alternative, each on all five light curves -- the same
+    # light curves, seeds and batches as one process alone, hence its T_sim to the last bit
+    _spawn(_protassov_worker, (world, _free_port(), str(tmp_path), "models"), world, tmp_path)
+    m0, m1 = (np.load(tmp_path / ("ptm2_%d.npz" % r)) for r in range(world))
+    assert (bool(m0["has_null"]), bool(m0["has_alt"]), bool(m1["has_null"]), bool(m1["has_alt"])) == (True, False, False, True)
+    assert (int(m0["n_local"]), int(m1["n_local"])) == (5, 5)
+    assert np.array_equal(m0["T_sim"], m1["T_sim"]) and float(m0["p"]) == float(m1["p"])
+    assert np.array_equal(m0["T_sim"], single["T_sim"]) and float(m0["T_obs"]) == float(single["T_obs"])
 
 
 # ---- the device-resident sampler, walker-sharded (mtg_ensemble_shard_*) -------------------------------------
