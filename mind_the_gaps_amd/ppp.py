@@ -377,7 +377,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     3. both kernels refitted to every simulated light curve in lock-step;
     4. p-value of ``T_obs`` in the simulated distribution.
 
-    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves, seconds) -- ``seconds``:
+    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves, seconds, split) -- ``seconds``:
     wall time of the observed chains, the simulation and the two refits on this process.
 
     ``concurrent_refits``: the null and the alternative refits of step 3 side by side on the device (two contexts, two
@@ -492,7 +492,8 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     seconds = dict(zip(("observed_chains", "simulate", "refit_null", "refit_alt", "gather"), np.diff(clock))) \
         if len(clock) == 6 else {"observed_chains": clock[1] - clock[0]}
     return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
-                sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds)
+                sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds,
+                split=None if not sharded else ("models" if len(models) < 2 else "lightcurves"))
 
 
 def _split_by_model(split, nsims, walkers, world):

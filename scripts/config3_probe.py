@@ -55,7 +55,7 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurre
         "workflow": "protassov_test, BASELINE configs[3]" + (", simulated light curves sharded over the ranks" if sharded else " on one GPU"),
         "nsims": nsims, "N": N, "walkers": W, "refit_steps": steps, "fft_points_per_simulation": sim.fftndatapoints,
         "observed_lightcurve_s": t_obs_sim, "whole_test_s": el,
-        "seconds": {k: float(v) for k, v in res["seconds"].items()},
+        "seconds": {k: float(v) for k, v in res["seconds"].items()}, "split": res["split"],
         "refit_evaluations": evals, "refit_evaluations_per_s_end_to_end": evals / el,
         "T_obs": res["T_obs"], "p_value": res["p_value"],
         "T_sim_quantiles_50_90_99": [float(q) for q in np.quantile(res["T_sim"], [0.5, 0.9, 0.99])],
