@@ -10,7 +10,7 @@ for sub in ("p1","p2"):
     for f in glob.glob("$OUT/%s/*/*counter_collection.csv"%sub):
         acc={}
         for r in csv.DictReader(open(f)):
-            if "mtg_solve_kernel<1, 2>" in r["Kernel_Name"]:
+            if "mtg_solve_kernel_multi<1, 2, 2, 1>" in r["Kernel_Name"] or "mtg_solve_kernel<1, 2" in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"],[]).append(float(r["Counter_Value"]))
                 dur=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
         for k,v in acc.items(): print(sub,k,sum(v)/len(v))
