@@ -195,6 +195,17 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
  */
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
 MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
+/*
+ * Speculative iterations of mtg_ensemble_run (default 1 = where they pay, 0 = never).  The time-parallel solve of a
+ * small batch takes as long for three times the rows -- most of the GPU is idle -- and the second half-step of a
+ * stretch-move iteration depends on the first only through each partner's coordinates: where it is, or where its own
+ * proposal would put it.  Both candidates are then evaluated beside the first half-step's proposals, one solve and one
+ * sampler launch per iteration instead of two and two (1.9 x the iterations per second for BASELINE configs[0] and
+ * [1]).  Taken when all 3 E W/2 rows get a workgroup of their own in one occupancy round (light curves of >= 4096
+ * samples: <= 256 rows, <= 512 up to rank 3; <= 1024 rows below), J <= 6, not walker-sharded.  The random numbers, hence the chain, are those of
+ * the sequential form (to the last bit where the solver's arithmetic for a row does not depend on the batch size).
+ */
+MTG_API int mtg_set_speculation(mtg_ctx *ctx, int mode);
 /* Name of the kernel the last batch was dispatched to, e.g. "mtg_solve_kernel<1,2,1>" (first structure of the
  * model when several were launched); "" before the first call.  For measurements (bench.py roofline.kernel). */
 MTG_API const char *mtg_last_solver(const mtg_ctx *ctx);

@@ -93,6 +93,7 @@ struct mtg_ctx {
     int64_t ens_L = 0, ens_N = 0;  // shape of the resident set the ensembles index into
     DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
         ens_naccept, ens_best_lnp, ens_best_coords, ens_notpd, ens_chain, ens_lnp_chain;
+    DevBuf ens_lc_spec;                 // light-curve index of the 3 E W/2 rows of a speculative iteration
     // walker sharding (mtg_ensemble_shard_*): this rank evaluates rows [shard_lo, shard_hi) of every
     // half-step's proposals; the exchange brings everybody's log-probabilities before the accept step
     int shard_kind = 0;  // 0 none, 1 RCCL all-gather on the stream, 2 host callback
@@ -136,6 +137,7 @@ struct mtg_ctx {
     // order of the serial sweep (mtg_sort.hip): 0 the caller's order, 1 always sorted by (structure, light curve),
     // 2 sorted unless the caller's order is known to be grouped already (host entry points look at lc_index)
     int sort_mode = 2;
+    int spec_mode = 1;                  // speculative iterations of small ensembles: 0 never, 1 where they pay (mtg_ensemble_run)
     int lc_grouped_hint = 0;   // set by the host-pointer entry points for the call in flight
     DevBuf sort_keys, sort_keys_out, sort_order, sort_tmp;
     char last_solver[96] = "";   // what the last solve dispatched (mtg_last_solver)
@@ -438,7 +440,10 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             sa.tp_gsize = g;
         }
     }
-    const bool wide = Bw <= 256 && ctx->N >= 4096;  // four waves per evaluation
+    // four waves per evaluation: while every evaluation's workgroup is resident at once (rank <= 3: two per CU, their
+    // elements take 68 KB of LDS; above: one)
+    // (scripts/spec_probe.py, J = 3, N = 1e4: 384 rows 70.9 us against 96.0 us with one wave each, 512 rows 77.4 / 97.2)
+    const bool wide = Bw <= (Jmodel <= 3 ? 512 : 256) && ctx->N >= 4096;
     mtg_solve_launcher fused = nullptr;
     if (small_ok && nsig > 1) {
         if (wide) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256);
@@ -611,7 +616,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     DevBuf *bufs[] = {&ctx->sort_keys, &ctx->sort_keys_out, &ctx->sort_order, &ctx->sort_tmp, &ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->tp_ws, &ctx->sig, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
                       &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
-                      &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_naccept,
+                      &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_lc_spec, &ctx->ens_naccept,
                       &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,
                       &ctx->ens_lnp_chain};
     for (DevBuf *b : bufs) b->release();
@@ -1005,21 +1010,25 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
     rc = use_device(ctx);
     if (rc) return rc;
     const int64_t EW = E * W, EH = E * (W / 2);
-    std::vector<int32_t> lc_full((size_t)EW), lc_half((size_t)EH);
+    std::vector<int32_t> lc_full((size_t)EW), lc_half((size_t)EH), lc_spec((size_t)(3 * EH));
     for (int64_t e = 0; e < E; ++e) {
         const int32_t l = lc_of_ensemble ? lc_of_ensemble[e] : (ctx->L == 1 ? 0 : (int32_t)e);
         if (l < 0 || l >= ctx->L) return fail(ctx, MTG_E_ARG, "mtg_ensemble_init: light curve %d out of range", l);
         for (int w = 0; w < W; ++w) lc_full[(size_t)(e * W + w)] = l;
-        for (int k = 0; k < W / 2; ++k) lc_half[(size_t)(e * (W / 2) + k)] = l;
+        for (int k = 0; k < W / 2; ++k)
+            lc_half[(size_t)(e * (W / 2) + k)] = lc_spec[(size_t)(e * (W / 2) + k)] = lc_spec[(size_t)(EH + e * (W / 2) + k)] =
+                lc_spec[(size_t)(2 * EH + e * (W / 2) + k)] = l;
     }
     CTX_STREAM(ctx, s);
     HIP_TRY(ctx, ctx->ens_coords.reserve((size_t)EW * P * 8));
     HIP_TRY(ctx, ctx->ens_lnp.reserve((size_t)EW * 8));
     HIP_TRY(ctx, ctx->ens_perm.reserve((size_t)EW * 4));
-    HIP_TRY(ctx, ctx->ens_q.reserve((size_t)EH * P * 8));
-    HIP_TRY(ctx, ctx->ens_factor.reserve((size_t)EH * 8));
-    HIP_TRY(ctx, ctx->ens_new.reserve((size_t)EW * 8));
-    HIP_TRY(ctx, ctx->ens_st.reserve((size_t)EW * 4));
+    // (proposals, their factors, log-probabilities and statuses: room for the 3 E W/2 rows of a speculative iteration)
+    HIP_TRY(ctx, ctx->ens_q.reserve((size_t)3 * EH * P * 8));
+    HIP_TRY(ctx, ctx->ens_factor.reserve((size_t)2 * EH * 8));
+    HIP_TRY(ctx, ctx->ens_new.reserve((size_t)3 * EH * 8));
+    HIP_TRY(ctx, ctx->ens_st.reserve((size_t)3 * EH * 4));
+    HIP_TRY(ctx, ctx->ens_lc_spec.reserve((size_t)3 * EH * 4));
     HIP_TRY(ctx, ctx->ens_lc_full.reserve((size_t)EW * 4));
     HIP_TRY(ctx, ctx->ens_lc_half.reserve((size_t)EH * 4));
     HIP_TRY(ctx, ctx->ens_naccept.reserve((size_t)EW * 4));
@@ -1029,6 +1038,7 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_coords.p, coords, (size_t)EW * P * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lc_full.p, lc_full.data(), (size_t)EW * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lc_half.p, lc_half.data(), (size_t)EH * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ens_lc_spec.p, lc_spec.data(), (size_t)3 * EH * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ens_naccept.p, 0, (size_t)EW * 4, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ens_notpd.p, 0, 4, s));
     // log-probability of the initial state (emcee evaluates p0 once); the rows are grouped by ensemble, hence by light curve
@@ -1336,9 +1346,41 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     g.best_coords = ctx->ens_best_coords.as<double>();
     g.n_notpd = ctx->ens_notpd.as<int32_t>();
     int bank = 0;
-    if (steps > 0)  // the first proposals of the run
+    // A small ensemble leaves most of the GPU idle and its solve takes as long for 3 H rows as for H: both half-steps of
+    // an iteration then go into one batch (mtg_sampler.hip: speculative iteration).  Where: the time-parallel kernels
+    // with every row on a workgroup of its own in one occupancy round -- 256 workgroups of four waves for long light
+    // curves (one per CU: their elements fill the LDS; two per CU up to rank 3), 1024 single-wave ones for short.
+    // Same chain either way.
+    const int Jmodel = ctx->model.nr0 + 2 * ctx->model.nc0;
+    const int64_t rows3 = 3 * EH;
+    const bool spec = steps > 0 && ctx->spec_mode != 0 && !sharded && ctx->tp_mode != 0 && Jmodel <= 6 && ctx->N >= 256 &&
+                      rows3 <= (ctx->N >= 4096 ? (Jmodel <= 3 ? 512 : 256) : 1024);
+    if (spec) {
+        rc = check_model_workspace(ctx, rows3);
+        if (rc) return rc;
+        auto prep3 = [&](int bank_) {
+            ctx->bank = bank_;
+            return make_prep_args(ctx, rows3, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>());
+        };
+        mtg_launch_sampler_spec(g, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, ctx->ens_iteration, prep3(bank), s);
+        for (int it = 0; it < steps; ++it) {
+            const uint32_t iter = ctx->ens_iteration;
+            ctx->bank = bank;
+            rc = solve_prepared(ctx, rows3, ctx->ens_lc_spec.as<int32_t>(), ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>(), s);
+            if (rc) return rc;
+            const bool more = it + 1 < steps;
+            int *used_counts = bank_counts(ctx);
+            mtg_launch_sampler_spec(g, 1, iter, ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>(), used_counts,
+                                    chain ? ctx->ens_chain.as<double>() + (size_t)it * EW * P : nullptr,
+                                    lnp_chain ? ctx->ens_lnp_chain.as<double>() + (size_t)it * EW : nullptr, more ? 1 : 0, iter + 1,
+                                    prep3(bank ^ 1), s);
+            bank ^= 1;
+            ctx->ens_iteration += 1;
+        }
+    }
+    if (steps > 0 && !spec)  // the first proposals of the run
         mtg_launch_sampler_step(g, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, ctx->ens_iteration, prep_args(bank), s);
-    for (int it = 0; it < steps; ++it) {
+    for (int it = 0; it < steps && !spec; ++it) {
         const uint32_t iter = ctx->ens_iteration;
         for (int half = 0; half < 2; ++half) {
             ctx->bank = bank;
@@ -1842,6 +1884,14 @@ MTG_API int mtg_set_tp_direct(mtg_ctx *ctx, int enabled)
 {
     if (!ctx) return MTG_E_ARG;
     ctx->tp_direct = enabled >= 2 ? enabled : (enabled ? 1 : 0);  // 2 (diagnostic): never fall back to the filter pass
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_speculation(mtg_ctx *ctx, int mode)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (mode < 0 || mode > 1) return fail(ctx, MTG_E_ARG, "mtg_set_speculation: mode must be 0 (never) or 1 (where it pays)");
+    ctx->spec_mode = mode;
     return MTG_OK;
 }
 

@@ -162,7 +162,7 @@ struct MtgEnsembleArgs {
     int32_t *perm;        // [E][W] red/blue split of the current iteration
     double *coords;       // [E][W][P]
     double *lnp;          // [E][W]
-    double *factor;       // [E][W/2] (P - 1) ln z of the current proposals
+    double *factor;       // [E][W/2] (P - 1) ln z of the current proposals ([2][E][W/2] for a speculative iteration)
     int32_t *naccept;     // [E][W]
     double *best_lnp;     // [E]
     double *best_coords;  // [E][P]
@@ -173,6 +173,11 @@ struct MtgEnsembleArgs {
 void mtg_launch_sampler_step(const MtgEnsembleArgs &g, int do_accept, int half, uint32_t iteration, const double *new_lnp,
                              const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
                              int next_half, uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t);
+// A whole iteration speculatively (mtg_sampler.hip): accept of both half-steps of `iteration` from the 3 E W/2 rows
+// in new_lnp / status, then the 3 E W/2 proposals of next_iteration (g.factor holds 2 E W/2 entries).
+void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t iteration, const double *new_lnp,
+                             const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
+                             uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t);
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
                              double *best_coords, hipStream_t);
 // TK95 light-curve simulation (mtg_simulate.hip)

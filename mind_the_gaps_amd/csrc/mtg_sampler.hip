@@ -63,41 +63,49 @@ enum { PURPOSE_SPLIT = 1, PURPOSE_PROPOSE = 2, PURPOSE_ACCEPT = 3 };
 //   proposal: z = ((a - 1) u + 1)^2 / a,  q = c_partner - (c_partner - s) z,  factor = (P - 1) ln z.
 //   expansion: mtg_prepare_one on the proposal (prior verdict, coefficient columns, structure lists).
 // s_key: W 64-bit keys, then W ranks (int), in LDS.
+// The red/blue split of one iteration: a uniformly random permutation of 0..W-1 from ranked 64-bit Philox keys (see
+// mtg_propose_part); perm[e][0..W/2) is the first half.  Ends with a barrier: the permutation is readable.
+__device__ __forceinline__ void mtg_split_part(const MtgEnsembleArgs &g, uint32_t iteration, uint64_t *s_key)
+{
+    const int W = g.W;
+    const int e = blockIdx.x;
+    int32_t *p = g.perm + (int64_t)e * W;
+    int *s_rank = (int *)(s_key + W);
+    for (int w = threadIdx.x; w < W; w += blockDim.x) {
+        const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, g.seed_lo, g.seed_hi);
+        s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
+        s_rank[w] = 0;
+    }
+    __syncthreads();
+    // rank of every key: W^2 comparisons spread over all the threads of the workgroup -- `parts` threads per
+    // walker, each counting over its share of the keys (one thread per walker and 512 serial comparisons were
+    // 12 us of the 25 us this kernel took at W = 256)
+    const int parts = blockDim.x >= (unsigned)W ? (int)blockDim.x / W : 1;
+    const int span = (W + parts - 1) / parts;
+    for (int i = threadIdx.x; i < W * parts; i += blockDim.x) {
+        const int w = i % W, part = i / W;
+        const uint64_t mine = s_key[w];
+        const int j0 = part * span, j1 = j0 + span < W ? j0 + span : W;
+        int rank = 0;
+        for (int j = j0; j < j1; ++j) {
+            const uint64_t other = s_key[j];
+            rank += (other < mine) || (other == mine && j < w);
+        }
+        if (parts > 1) atomicAdd(&s_rank[w], rank);
+        else s_rank[w] = rank;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += blockDim.x) p[s_rank[w]] = w;
+    __syncthreads();  // the permutation is read back below (same workgroup: visible after the barrier)
+}
+
 __device__ __forceinline__ void mtg_propose_part(const MtgEnsembleArgs &g, int half, uint32_t iteration, const MtgPrepArgs &pa,
                                                  uint64_t *s_key)
 {
     const int W = g.W, P = g.P, H = W / 2;
     const int e = blockIdx.x;
     int32_t *p = g.perm + (int64_t)e * W;
-    if (half == 0) {
-        int *s_rank = (int *)(s_key + W);
-        for (int w = threadIdx.x; w < W; w += blockDim.x) {
-            const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, g.seed_lo, g.seed_hi);
-            s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
-            s_rank[w] = 0;
-        }
-        __syncthreads();
-        // rank of every key: W^2 comparisons spread over all the threads of the workgroup -- `parts` threads per
-        // walker, each counting over its share of the keys (one thread per walker and 512 serial comparisons were
-        // 12 us of the 25 us this kernel took at W = 256)
-        const int parts = blockDim.x >= (unsigned)W ? (int)blockDim.x / W : 1;
-        const int span = (W + parts - 1) / parts;
-        for (int i = threadIdx.x; i < W * parts; i += blockDim.x) {
-            const int w = i % W, part = i / W;
-            const uint64_t mine = s_key[w];
-            const int j0 = part * span, j1 = j0 + span < W ? j0 + span : W;
-            int rank = 0;
-            for (int j = j0; j < j1; ++j) {
-                const uint64_t other = s_key[j];
-                rank += (other < mine) || (other == mine && j < w);
-            }
-            if (parts > 1) atomicAdd(&s_rank[w], rank);
-            else s_rank[w] = rank;
-        }
-        __syncthreads();
-        for (int w = threadIdx.x; w < W; w += blockDim.x) p[s_rank[w]] = w;
-        __syncthreads();  // the permutation is read back below (same workgroup: visible after the barrier)
-    }
+    if (half == 0) mtg_split_part(g, iteration, s_key);
     double *q = const_cast<double *>(pa.theta);  // the proposals ARE the batch the expansion reads
     for (int k0 = 0; k0 < H; k0 += blockDim.x) {  // uniform trip count: mtg_prepare_one votes per wave
         const int k = k0 + (int)threadIdx.x;
@@ -177,6 +185,146 @@ __device__ __forceinline__ void mtg_accept_part(const MtgEnsembleArgs &g, int ha
         for (int w = threadIdx.x; w < W; w += 256) lnp_chain_row[(int64_t)e * W + w] = g.lnp[(int64_t)e * W + w];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Speculative iteration: BOTH half-steps of an iteration in one batch of 3 E H rows.
+//
+// A small ensemble leaves most of the GPU idle: the time-parallel solve of 64 rows takes as long as that of 192.
+// The second half-step's proposals depend on the first half-step's outcome only through the partner's coordinates
+// -- the partner either accepted its proposal or kept its place -- so both candidates are evaluated beside the first
+// half-step's proposals, and the accept step picks the one that applies:
+//     rows [0, EH)       first half-step's proposals (as mtg_propose_part, half 0)
+//     rows [EH, 2 EH)    second half-step's proposals with the partner where it IS
+//     rows [2 EH, 3 EH)  ... with the partner where its own proposal would put it
+// One solve and one launch of this kernel per iteration instead of two and two.  Same Philox counters as the
+// sequential form, hence the same chain to the last bit where the solver's arithmetic for a row does not depend on
+// the batch (tests/test_device_sampler_gpu.py compares the two).
+__device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint32_t iteration, const MtgPrepArgs &pa, uint64_t *s_key)
+{
+    const int W = g.W, P = g.P, H = W / 2;
+    const int e = blockIdx.x;
+    const int64_t EH = (int64_t)g.E * H;
+    const int32_t *p = g.perm + (int64_t)e * W;
+    mtg_split_part(g, iteration, s_key);
+    double *q = const_cast<double *>(pa.theta);
+    // the first half-step's proposals: one thread each
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const int64_t i = (int64_t)e * H + k;
+        const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+        const double u = u01(r.c[0], r.c[1]);
+        const double zr = (g.a - 1.0) * u + 1.0;
+        const double z = zr * zr / g.a;
+        const int w = p[k];
+        const int partner = p[H + (int)(u01(r.c[2], r.c[3]) * (double)H)];
+        const double *s = g.coords + ((int64_t)e * W + w) * P;
+        const double *c = g.coords + ((int64_t)e * W + partner) * P;
+        double *qo = q + i * P;
+        for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
+        g.factor[i] = (double)(P - 1) * log(z);
+    }
+    __syncthreads();  // ... which other threads of this workgroup read as the partner's would-be place
+    // the second half-step's two candidates: one thread per candidate
+    for (int t = threadIdx.x; t < 2 * H; t += blockDim.x) {
+        const int k = t % H, which = t / H;
+        const int64_t i = (int64_t)e * H + k;
+        const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+        const double u = u01(r.c[0], r.c[1]);
+        const double zr = (g.a - 1.0) * u + 1.0;
+        const double z = zr * zr / g.a;
+        const int w = p[H + k];
+        const int j = (int)(u01(r.c[2], r.c[3]) * (double)H);              // the partner's slot in the first half
+        const double *s = g.coords + ((int64_t)e * W + w) * P;
+        const double *c = which ? q + ((int64_t)e * H + j) * P              // where its proposal would put it
+                                : g.coords + ((int64_t)e * W + p[j]) * P;   // where it is
+        double *qo = q + ((which ? 2 * EH : EH) + i) * P;
+        for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
+        if (!which) g.factor[EH + i] = (double)(P - 1) * log(z);
+    }
+    __syncthreads();  // every row is expanded by the thread with its number, not by the one that wrote it
+    for (int t0 = 0; t0 < 3 * H; t0 += blockDim.x) {  // uniform trip count: mtg_prepare_one votes per wave
+        const int t = t0 + (int)threadIdx.x;
+        const bool live = t < 3 * H;
+        const int block = live ? t / H : 0, k = live ? t % H : 0;
+        mtg_prepare_one(pa, (int64_t)block * EH + (int64_t)e * H + k, live);
+    }
+}
+
+// Accept / reject of both half-steps of a speculative iteration (rows as above).  s_acc: H ints of LDS.
+__device__ __forceinline__ void mtg_accept_both(const MtgEnsembleArgs &g, uint32_t iteration, const double *q, const double *new_lnp,
+                                                const int32_t *status, int *clear_counts, double *chain_row,
+                                                double *lnp_chain_row, double *s_best, int *s_idx, int *s_acc)
+{
+    const int W = g.W, P = g.P, H = W / 2;
+    const int e = blockIdx.x;
+    const int64_t EH = (int64_t)g.E * H;
+    const bool worker = threadIdx.x < 256;
+    if (e == 0 && threadIdx.x < 64 && clear_counts) clear_counts[threadIdx.x] = 0;
+    double my_best = -INFINITY;
+    int64_t my_idx = -1;
+    for (int half = 0; half < 2; ++half) {
+        if (worker)
+            for (int k = threadIdx.x; k < H; k += 256) {
+                const int64_t i = (int64_t)e * H + k;
+                int64_t row = i;  // the row that holds this walker's proposal
+                if (half == 1) {
+                    const Philox rp = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+                    const int j = (int)(u01(rp.c[2], rp.c[3]) * (double)H);
+                    row = (s_acc[j] ? 2 * EH : EH) + i;
+                }
+                const int w = g.perm[(int64_t)e * W + half * H + k];
+                const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+                const double lu = log(u01(r.c[0], r.c[1]));
+                const double cand = new_lnp[row];
+                if (status[row] == MTG_ST_NOTPD) atomicAdd(g.n_notpd, 1);
+                const int64_t wi = (int64_t)e * W + w;
+                const double diff = g.factor[half ? EH + i : i] + cand - g.lnp[wi];
+                const bool accept = diff > lu;  // false for NaN and for cand = -inf
+                if (half == 0) s_acc[k] = accept ? 1 : 0;
+                if (accept) {
+                    for (int d = 0; d < P; ++d) g.coords[wi * P + d] = q[row * P + d];
+                    g.lnp[wi] = cand;
+                    g.naccept[wi] += 1;
+                    if (cand > my_best) { my_best = cand; my_idx = row; }
+                }
+            }
+        __syncthreads();  // half 0: the accept flags; half 1: this workgroup's updates of the ensemble
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(my_best, off);
+        const int64_t oi = __shfl_down(my_idx, off);
+        if (ob > my_best) { my_best = ob; my_idx = oi; }
+    }
+    if (worker && (threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = my_best; s_idx[threadIdx.x >> 6] = (int)my_idx; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int wv = 1; wv < 4; ++wv)
+            if (s_best[wv] > s_best[0]) { s_best[0] = s_best[wv]; s_idx[0] = s_idx[wv]; }
+    if (threadIdx.x == 0 && s_idx[0] >= 0 && s_best[0] > g.best_lnp[e]) {
+        g.best_lnp[e] = s_best[0];
+        for (int d = 0; d < P; ++d) g.best_coords[(int64_t)e * P + d] = q[(int64_t)s_idx[0] * P + d];
+    }
+    if (chain_row && worker)
+        for (int j = threadIdx.x; j < W * P; j += 256)
+            chain_row[(int64_t)e * W * P + j] = g.coords[(int64_t)e * W * P + j];
+    if (lnp_chain_row && worker)
+        for (int w = threadIdx.x; w < W; w += 256) lnp_chain_row[(int64_t)e * W + w] = g.lnp[(int64_t)e * W + w];
+}
+
+__global__ void __launch_bounds__(1024)
+mtg_sampler_spec_kernel(MtgEnsembleArgs g, int do_accept, uint32_t iteration, const double *new_lnp, const int32_t *status,
+                        int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose, uint32_t next_iteration,
+                        MtgPrepArgs pa)
+{
+    extern __shared__ uint64_t s_key[];   // W keys, W ranks (int), H accept flags (int)
+    __shared__ double s_best[256];
+    __shared__ int s_idx[256];
+    int *s_acc = (int *)(s_key + g.W) + g.W;
+    if (do_accept) {
+        mtg_accept_both(g, iteration, pa.theta, new_lnp, status, clear_counts, chain_row, lnp_chain_row, s_best, s_idx, s_acc);
+        __syncthreads();
+    }
+    if (do_propose) mtg_propose_both(g, next_iteration, pa, s_key);
+}
+
 // One kernel between two solves: the accept step of the half-step just evaluated, then -- do_propose -- the
 // proposals of the next one (expanded into the OTHER bank of structure lists: workgroup 0 clears the bank the
 // solver has just used while the others may already be appending to the next one).  do_accept = 0: the very first
@@ -225,6 +373,16 @@ void mtg_launch_sampler_step(const MtgEnsembleArgs &g, int do_accept, int half, 
     hipLaunchKernelGGL(mtg_sampler_step_kernel, dim3((unsigned)g.E), dim3(threads), (size_t)g.W * (sizeof(uint64_t) + sizeof(int)), s,
                        g, do_accept, half, iteration, new_lnp, status, clear_counts, chain_row, lnp_chain_row, do_propose, next_half,
                        next_iteration, pa);
+}
+
+void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t iteration, const double *new_lnp,
+                             const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
+                             uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t s)
+{
+    const int threads = do_propose && g.E <= 64 ? 1024 : 256;   // (the split ranks W keys against each other)
+    hipLaunchKernelGGL(mtg_sampler_spec_kernel, dim3((unsigned)g.E), dim3(threads),
+                       (size_t)g.W * (sizeof(uint64_t) + sizeof(int)) + (size_t)(g.W / 2) * sizeof(int), s, g, do_accept, iteration,
+                       new_lnp, status, clear_counts, chain_row, lnp_chain_row, do_propose, next_iteration, pa);
 }
 
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,

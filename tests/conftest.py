@@ -29,3 +29,13 @@ def engine():
     eng = Engine(0)
     yield eng
     eng.close()
+
+
+@pytest.fixture(autouse=True)
+def _stacks_if_a_test_hangs():
+    """A test still running after five minutes writes every thread's Python stack to stderr (and goes on): a hang
+    on the GPU box then says where it waits instead of only timing the run out."""
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=False)
+    yield
+    faulthandler.cancel_dump_traceback_later()

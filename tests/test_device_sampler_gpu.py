@@ -180,3 +180,37 @@ def test_resume_is_bit_for_bit_where_the_batch_size_picks_the_kernel(engine, tmp
     assert np.array_equal(second.get_chain(), whole.get_chain()) and np.array_equal(second.get_log_prob(), whole.get_log_prob())
     for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
         assert np.array_equal(state[key], whole.state[key]), key
+
+
+@pytest.mark.parametrize("case", ["drw_n1000_w32", "null_n5000_w32", "alt_three_ensembles"])
+def test_speculative_iterations_give_the_sequential_chain(engine, case):
+    """Both half-steps of an iteration in one batch of 3 E W/2 rows (mtg_set_speculation, the default for small
+    ensembles) against one solve per half-step: the same random numbers, the same rows through the same kernels,
+    hence the same chain, acceptance counts and running best to the last bit."""
+    kinds, N, E, W = {"drw_n1000_w32": ([synth.K_DRW], 1000, 1, 32), "null_n5000_w32": (synth.NULL_MODEL, 5000, 1, 32),
+                      "alt_three_ensembles": (synth.ALT_MODEL, 600, 3, 16)}[case]
+    steps, seed = 60, 0xFEEDBEEF
+    p0, oracle_lnp = setup_problem(engine, kinds, N, E, W, seed=11)
+    if case == "alt_three_ensembles":
+        p0[:, ::3, 3] = np.log(0.3)                                  # some walkers start over-damped: two structures
+    results = {}
+    try:
+        for mode in (0, 1):
+            engine.set_speculation(mode)
+            engine.ensemble_init(p0, seed=seed)
+            chain, lnp_chain = engine.ensemble_run(steps, store_chain=True)
+            more, more_lnp = engine.ensemble_run(7, store_chain=True)       # continuing works the same
+            results[mode] = (chain, lnp_chain, more, more_lnp, engine.ensemble_state())
+    finally:
+        engine.set_speculation(1)
+    a, b = results[0], results[1]
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y)
+    for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
+        assert np.array_equal(a[4][key], b[4][key]), key
+    assert a[4]["iteration"] == b[4]["iteration"] == steps + 7 and a[4]["n_not_pd"] == b[4]["n_not_pd"]
+    assert 0.1 < a[4]["naccept"].mean() / (steps + 7) < 0.9
+    if case == "drw_n1000_w32":                                   # and it is the chain the host replay makes
+        lnp0 = oracle_lnp(p0.reshape(E * W, -1), np.repeat(np.arange(E), W)).reshape(E, W)
+        ref_chain, ref_lnp, ref_acc = philox_replay.run(p0, lnp0, oracle_lnp, steps, seed)
+        assert np.allclose(b[0], ref_chain, rtol=0, atol=1e-10)
