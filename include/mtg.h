@@ -202,8 +202,9 @@ MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
  * proposal would put it.  Both candidates are then evaluated beside the first half-step's proposals, one solve and one
  * sampler launch per iteration instead of two and two (1.9 x the iterations per second for BASELINE configs[0] and
  * [1]).  Taken when all 3 E W/2 rows get a workgroup of their own in one occupancy round (light curves of >= 4096
- * samples: <= 256 rows, <= 512 up to rank 3; <= 1024 rows below), J <= 6, not walker-sharded.  The random numbers, hence the chain, are those of
- * the sequential form (to the last bit where the solver's arithmetic for a row does not depend on the batch size).
+ * samples: <= 512 rows up to rank 5, <= 256 at rank 6; <= 1024 rows below), J <= 6, not walker-sharded.  The random numbers, hence the chain, are those of
+ * the sequential form -- to the last bit where both forms run the same kernel (the batch size picks it: e.g. rank 5,
+ * 256 walkers: four waves per evaluation for the 128 rows of a half-step, two for the 384 of a speculative iteration).
  */
 MTG_API int mtg_set_speculation(mtg_ctx *ctx, int mode);
 /* Name of the kernel the last batch was dispatched to, e.g. "mtg_solve_kernel<1,2,1>" (first structure of the

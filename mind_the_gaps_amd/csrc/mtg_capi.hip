@@ -444,9 +444,14 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // elements take 68 KB of LDS; above: one)
     // (scripts/spec_probe.py, J = 3, N = 1e4: 384 rows 70.9 us against 96.0 us with one wave each, 512 rows 77.4 / 97.2)
     const bool wide = Bw <= (Jmodel <= 3 ? 512 : 256) && ctx->N >= 4096;
+    // two waves per evaluation between 257 and 512 rows of rank 4 or 5: half a CU's LDS each, all resident at once
+    // (scripts/spec_probe.py, J = 5, N = 1e4, 384 rows: see DESIGN.md)
+    const bool mid = !wide && Bw <= 512 && ctx->N >= 4096 && (Jmodel == 4 || Jmodel == 5);
     mtg_solve_launcher fused = nullptr;
+    int fused_lanes = 64;
     if (small_ok && nsig > 1) {
-        if (wide) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256);
+        if (wide && (fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256))) fused_lanes = 256;
+        if (!fused && mid && (fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 128))) fused_lanes = 128;
         if (!fused) fused = mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 64);
     }
     sa.solo = 0; sa.left_list = nullptr; sa.left_count = nullptr;
@@ -480,8 +485,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     } else if (fused) {  // every signature in one launch
         sa.list = bank_lists(ctx);
         sa.count_ptr = bank_counts(ctx);
-        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_fused_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig,
-                 wide && mtg_find_tp_fused_solver(m.nr0, m.nc0, nsig, 256) ? 256 : 64);
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_fused_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig, fused_lanes);
         fused(sa, B, s);
     } else if (mtg_solve_launcher multi = sorted && nsig > 1 && sa.yv_bytes <= sa.window_bytes && sweep_multi_enabled()
                                               ? mtg_find_multi_solver(m.nr0, m.nc0, nsig, m.last_b0) : nullptr) {
@@ -1349,12 +1353,12 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     // A small ensemble leaves most of the GPU idle and its solve takes as long for 3 H rows as for H: both half-steps of
     // an iteration then go into one batch (mtg_sampler.hip: speculative iteration).  Where: the time-parallel kernels
     // with every row on a workgroup of its own in one occupancy round -- 256 workgroups of four waves for long light
-    // curves (one per CU: their elements fill the LDS; two per CU up to rank 3), 1024 single-wave ones for short.
-    // Same chain either way.
+    // curves (one per CU: their elements fill the LDS; two per CU up to rank 3, and for ranks 4 and 5 with two waves
+    // each), 1024 single-wave ones for short.  Same chain either way where both forms run the same kernel.
     const int Jmodel = ctx->model.nr0 + 2 * ctx->model.nc0;
     const int64_t rows3 = 3 * EH;
     const bool spec = steps > 0 && ctx->spec_mode != 0 && !sharded && ctx->tp_mode != 0 && Jmodel <= 6 && ctx->N >= 256 &&
-                      rows3 <= (ctx->N >= 4096 ? (Jmodel <= 3 ? 512 : 256) : 1024);
+                      rows3 <= (ctx->N >= 4096 ? (Jmodel <= 5 ? 512 : 256) : 1024);
     if (spec) {
         rc = check_model_workspace(ctx, rows3);
         if (rc) return rc;

@@ -19,6 +19,9 @@ struct Sel<NR0, NSIG, LANES, false> { static constexpr mtg_solve_launcher fn = n
 #define ROW(nr0, lanes) { Sel<(nr0), 2, (lanes)>::fn, Sel<(nr0), 3, (lanes)>::fn, Sel<(nr0), 4, (lanes)>::fn }
 const mtg_solve_launcher table64[5][3] = {ROW(0, 64), ROW(1, 64), ROW(2, 64), ROW(3, 64), ROW(4, 64)};
 const mtg_solve_launcher table256[5][3] = {ROW(0, 256), ROW(1, 256), ROW(2, 256), ROW(3, 256), ROW(4, 256)};
+// two waves per evaluation: the elements of a rank-4 or rank-5 evaluation then take half a CU's LDS, two workgroups
+// share a CU, and 257 ... 512 evaluations are resident at once
+const mtg_solve_launcher table128[5][3] = {ROW(0, 128), ROW(1, 128), ROW(2, 128), ROW(3, 128), ROW(4, 128)};
 
 }  // namespace
 
@@ -28,5 +31,5 @@ const mtg_solve_launcher table256[5][3] = {ROW(0, 256), ROW(1, 256), ROW(2, 256)
 mtg_solve_launcher MTG_TPF_CAT(mtg_find_tp_fused_nc, MTG_TPF_NC0)(int nr0, int nsig, int lanes)
 {
     if (nr0 < 0 || nr0 > 4 || nsig < 2 || nsig > 4) return nullptr;
-    return (lanes == 256 ? table256 : table64)[nr0][nsig - 2];
+    return (lanes == 256 ? table256 : lanes == 128 ? table128 : table64)[nr0][nsig - 2];
 }
