@@ -214,3 +214,118 @@ def test_speculative_iterations_give_the_sequential_chain(engine, case):
         lnp0 = oracle_lnp(p0.reshape(E * W, -1), np.repeat(np.arange(E), W)).reshape(E, W)
         ref_chain, ref_lnp, ref_acc = philox_replay.run(p0, lnp0, oracle_lnp, steps, seed)
         assert np.allclose(b[0], ref_chain, rtol=0, atol=1e-10)
+
+
+# ---- the speculative iteration at the shapes it ships on (BASELINE configs[1] and [2]) ---------------------------
+# 3 E W/2 rows per iteration: 192 rows for the 128 walkers of configs[1] (four waves per evaluation, 1024-thread
+# mtg_sampler_spec_kernel), 384 rows for the 256 walkers of configs[2] (two waves per evaluation at rank 5).  The
+# sequential form evaluates W/2 = 64 / 128 rows per half-step, which the dispatch sends to the four-wave kernels: the
+# two forms then run DIFFERENT kernels for the same row, whose sums differ in the last bits -- what holds between them is
+# "the same decisions, log-probabilities to rounding", not "the same bits" (that holds where both forms dispatch the
+# same kernel: test_speculative_iterations_give_the_sequential_chain above).
+SHIPPED = {"configs1_null_w128": (synth.NULL_MODEL, 128, 192), "configs2_alt_w256": (synth.ALT_MODEL, 256, 384)}
+
+
+def _shipped_problem(engine, case, overdamped=False):
+    kinds, W, rows = SHIPPED[case]
+    p0, oracle_lnp = setup_problem(engine, kinds, 10000, 1, W, seed=21)
+    if overdamped:
+        p0[:, ::5, 3] = np.log(0.3)               # every fifth walker starts with its SHO term over-damped (Q < 1/2)
+    lnp0 = oracle_lnp(p0.reshape(W, -1), np.zeros(W, dtype=np.int64)).reshape(1, W)
+    return kinds, W, rows, p0, lnp0, oracle_lnp
+
+
+@pytest.mark.parametrize("case", sorted(SHIPPED))
+def test_speculative_sampler_at_the_shipped_shapes_replays_on_the_host(engine, case):
+    """(a) of the round-3 review: 40 default (speculative) iterations of the device sampler at N = 1e4, replayed on the
+    host with the ORACLE likelihood: every accept decision equal, chain within 1e-10, log-probabilities within 1e-9."""
+    kinds, W, rows, p0, lnp0, oracle_lnp = _shipped_problem(engine, case)
+    steps, seed = 40, 0xC0FFEE123
+    engine.set_speculation(1)
+    engine.ensemble_init(p0, seed=seed)
+    st0 = engine.ensemble_state()
+    assert np.max(np.abs(st0["log_prob"] - lnp0) / np.abs(lnp0)) < 1e-9
+    chain, lnp_chain = engine.ensemble_run(steps, store_chain=True)
+    solver = engine.last_solver
+    assert "mtg_tp_" in solver, solver                                # a time-parallel kernel took the 3 W/2 rows
+    ref_chain, ref_lnp, ref_acc = philox_replay.run(p0, lnp0, oracle_lnp, steps, seed)
+    st = engine.ensemble_state()
+    assert np.array_equal(st["naccept"], ref_acc)                     # the same decisions, walker by walker
+    moved = np.any(chain[1:] != chain[:-1], axis=-1)
+    assert np.array_equal(moved, np.any(ref_chain[1:] != ref_chain[:-1], axis=-1))
+    assert np.allclose(chain, ref_chain, rtol=0, atol=1e-10)
+    assert np.allclose(lnp_chain, ref_lnp, rtol=1e-9, atol=0)
+    assert st["iteration"] == steps and st["n_not_pd"] == 0
+    assert 0.02 < st["naccept"].mean() / steps < 0.95
+
+
+@pytest.mark.parametrize("case", sorted(SHIPPED))
+def test_speculative_and_sequential_forms_at_the_shipped_shapes(engine, case):
+    """(b): the same run with one solve per half-step.  The two forms send a row through different kernels at these
+    sizes (rows per batch pick the kernel), so: identical accept decisions and coordinates that differ only through
+    nothing at all -- a proposal is a function of coordinates and random numbers, not of log-probabilities -- while the
+    stored log-probabilities agree to rounding (1e-12 relative; ~1e-14 observed)."""
+    kinds, W, rows, p0, lnp0, oracle_lnp = _shipped_problem(engine, case)
+    steps, seed = 40, 0xC0FFEE123
+    out = {}
+    try:
+        for mode in (0, 1):
+            engine.set_speculation(mode)
+            engine.ensemble_init(p0, seed=seed)
+            chain, lnp_chain = engine.ensemble_run(steps, store_chain=True)
+            out[mode] = (chain, lnp_chain, engine.ensemble_state(), engine.last_solver)
+    finally:
+        engine.set_speculation(1)
+    (c0, l0, s0, k0), (c1, l1, s1, k1) = out[0], out[1]
+    assert np.array_equal(s0["naccept"], s1["naccept"])
+    assert np.array_equal(c0, c1)                                     # same decisions => the very same coordinates
+    assert np.max(np.abs(l0 - l1) / np.abs(l0)) < 1e-12, (k0, k1)
+    assert np.allclose(s0["best_log_prob"], s1["best_log_prob"], rtol=1e-12) and s0["iteration"] == s1["iteration"] == steps
+
+
+def test_speculative_sampler_with_two_structures_in_a_384_row_batch(engine):
+    """(c): a fifth of the 256 walkers start over-damped (SHO as two real terms): the 384 rows of an iteration hold both
+    structures and go through the fused kernel (every structure in one launch).  Host replay with the oracle."""
+    kinds, W, rows, p0, lnp0, oracle_lnp = _shipped_problem(engine, "configs2_alt_w256", overdamped=True)
+    steps, seed = 30, 0xABCDEF01
+    engine.set_speculation(1)
+    engine.ensemble_init(p0, seed=seed)
+    chain, lnp_chain = engine.ensemble_run(steps, store_chain=True)
+    assert "mtg_tp_fused_kernel" in engine.last_solver, engine.last_solver
+    over = chain[..., 3] < np.log(0.5)
+    assert over.any() and (~over).any()                               # both structures were sampled throughout
+    assert over[-1].any()
+    ref_chain, ref_lnp, ref_acc = philox_replay.run(p0, lnp0, oracle_lnp, steps, seed)
+    assert np.array_equal(engine.ensemble_state()["naccept"], ref_acc)
+    assert np.allclose(chain, ref_chain, rtol=0, atol=1e-10)
+    assert np.allclose(lnp_chain, ref_lnp, rtol=1e-9, atol=0)
+
+
+def test_resume_across_a_speculative_run_at_256_walkers(engine, tmp_path):
+    """(d): save / load in the middle of a speculative run of configs[2]'s shape: the continuation is the one-go chain
+    bit for bit (the restart evaluates nothing: the saved log-probabilities come back through mtg_ensemble_restore)."""
+    from mind_the_gaps_amd.device_sampler import DeviceEnsembleSampler
+    kinds, W = synth.ALT_MODEL, 256
+    t, y, dy = synth.make_lightcurves(10000, 1, seed=21)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+
+    def bind():
+        engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+        engine.set_model(kinds, full, free, bounds)
+        engine.set_speculation(1)
+        return engine
+    P = len(free)
+    p0 = synth.draw_thetas(kinds, W, seed=2, percent=0.02)[None]
+    whole = DeviceEnsembleSampler(bind, W, P, seed=4321)
+    whole.run_mcmc(p0, 9)
+    first = DeviceEnsembleSampler(bind, W, P, seed=4321)
+    first.run_mcmc(p0, 4)
+    first.save(tmp_path / "ckpt")
+    second = DeviceEnsembleSampler(bind, W, P, seed=1)
+    restored = second.load(tmp_path / "ckpt")
+    assert np.array_equal(restored["log_prob"], first.state["log_prob"])
+    state = second.run_mcmc(None, 5)
+    assert second.iteration == 9
+    assert np.array_equal(second.get_chain(), whole.get_chain()) and np.array_equal(second.get_log_prob(), whole.get_log_prob())
+    for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
+        assert np.array_equal(state[key], whole.state[key]), key
