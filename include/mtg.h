@@ -196,6 +196,16 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
 MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
 /*
+ * The serial sweep as a two-wave pipeline (csrc/mtg_kernels_pipe.hip): 0 = never, 1 = whenever the model has the
+ * kernel (ranks 3-6 with a complex term; light curves of at least 64 samples; measurements and tests), 2 (default) =
+ * for batches beyond the time-parallel kernels' range that still fit one workgroup of 128 rows per compute unit
+ * (32 768 rows on an MI355X), where the one-lane-per-evaluation launch would leave a lone wave on half of the SIMDs:
+ * e.g. one GPU's share of the Protassov refits at 8 GPUs -- 250 light curves x 128 walkers per half-step of the
+ * reference's loop (docs/notebooks/tutorial_ppp.ipynb:326-343, gpmodelling.py:247-248).  A row's result is the
+ * same to the last bit as from the one-lane kernel.
+ */
+MTG_API int mtg_set_pipeline(mtg_ctx *ctx, int mode);
+/*
  * Speculative iterations of mtg_ensemble_run (default 1 = where they pay, 0 = never).  The time-parallel solve of a
  * small batch takes as long for three times the rows -- most of the GPU is idle -- and the second half-step of a
  * stretch-move iteration depends on the first only through each partner's coordinates: where it is, or where its own

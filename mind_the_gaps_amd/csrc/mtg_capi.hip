@@ -84,6 +84,8 @@ struct mtg_ctx {
     // small batches: one wave per evaluation, parallel in time (0 never, 1 whenever compiled, 2 auto)
     int tp_mode = 2;
     int tp_direct = 1;  // rank-10 time-parallel path: likelihood without the filter pass (mtg_set_tp_direct)
+    int pipe_mode = 2;  // two-wave pipeline of the serial sweep (mtg_set_pipeline): 0 never, 1 whenever compiled, 2 auto
+    int cus = 0;        // compute units of the device
 
     // device-resident ensembles (mtg_ensemble_*)
     int64_t ens_E = 0;
@@ -447,6 +449,13 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // two waves per evaluation between 257 and 512 rows of rank 4 or 5: half a CU's LDS each, all resident at once
     // (scripts/spec_probe.py, J = 5, N = 1e4, 384 rows: see DESIGN.md)
     const bool mid = !wide && Bw <= 512 && ctx->N >= 4096 && (Jmodel == 4 || Jmodel == 5);
+    // Between the time-parallel kernels' range and ~one wave per SIMD the serial sweep is one lone wave per 64 rows on
+    // a fraction of the SIMDs, N dependent steps of ~166 instructions: the pipelined form puts the generators of those
+    // rows on a second wave (mtg_kernels_pipe.hip) -- one workgroup of 128 rows per CU, all resident at once.
+    mtg_solve_launcher pipe = nullptr;
+    if (!small_ok && ctx->pipe_mode != 0 && ctx->N >= 64 && sa.yv_bytes <= sa.window_bytes &&
+        (ctx->pipe_mode == 1 || (ctx->N >= 256 && B <= (int64_t)MTG_PIPE_ROWS_PER_CU * ctx->cus)))
+        pipe = mtg_find_pipe_solver(m.nr0, m.nc0, nsig, m.last_b0);
     mtg_solve_launcher fused = nullptr;
     int fused_lanes = 64;
     if (small_ok && nsig > 1) {
@@ -487,6 +496,13 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         sa.count_ptr = bank_counts(ctx);
         snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_fused_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig, fused_lanes);
         fused(sa, B, s);
+    } else if (pipe && (nsig == 1 || sorted)) {
+        sa.list = sorted;            // nsig == 1: the sorted order, or NULL = the caller's
+        sa.count_ptr = nullptr;
+        sa.seg_counts = nsig > 1 ? bank_counts(ctx) : nullptr;
+        sa.seg_k = 0;
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_pipe_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0);
+        pipe(sa, B, s);
     } else if (mtg_solve_launcher multi = sorted && nsig > 1 && sa.yv_bytes <= sa.window_bytes && sweep_multi_enabled()
                                               ? mtg_find_multi_solver(m.nr0, m.nc0, nsig, m.last_b0) : nullptr) {
         // every structure of the sorted order in one launch of identical workgroups (mtg_kernels_multi.hip)
@@ -608,6 +624,8 @@ MTG_API mtg_ctx *mtg_create(int device)
         delete ctx;
         return nullptr;
     }
+    if (hipDeviceGetAttribute(&ctx->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->cus <= 0)
+        ctx->cus = 256;
     return ctx;
 }
 
@@ -1881,6 +1899,14 @@ MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return MTG_E_ARG;
     ctx->tp_mode = mode;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_pipeline(mtg_ctx *ctx, int mode)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (mode < 0 || mode > 2) return fail(ctx, MTG_E_ARG, "pipeline mode must be 0, 1 or 2");
+    ctx->pipe_mode = mode;
     return MTG_OK;
 }
 

@@ -149,6 +149,11 @@ hipError_t mtg_launch_sort_by_lightcurve(int64_t B, const int32_t *status, const
 // every structure of a sorted batch in one launch (mtg_kernels_multi.hip): a.list = the sorted order, a.seg_counts =
 // the rows per structure; nullptr when the combination is not compiled
 mtg_solve_launcher mtg_find_multi_solver(int nr0, int nc0, int nsig, int last_b0);
+// the serial sweep as a producer / consumer pipeline of two waves per 64 rows (mtg_kernels_pipe.hip), for batches that
+// leave the one-lane-per-evaluation launch a single wave on half of the SIMDs; nsig = 1: list / count_ptr as for
+// mtg_find_solver's kernels, nsig > 1: the sorted order and seg_counts as for mtg_find_multi_solver's
+mtg_solve_launcher mtg_find_pipe_solver(int nr0, int nc0, int nsig, int last_b0);
+#define MTG_PIPE_ROWS_PER_CU 128
 // does mtg_find_solver(nr, nc, last_b0) return the b = 0 specialisation?
 int mtg_solver_uses_b0(int nr, int nc, int last_b0);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,

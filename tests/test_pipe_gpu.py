@@ -1,0 +1,158 @@
+"""The serial sweep as a two-wave pipeline (csrc/mtg_sweep_pipe.h, mtg_kernels_pipe.hip; mtg_set_pipeline): a producer
+wave computes the generators of every sample, a consumer wave runs the recurrences.  Same expressions in the same
+order as the one-lane-per-evaluation sweep, so a row must come out THE SAME TO THE LAST BIT as from
+mtg_solve_kernel / mtg_solve_kernel_multi -- and within 1e-8 of the oracle (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from mind_the_gaps_amd import synthetic as synth
+from oracle import celerite as oracle_c
+
+pytestmark = pytest.mark.gpu
+
+K = synth
+MODELS = {
+    "null_drw_sho": [K.K_DRW, K.K_SHO],                      # (1, 1) / (3, 0): two structures
+    "alt_drw_sho_lorentzian": K.ALT_MODEL,                   # (1, 2) / (3, 1), last complex term with b = 0
+    "drw_lorentzian": [K.K_DRW, K.K_LORENTZIAN],             # (1, 1), one structure, b = 0
+    "real_complex4": [K.K_REAL, K.K_COMPLEX4],               # (1, 1), one structure, b != 0
+    "two_sho": [K.K_SHO, K.K_SHO],                           # (0, 2) / (2, 1) / (4, 0): three structures
+    "drw_complex4_complex3_real": [K.K_DRW, K.K_COMPLEX4, K.K_COMPLEX3, K.K_REAL],   # (2, 2): rank 6
+    "matern_sho": [K.K_MATERN32, K.K_SHO],                   # (0, 2) / (2, 1)
+}
+
+
+@pytest.fixture
+def pipe(engine):
+    engine.set_time_parallel(0)
+    yield engine
+    engine.set_pipeline(2)
+    engine.set_time_parallel(2)
+
+
+def both(eng, theta, lc, add_prior=True):
+    eng.set_pipeline(0)
+    want, wst = eng.loglike(theta, lc, add_prior=add_prior)
+    serial = eng.last_solver
+    eng.set_pipeline(1)
+    got, gst = eng.loglike(theta, lc, add_prior=add_prior)
+    assert "mtg_pipe_kernel" in eng.last_solver and "mtg_pipe_kernel" not in serial, (serial, eng.last_solver)
+    return want, wst, got, gst
+
+
+@pytest.mark.parametrize("name", sorted(MODELS))
+@pytest.mark.parametrize("N", [64, 71, 77, 1000, 1002, 1003, 1009])
+def test_pipeline_is_the_serial_sweep_bit_for_bit(pipe, name, N):
+    """Every compiled shape, light-curve lengths on all sides of the chunking (four samples per hand-over, trips of three
+    chunks), several light curves in scattered order, prior rejections and both SHO regimes in one batch."""
+    kinds = MODELS[name]
+    L, B = 7, 900
+    t, y, dy = synth.make_lightcurves(N, L, seed=N)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    pipe.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    pipe.set_model(kinds, full, free, bounds)
+    rng = np.random.default_rng(5)
+    theta = synth.draw_thetas(kinds, B, seed=N + 1, percent=0.5 if K.K_SHO in kinds else 0.15)
+    theta[::97, 0] = 60.0                                       # outside the prior box
+    lc = rng.integers(0, L, B).astype(np.int32)
+    want, wst, got, gst = both(pipe, theta, lc)
+    assert np.array_equal(gst, wst)
+    ok = wst == 0
+    assert ok.sum() > B // 2 and (wst == 1).sum() >= 9
+    assert np.array_equal(got, want)                            # -inf where rejected, bit for bit elsewhere
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, y.mean(axis=1)[lc][:, None]]),
+                                      bounds=bounds, lc_index=lc, add_prior=True, nthreads=8)
+    assert np.array_equal(rst, gst)
+    assert np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
+
+
+def test_pipeline_with_a_fitted_mean_jitter_and_per_lightcurve_times(pipe):
+    """The MEAN variant of the consumer (linear mean function fitted, JitterTerm) and per-light-curve sampling."""
+    N, L, B = 333, 5, 640
+    rng = np.random.default_rng(8)
+    t = np.cumsum(0.05 + rng.exponential(1.0, (L, N)), axis=1)
+    _, y, dy = synth.make_lightcurves(N, L, seed=12)
+    kinds = [K.K_DRW, K.K_SHO, K.K_JITTER]
+    from mind_the_gaps_amd.engine import MEAN_LINEAR
+    full, free, bounds = synth.model_spec(kinds, y, mean_kind=MEAN_LINEAR, fit_mean=True)
+    pipe.set_lightcurves(t, y, dy + 1e-12)
+    pipe.set_model(kinds, full, free, bounds, mean_kind=MEAN_LINEAR)
+    theta = np.tile(full, (B, 1)) + 0.05 * rng.standard_normal((B, len(full)))
+    theta[:, -2] = 1e-3 * rng.standard_normal(B)                # slope
+    theta[::4, 3] = np.log(0.2)                                 # over-damped rows
+    lc = rng.integers(0, L, B).astype(np.int32)
+    want, wst, got, gst = both(pipe, theta, lc, add_prior=False)
+    assert np.array_equal(gst, wst) and np.all(gst == 0)
+    assert np.array_equal(got, want)
+
+
+def test_pipeline_takes_the_libm_sincos_with_the_serial_sweep(pipe):
+    """A row whose phase step leaves the table's range sends its 64 rows through the libm sincos in both kernels
+    (decided per 64 consecutive rows of the order in both): still bit for bit."""
+    rng = np.random.default_rng(3)
+    t = np.cumsum(rng.exponential(0.5, 150))
+    t[75:] += 2.0e8
+    y, dy = rng.standard_normal(150), rng.uniform(0.2, 0.5, 150)
+    kinds = [K.K_COMPLEX3, K.K_DRW]
+    base = np.array([np.log(2.0), np.log(0.3), np.log(3.0), np.log(1.5), np.log(0.2)])
+    full, free = np.concatenate([base, [0.0]]), np.arange(5, dtype=np.int32)
+    bounds = np.tile([-np.inf, np.inf], (6, 1))
+    theta = base + 0.01 * rng.standard_normal((200, 5))
+    theta[70, 2] = np.log(9000.0)                               # d dx = 1.8e12 in the second group of 64 rows
+    pipe.set_lightcurves(t, y, dy + 1e-12)
+    pipe.set_model(kinds, full, free, bounds)
+    want, wst, got, gst = both(pipe, theta, None, add_prior=False)
+    assert np.array_equal(gst, wst) and np.array_equal(got, want)
+    pipe.set_pipeline(0)
+    calm, _ = pipe.loglike(np.delete(theta, 70, axis=0), None, add_prior=False)
+    # without that row its wave-mates take the table sincos: the first 64 rows are untouched, the next 63 are not
+    assert np.array_equal(calm[:64], want[:64]) and np.any(calm[64:127] != np.r_[want[64:70], want[71:128]])
+
+
+def test_pipeline_default_dispatch_and_the_device_sampler(pipe):
+    """Automatic mode: a batch beyond the time-parallel kernels' range that fits one workgroup per compute unit goes to
+    the pipeline, a larger one to the one-lane sweep; the device sampler's half-steps take it too, same chain."""
+    kinds = K.ALT_MODEL
+    N, L, W = 300, 96, 128
+    t, y, dy = synth.make_lightcurves(N, L, seed=2)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    pipe.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    pipe.set_model(kinds, full, free, bounds)
+    pipe.set_time_parallel(2)
+    pipe.set_pipeline(2)
+    B = L * W
+    theta = synth.draw_thetas(kinds, B, seed=4)
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    out, st = pipe.loglike(theta, lc)
+    assert "mtg_pipe_kernel" in pipe.last_solver, pipe.last_solver         # 12 288 rows
+    big = np.tile(theta, (4, 1))
+    out4, st4 = pipe.loglike(big, np.tile(lc, 4))
+    assert "mtg_solve_kernel" in pipe.last_solver, pipe.last_solver        # 49 152 rows: beyond one round
+    assert np.array_equal(out4[:B], out) and np.array_equal(st4[:B], st)
+    small, _ = pipe.loglike(theta[:2000], lc[:2000])
+    assert "mtg_tp_" in pipe.last_solver, pipe.last_solver
+    # the sampler: 96 ensembles x 64 proposals per half-step = 6144 rows -> time-parallel by default; force the serial
+    # forms and compare the chains
+    p0 = synth.truth(kinds) * (1 + 0.02 * np.random.default_rng(1).standard_normal((L, W, len(free))))
+    chains = []
+    pipe.set_time_parallel(0)
+    for mode in (0, 1):
+        pipe.set_pipeline(mode)
+        pipe.ensemble_init(p0, seed=99)
+        chains.append(pipe.ensemble_run(6, store_chain=True))
+        assert ("mtg_pipe_kernel" in pipe.last_solver) == bool(mode), pipe.last_solver
+    assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1])
+
+
+def test_models_without_a_pipeline_keep_the_one_lane_sweep(pipe):
+    """Three complex terms hand over more than the ring holds, a real-only model next to nothing: mtg_set_pipeline(1)
+    leaves them on the one-lane-per-evaluation sweep."""
+    t, y, dy = synth.make_lightcurves(200, 2, seed=3)
+    for kinds in ([K.K_COMPLEX4, K.K_COMPLEX3, K.K_LORENTZIAN], [K.K_DRW, K.K_REAL]):
+        full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+        pipe.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+        pipe.set_model(kinds, full, free, bounds)
+        pipe.set_pipeline(1)
+        theta = synth.draw_thetas(kinds, 300, seed=1)
+        out, st = pipe.loglike(theta, np.zeros(300, dtype=np.int32))
+        assert "mtg_solve_kernel" in pipe.last_solver and np.all(st <= 1) and np.all(np.isfinite(out[st == 0])) and (st == 0).sum() > 100
