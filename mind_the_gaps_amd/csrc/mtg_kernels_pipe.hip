@@ -15,7 +15,7 @@ namespace {
 template <int NR, int NC, int LASTB0>
 struct PipeB0 { static constexpr int value = (LASTB0 && NC > 0 && NR < 5 && NC < 4 && NR + 2 * NC <= 6) ? 1 : 0; };
 
-template <int NR, int NC, int NB0>
+template <int NR, int NC, int NB0, int CH>
 __device__ __forceinline__ void pipe_rows(const MtgSolveArgs &a, int64_t e, bool active, int wave, double2 *ring,
                                           const MtgMathTables *tab)
 {
@@ -32,24 +32,24 @@ __device__ __forceinline__ void pipe_rows(const MtgSolveArgs &a, int64_t e, bool
 #pragma unroll
         for (int k = 0; k < NC; ++k) dmax = fmax(dmax, fabs(a.coef[e + a.lay.dc(k) * a.cstride]));
         const bool fast = !__any(active && !(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
-        if (fast) mtg_pipe_produce<NR, NC, true>(a, e, toff, ring, tab);
-        else mtg_pipe_produce<NR, NC, false>(a, e, toff, ring, tab);
+        if (fast) mtg_pipe_produce<NR, NC, true, CH>(a, e, toff, ring, tab);
+        else mtg_pipe_produce<NR, NC, false, CH>(a, e, toff, ring, tab);
     } else {
         if (lost) {  // a device-side lc_index outside the resident set: no likelihood (as mtg_solve_row)
             a.out[e] = -INFINITY;
             a.status[e] = MTG_ST_NONFINITE;
         }
-        if (a.has_mean) mtg_pipe_consume<NR, NC, NB0, true>(a, e, active, yoff, toff, ring);
-        else mtg_pipe_consume<NR, NC, NB0, false>(a, e, active, yoff, toff, ring);
+        if (a.has_mean) mtg_pipe_consume<NR, NC, NB0, true, CH>(a, e, active, yoff, toff, ring);
+        else mtg_pipe_consume<NR, NC, NB0, false, CH>(a, e, active, yoff, toff, ring);
     }
 }
 
-template <int NR0, int NC0, int NSIG, int LASTB0, int S = 0>
+template <int NR0, int NC0, int NSIG, int LASTB0, int CH, int S = 0>
 __device__ __forceinline__ void pipe_dispatch(int k, const MtgSolveArgs &a, int64_t e, bool active, int wave,
                                               double2 *ring, const MtgMathTables *tab)
 {
-    if (k == S) pipe_rows<NR0 + 2 * S, NC0 - S, PipeB0<NR0 + 2 * S, NC0 - S, LASTB0>::value>(a, e, active, wave, ring, tab);
-    else if constexpr (S + 1 < NSIG) pipe_dispatch<NR0, NC0, NSIG, LASTB0, S + 1>(k, a, e, active, wave, ring, tab);
+    if (k == S) pipe_rows<NR0 + 2 * S, NC0 - S, PipeB0<NR0 + 2 * S, NC0 - S, LASTB0>::value, CH>(a, e, active, wave, ring, tab);
+    else if constexpr (S + 1 < NSIG) pipe_dispatch<NR0, NC0, NSIG, LASTB0, CH, S + 1>(k, a, e, active, wave, ring, tab);
 }
 
 template <int NR0, int NC0, int NSIG, int LASTB0>
@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(MTG_PIPE_BLOCK, 1) mtg_pipe_kernel(MtgSolveArg
         if (block * MTG_PIPE_ROWS >= count) return;
     }
     __shared__ MtgMathTables tab;
-    __shared__ double2 ring[2][MTG_PIPE_RING * MTG_PIPE_CHUNK * N2 * 64];
+    constexpr int CH = mtg_pipe_chunk(N2);
+    __shared__ double2 ring[2][MTG_PIPE_RING * CH * N2 * 64];
     mtg_fill_tables(&tab, threadIdx.x, MTG_PIPE_BLOCK);
     __syncthreads();
     const int wave = threadIdx.x >> 6, pair = wave & 1, lane = threadIdx.x & 63;
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(MTG_PIPE_BLOCK, 1) mtg_pipe_kernel(MtgSolveArg
     int64_t e = 0;
     if (active) e = a.list ? (int64_t)a.list[first + gid] : gid;
     if (active && a.status[e] != MTG_ST_OK) active = false;  // prior said -inf, or another rank's row
-    pipe_dispatch<NR0, NC0, NSIG, LASTB0>(k, a, e, active, wave, &ring[pair][lane], &tab);
+    pipe_dispatch<NR0, NC0, NSIG, LASTB0, CH>(k, a, e, active, wave, &ring[pair][lane], &tab);
 }
 
 template <int NR0, int NC0, int NSIG, int LASTB0>

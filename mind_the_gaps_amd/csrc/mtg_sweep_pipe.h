@@ -32,9 +32,15 @@
 
 #define MTG_PIPE_BLOCK 256   // four waves: producers of pair 0 and 1, consumers of pair 0 and 1
 #define MTG_PIPE_ROWS 128    // evaluations per workgroup
-#ifndef MTG_PIPE_CHUNK
-#define MTG_PIPE_CHUNK 4     // samples per hand-over (one barrier each); even: the pivot product is renormalised in pairs
+// samples per hand-over (one barrier each), by the 16-byte slots a sample takes in the kernel's widest structure:
+// 3 chunks x CH samples x N2 KiB x 2 pairs next to 48 KiB of tables in 160 KiB of LDS; even: the pivot product is
+// renormalised in pairs.  Rank 3 hands over two slots per sample and has room for eight samples per chunk; measured
+// (scripts/pipe_ab.py, 32 000 rows, N = 1e4): 1.47 ms with four, 1.58 with six, 1.62 with eight -- the unrolled trip
+// of 24 samples outgrows what the instruction cache keeps of the two roles.
+#ifndef MTG_PIPE_CHUNK_SMALL
+#define MTG_PIPE_CHUNK_SMALL 4
 #endif
+__host__ __device__ constexpr int mtg_pipe_chunk(int n2) { return n2 <= 2 ? MTG_PIPE_CHUNK_SMALL : 4; }
 #define MTG_PIPE_RING 3      // chunks in the ring: one being written, one being read, one in between
 
 // What the producer hands over per sample and lane: the NT = NR + NC propagators, then (cos, sin) of every complex
@@ -72,12 +78,12 @@ __device__ __forceinline__ void mtg_pipe_barrier_after(double &z, double &invD)
 // ---------------------------------------------------------------------------------------------------------------
 // producer: propagators and phases of every sample into ring[chunk mod R][sample][slot][lane]
 // ---------------------------------------------------------------------------------------------------------------
-template <int NR, int NC, bool FAST, class Tab>
+template <int NR, int NC, bool FAST, int CH, class Tab>
 __device__ __forceinline__ void mtg_pipe_produce(const MtgSolveArgs &a, int64_t e, uint32_t toff, double2 *ring,
                                                  const Tab *tab)
 {
 #pragma clang fp contract(off)
-    constexpr int R = MTG_PIPE_RING, CH = MTG_PIPE_CHUNK, TRIP = R * CH;
+    constexpr int R = MTG_PIPE_RING, TRIP = R * CH;
     constexpr int NT = NR + NC;
     constexpr int N2 = MtgPipeShape<NR, NC>::N2;
     constexpr int NV = MtgPipeShape<NR, NC>::NV;
@@ -186,12 +192,12 @@ __device__ __forceinline__ void mtg_pipe_produce(const MtgSolveArgs &a, int64_t 
 // ---------------------------------------------------------------------------------------------------------------
 // consumer: the recurrences of mtg_sweep.h's step on the generators in LDS; writes lnL and status
 // ---------------------------------------------------------------------------------------------------------------
-template <int NR, int NC, int NB0, bool MEAN>
+template <int NR, int NC, int NB0, bool MEAN, int CH>
 __device__ __forceinline__ void mtg_pipe_consume(const MtgSolveArgs &a, int64_t e, bool active, uint32_t yoff,
                                                  uint32_t toff, const double2 *ring)
 {
 #pragma clang fp contract(off)
-    constexpr int R = MTG_PIPE_RING, CH = MTG_PIPE_CHUNK, TRIP = R * CH;
+    constexpr int R = MTG_PIPE_RING, TRIP = R * CH;
     constexpr int J = NR + 2 * NC;
     constexpr int NT = NR + NC;
     constexpr int N2 = MtgPipeShape<NR, NC>::N2;
