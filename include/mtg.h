@@ -191,9 +191,23 @@ MTG_API int mtg_loglike_coeffs(mtg_ctx *ctx, int64_t B, int jr, int jc, const do
  * (default): time-parallel for light curves of at least 256 samples and batches of at most 1024
  * evaluations (J <= 6: 4-10x faster there); J = 10: at least 1024 samples and at most 8192 evaluations
  * (the light curve is cut into as many chunks as fill the GPU: 40-100x faster than the serial sweep for
- * the 32-256 evaluations of an ensemble half-step).
+ * the 32-256 evaluations of an ensemble half-step).  3 = as 1, restricted to the one-wave-per-evaluation kernel
+ * (J <= 6): under 1 and 2 the number of rows in a batch picks between kernels whose sums differ in the last bits;
+ * under 0 (one-lane sweep and its pipelined form, bit-identical to each other) and under 3 a row's result does not
+ * depend on what else is in the batch -- what a job that splits its rows over several GPUs needs to reproduce the
+ * one-GPU result exactly (ppp.protassov_test(reproducible=True)).
  */
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
+/*
+ * Index of this context's first resident ensemble (mtg_ensemble_*) and first simulated series
+ * (mtg_simulate_tk95) in the caller's global numbering, default 0.  The counter-based random streams are keyed by
+ * (seed, ..., first_index + local index): a job that splits E ensembles or S series over several contexts (GPUs)
+ * with the same seed draws, for every one of them, exactly the numbers ONE context holding them all would draw --
+ * the result of the reference's loop over simulated light curves (docs/notebooks/tutorial_ppp.ipynb:326-343,
+ * gpmodelling.py:505-513) no longer depends on how many GPUs share it.  Read at mtg_ensemble_init / at every
+ * mtg_simulate_tk95; enters random counters only, never an address.
+ */
+MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index);
 MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
 /*
  * The serial sweep as a two-wave pipeline (csrc/mtg_kernels_pipe.hip): 0 = never, 1 = whenever the model has the

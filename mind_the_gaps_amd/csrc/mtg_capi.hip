@@ -82,7 +82,7 @@ struct mtg_ctx {
     DevBuf theta, lc, out, status;
 
     // small batches: one wave per evaluation, parallel in time (0 never, 1 whenever compiled, 2 auto)
-    int tp_mode = 2;
+    int tp_mode = 2;   // (3: as 1, but the one-wave-per-evaluation kernel only -- results independent of the batch size)
     int tp_direct = 1;  // rank-10 time-parallel path: likelihood without the filter pass (mtg_set_tp_direct)
     int pipe_mode = 2;  // two-wave pipeline of the serial sweep (mtg_set_pipeline): 0 never, 1 whenever compiled, 2 auto
     int cus = 0;        // compute units of the device
@@ -91,6 +91,8 @@ struct mtg_ctx {
     int64_t ens_E = 0;
     int ens_W = 0, ens_P = 0;
     uint64_t ens_seed = 0;
+    int64_t stream_base = 0;      // mtg_set_stream_base: global index of the context's first ensemble / simulated series
+    int64_t ens_base = 0;         // ... as it was when the resident ensembles were made
     uint32_t ens_iteration = 0;
     int64_t ens_L = 0, ens_N = 0;  // shape of the resident set the ensembles index into
     DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
@@ -416,7 +418,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // 3.4 / 1.0 at 4096, 3.4 / 1.8 at 8192, equal at 16 384; N = 1e3, J = 5: 0.36 / 0.29 at 4096, 0.36 / 0.51 at 8192)
     if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= (ctx->N >= 4096 ? 8192 : 4096);
     else pays = ctx->N >= 1024 && Bw <= 8192;
-    const bool small = ctx->tp_mode == 1 || (ctx->tp_mode == 2 && pays);
+    const bool small = ctx->tp_mode == 1 || ctx->tp_mode == 3 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
     sa.tp_gsize = 0;
@@ -445,10 +447,11 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // four waves per evaluation: while every evaluation's workgroup is resident at once (rank <= 3: two per CU, their
     // elements take 68 KB of LDS; above: one)
     // (scripts/spec_probe.py, J = 3, N = 1e4: 384 rows 70.9 us against 96.0 us with one wave each, 512 rows 77.4 / 97.2)
-    const bool wide = Bw <= (Jmodel <= 3 ? 512 : 256) && ctx->N >= 4096;
+    // (mode 3: the one-wave kernel whatever the batch, so that a row's bits do not depend on how many rows travel with it)
+    const bool wide = ctx->tp_mode != 3 && Bw <= (Jmodel <= 3 ? 512 : 256) && ctx->N >= 4096;
     // two waves per evaluation between 257 and 512 rows of rank 4 or 5: half a CU's LDS each, all resident at once
     // (scripts/spec_probe.py, J = 5, N = 1e4, 384 rows: see DESIGN.md)
-    const bool mid = !wide && Bw <= 512 && ctx->N >= 4096 && (Jmodel == 4 || Jmodel == 5);
+    const bool mid = ctx->tp_mode != 3 && !wide && Bw <= 512 && ctx->N >= 4096 && (Jmodel == 4 || Jmodel == 5);
     // Between the time-parallel kernels' range and ~one wave per SIMD the serial sweep is one lone wave per 64 rows on
     // a fraction of the SIMDs, N dependent steps of ~166 instructions: the pipelined form puts the generators of those
     // rows on a second wave (mtg_kernels_pipe.hip) -- one workgroup of 128 rows per CU, all resident at once.
@@ -1072,7 +1075,7 @@ MTG_API int mtg_ensemble_init(mtg_ctx *ctx, int64_t E, int W, uint64_t seed, con
                             ctx->ens_best_lnp.as<double>(), ctx->ens_best_coords.as<double>(), s);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));  // lc_full / lc_half live on this stack frame
-    ctx->ens_E = E; ctx->ens_W = W; ctx->ens_P = P; ctx->ens_seed = seed; ctx->ens_iteration = 0;
+    ctx->ens_E = E; ctx->ens_W = W; ctx->ens_P = P; ctx->ens_seed = seed; ctx->ens_iteration = 0; ctx->ens_base = ctx->stream_base;
     ctx->ens_L = ctx->L; ctx->ens_N = ctx->N;
     shard_release(ctx);  // a new set of ensembles starts unsharded (mtg_ensemble_shard_* after this call)
     return MTG_OK;
@@ -1357,6 +1360,7 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
     };
     MtgEnsembleArgs g;
     g.E = E; g.W = W; g.P = P;
+    g.e_base = (uint32_t)ctx->ens_base;
     g.seed_lo = (uint32_t)ctx->ens_seed; g.seed_hi = (uint32_t)(ctx->ens_seed >> 32);
     g.a = 2.0;
     g.perm = ctx->ens_perm.as<int32_t>();
@@ -1666,7 +1670,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     for (int64_t s0 = 0; e == hipSuccess && s0 < S; s0 += chunk) {
         const int64_t sc = s0 + chunk <= S ? chunk : S - s0;
         what = "simulation kernels";
-        mtg_launch_tk95_spectrum(sc, s0, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
+        mtg_launch_tk95_spectrum(sc, s0, ctx->stream_base, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
                                  d_sig.as<int32_t>(), psd_table ? d_psd.as<double>() : nullptr, psd_rows, seed,
                                  spec.as<double2>(), s);
         if (sc < chunk)  // a short last group: the unused slots transform zeros
@@ -1676,11 +1680,11 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
             cleanup();
             return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");  // (the resident set is untouched so far)
         }
-        mtg_launch_tk95_observe(sc, s0, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
+        mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
                                 d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
                                 -1, seed, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
         if (segments)
-            mtg_launch_tk95_segment(sc, s0, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
+            mtg_launch_tk95_segment(sc, s0, ctx->stream_base, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
                                     d_seg.as<double>(), s);
         e = hipGetLastError();
     }
@@ -1737,7 +1741,7 @@ MTG_API int mtg_tk95_observe_series(mtg_ctx *ctx, int64_t S, int64_t nfft, int64
     if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, win_hi, (size_t)N * 4, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         // scale = dt = 1, mean 0, no noise: the plain window average of the series
-        mtg_launch_tk95_observe(S, 0, N, nfft, seg_len, 1.0, 1.0, 0.0, d_series.as<double>(), d_lo.as<int32_t>(),
+        mtg_launch_tk95_observe(S, 0, 0, N, nfft, seg_len, 1.0, 1.0, 0.0, d_series.as<double>(), d_lo.as<int32_t>(),
                                 d_hi.as<int32_t>(), 0, 0.0, nullptr, start, 0, nullptr, d_rates.as<double>(),
                                 d_dy.as<double>(), s);
         e = hipGetLastError();
@@ -1897,8 +1901,16 @@ MTG_API int mtg_math_probe(mtg_ctx *ctx, int64_t n, const double *x, double *exp
 
 MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 2) return MTG_E_ARG;
+    if (!ctx || mode < 0 || mode > 3) return MTG_E_ARG;
     ctx->tp_mode = mode;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (first_index < 0 || first_index > 0x7fffffffll) return fail(ctx, MTG_E_ARG, "stream base must be in [0, 2^31)");
+    ctx->stream_base = first_index;
     return MTG_OK;
 }
 

@@ -162,6 +162,7 @@ void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, 
 // device-resident ensemble sampler (mtg_sampler.hip)
 struct MtgEnsembleArgs {
     int E, W, P;
+    uint32_t e_base;      // index of ensemble 0 in the caller's global numbering: random counters only (mtg_set_stream_base)
     uint32_t seed_lo, seed_hi;
     double a;             // stretch scale
     int32_t *perm;        // [E][W] red/blue split of the current iteration
@@ -186,12 +187,12 @@ void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t i
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
                              double *best_coords, hipStream_t);
 // TK95 light-curve simulation (mtg_simulate.hip)
-void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
+void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, double dt, const double *coef, int64_t cstride,
                               MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
                               int64_t psd_rows, uint64_t seed, double2 *X, hipStream_t);
-void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t nfft, int64_t seg_len, double dt, double scale,
+void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, uint64_t seed, double *out, hipStream_t);
-void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
+void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
                              uint64_t seed, double *clean, double *rates, double *dy, hipStream_t);

@@ -72,7 +72,7 @@ __device__ __forceinline__ void mtg_split_part(const MtgEnsembleArgs &g, uint32_
     int32_t *p = g.perm + (int64_t)e * W;
     int *s_rank = (int *)(s_key + W);
     for (int w = threadIdx.x; w < W; w += blockDim.x) {
-        const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e, (uint32_t)w, g.seed_lo, g.seed_hi);
+        const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e + g.e_base, (uint32_t)w, g.seed_lo, g.seed_hi);
         s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
         s_rank[w] = 0;
     }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void mtg_propose_part(const MtgEnsembleArgs &g, int h
         const bool live = k < H;
         const int64_t i = (int64_t)e * H + (live ? k : 0);
         if (live) {
-            const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16 * half, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+            const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16 * half, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
             const double u = u01(r.c[0], r.c[1]);
             const double zr = (g.a - 1.0) * u + 1.0;
             const double z = zr * zr / g.a;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void mtg_accept_part(const MtgEnsembleArgs &g, int ha
         for (int k = threadIdx.x; k < H; k += 256) {
             const int64_t i = (int64_t)e * H + k;
             const int w = g.perm[(int64_t)e * W + half * H + k];
-            const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+            const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
             const double lu = log(u01(r.c[0], r.c[1]));
             const double cand = new_lnp[i];
             if (status[i] == MTG_ST_NOTPD) atomicAdd(g.n_notpd, 1);
@@ -209,7 +209,7 @@ __device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint3
     // the first half-step's proposals: one thread each
     for (int k = threadIdx.x; k < H; k += blockDim.x) {
         const int64_t i = (int64_t)e * H + k;
-        const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+        const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
         const double u = u01(r.c[0], r.c[1]);
         const double zr = (g.a - 1.0) * u + 1.0;
         const double z = zr * zr / g.a;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint3
     for (int t = threadIdx.x; t < 2 * H; t += blockDim.x) {
         const int k = t % H, which = t / H;
         const int64_t i = (int64_t)e * H + k;
-        const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+        const Philox r = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
         const double u = u01(r.c[0], r.c[1]);
         const double zr = (g.a - 1.0) * u + 1.0;
         const double z = zr * zr / g.a;
@@ -266,12 +266,12 @@ __device__ __forceinline__ void mtg_accept_both(const MtgEnsembleArgs &g, uint32
                 const int64_t i = (int64_t)e * H + k;
                 int64_t row = i;  // the row that holds this walker's proposal
                 if (half == 1) {
-                    const Philox rp = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+                    const Philox rp = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
                     const int j = (int)(u01(rp.c[2], rp.c[3]) * (double)H);
                     row = (s_acc[j] ? 2 * EH : EH) + i;
                 }
                 const int w = g.perm[(int64_t)e * W + half * H + k];
-                const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e, (uint32_t)k, g.seed_lo, g.seed_hi);
+                const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16 * half, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
                 const double lu = log(u01(r.c[0], r.c[1]));
                 const double cand = new_lnp[row];
                 if (status[row] == MTG_ST_NOTPD) atomicAdd(g.n_notpd, 1);

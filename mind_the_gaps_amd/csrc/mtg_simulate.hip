@@ -75,9 +75,10 @@ __device__ inline double mtg_psd(const double *cf, int64_t cs, const MtgCoefLayo
     return 0.79788456080286535588 * p;  // sqrt(2 / pi)
 }
 
-// X[s][k], k = 0..nfft/2 (hipFFT Z2D input layout)
+// X[s][k], k = 0..nfft/2 (hipFFT Z2D input layout).  sbase: index of the call's first series in the caller's global
+// numbering (mtg_set_stream_base) -- it enters the random counters only, never an address.
 __global__ void __launch_bounds__(256)
-mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
+mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, double dt, const double *coef, int64_t cstride,
                          MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
                          int64_t psd_rows, uint32_t seed_lo, uint32_t seed_hi, double2 *X)
 {
@@ -97,7 +98,7 @@ mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t nfft, double dt, const d
             power = mtg_psd(coef + sg, cstride, lay, nr, nc, w);
         }
         const double amp = sqrt(0.5 * power);
-        const Philox r = philox4x32_10((uint32_t)k, PURPOSE_SPECTRUM, (uint32_t)sg, (uint32_t)(k >> 32), seed_lo, seed_hi);
+        const Philox r = philox4x32_10((uint32_t)k, PURPOSE_SPECTRUM, (uint32_t)(sg + sbase), (uint32_t)(k >> 32), seed_lo, seed_hi);
         normal2(r, &re, &im);
         re *= amp; im *= amp;
         if (2 * k == nfft) im = 0.0;  // Nyquist term of an even-length series is real
@@ -122,19 +123,19 @@ __device__ inline int64_t tk95_segment_start(int64_t sg, int64_t nfft, int64_t s
 // The cut segment itself, as rates on the fine grid (the light curve the reference hands to its E13
 // amplitude adjustment before down-sampling): out[sg][j] = series[s][j0 + j] scale / dt + mean.
 __global__ void __launch_bounds__(256)
-mtg_tk95_segment_kernel(int64_t S, int64_t s0, int64_t nfft, int64_t seg_len, double dt, double scale, double mean_rate,
+mtg_tk95_segment_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale, double mean_rate,
                         const double *series, uint32_t seed_lo, uint32_t seed_hi, double *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * seg_len) return;
     const int64_t s = i / seg_len, j = i % seg_len, sg = s0 + s;
-    const int64_t j0 = tk95_segment_start(sg, nfft, seg_len, -1, seed_lo, seed_hi);
+    const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, -1, seed_lo, seed_hi);
     out[sg * seg_len + j] = series[s * nfft + j0 + j] * scale / dt + mean_rate;
 }
 
 // Segment cut + bin average onto the observing pattern + noise.  One thread per (simulation, epoch).
 __global__ void __launch_bounds__(256)
-mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
+mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                         double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                         int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
                         uint32_t seed_lo, uint32_t seed_hi, double *clean, double *rates, double *dy)
@@ -142,7 +143,7 @@ mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * N) return;
     const int64_t s = i / N, n = i % N, sg = s0 + s;
-    const int64_t j0 = tk95_segment_start(sg, nfft, seg_len, fixed_start, seed_lo, seed_hi);
+    const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, fixed_start, seed_lo, seed_hi);
     const double *x = series + s * nfft + j0;
     const int lo = win_lo[n], hi = win_hi[n];
     double acc = 0.0;
@@ -153,7 +154,7 @@ mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t 
     if (clean) clean[o] = rate;
     double yv = rate, ev = 0.0;
     if (noise_kind == 1) {  // GaussianNoise (noise_models.py:152-184)
-        const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)sg, 0u, seed_lo, seed_hi);
+        const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)(sg + sbase), 0u, seed_lo, seed_hi);
         double g1, g2;
         normal2(r, &g1, &g2);
         yv = rate + sigma_noise * g1;
@@ -169,7 +170,7 @@ mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t 
             double prod = 1.0;
             int kcount = 0;
             for (uint32_t ctr = 1; ctr < 64; ++ctr) {
-                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)sg, ctr, seed_lo, seed_hi);
+                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)(sg + sbase), ctr, seed_lo, seed_hi);
                 prod *= u01(r.c[0], r.c[1]);
                 if (prod <= limit) break;
                 ++kcount;
@@ -184,7 +185,7 @@ mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t 
             const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
             counts = floor(lam + 0.5);
             for (uint32_t ctr = 1; ctr < 256; ++ctr) {
-                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)sg, ctr, seed_lo, seed_hi);
+                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)(sg + sbase), ctr, seed_lo, seed_hi);
                 const double U = u01(r.c[0], r.c[1]) - 0.5, V = u01(r.c[2], r.c[3]);
                 const double us = 0.5 - fabs(U);
                 const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
@@ -233,30 +234,30 @@ void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const d
     hipLaunchKernelGGL(mtg_tk95_resident_kernel, dim3((unsigned)L), dim3(256), 0, st, N, rates, dy, yv, means);
 }
 
-void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t nfft, double dt, const double *coef, int64_t cstride,
+void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, double dt, const double *coef, int64_t cstride,
                               MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
                               int64_t psd_rows, uint64_t seed, double2 *X, hipStream_t st)
 {
     const int64_t n = S * (nfft / 2 + 1);
-    hipLaunchKernelGGL(mtg_tk95_spectrum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, nfft, dt,
+    hipLaunchKernelGGL(mtg_tk95_spectrum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, nfft, dt,
                        coef, cstride, lay, nr0, nc0, sig, psd_table, psd_rows, (uint32_t)seed, (uint32_t)(seed >> 32), X);
 }
 
-void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t nfft, int64_t seg_len, double dt, double scale,
+void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, uint64_t seed, double *out, hipStream_t st)
 {
     const int64_t n = S * seg_len;
-    hipLaunchKernelGGL(mtg_tk95_segment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, nfft, seg_len,
+    hipLaunchKernelGGL(mtg_tk95_segment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, nfft, seg_len,
                        dt, scale, mean_rate, series, (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
 
-void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
+void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
                              uint64_t seed, double *clean, double *rates, double *dy, hipStream_t st)
 {
     const int64_t n = S * N;
-    hipLaunchKernelGGL(mtg_tk95_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, N, nfft,
+    hipLaunchKernelGGL(mtg_tk95_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, N, nfft,
                        seg_len, dt, scale, mean_rate, series, win_lo, win_hi, noise_kind, sigma_noise, exposures,
                        fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), clean, rates, dy);
 }

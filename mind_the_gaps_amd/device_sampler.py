@@ -70,7 +70,7 @@ class DeviceEnsembleSampler:
     """
 
     def __init__(self, bind, nwalkers, ndim, n_ensembles=1, lc_of_ensemble=None, seed=None,
-                 store_chain=True, shard_group=False, shard_transport=None):
+                 store_chain=True, shard_group=False, shard_transport=None, index_base=0):
         if nwalkers < 2 * ndim:
             raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than "
                                "twice the number of dimensions.")
@@ -85,6 +85,9 @@ class DeviceEnsembleSampler:
         # walker sharding: False = none; None = the default process group; or a torch.distributed group.  Every
         # rank then holds the same chain (distributed.shard_device_ensemble).
         self.shard_group, self.shard_transport = shard_group, shard_transport
+        # global index of ensemble 0 (mtg_set_stream_base): with the same seed, ensembles [index_base, index_base + E)
+        # of a job split over several GPUs get the random numbers they would get in one sampler holding them all
+        self.index_base = int(index_base)
         self.iteration = 0
         self._chain = np.empty((0, self.E, self.nwalkers, self.ndim))
         self._log_prob = np.empty((0, self.E, self.nwalkers))
@@ -105,7 +108,7 @@ class DeviceEnsembleSampler:
             if self.shard_group is not False:
                 from .distributed import broadcast_start, shard_device_ensemble
                 p0, self.seed = broadcast_start(p0, self.seed, self.shard_group)
-            eng.ensemble_init(p0, seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
+            self._init(eng, p0)
             if self.shard_group is not False:
                 self.transport = shard_device_ensemble(eng, self.shard_group, self.shard_transport)
             self._started = True
@@ -122,11 +125,18 @@ class DeviceEnsembleSampler:
         self._state = eng.ensemble_state()
         return self._state
 
+    def _init(self, eng, coords):
+        eng.set_stream_base(self.index_base)      # read by mtg_ensemble_init, kept with the resident ensembles
+        try:
+            eng.ensemble_init(coords, seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
+        finally:
+            eng.set_stream_base(0)
+
     # -- checkpoint / resume (the reference keeps its chains in memory only) -----------------
     def save(self, path):
         """Everything needed to continue this run in another process: state, Philox seed, iteration, chain."""
         np.savez(path, seed=np.uint64(self.seed), iteration=self.iteration, chain=self._chain, log_prob=self._log_prob,
-                 shape=np.array([self.E, self.nwalkers, self.ndim]), **{"state_" + k: v for k, v in self._state.items()})
+                 index_base=self.index_base, shape=np.array([self.E, self.nwalkers, self.ndim]), **{"state_" + k: v for k, v in self._state.items()})
 
     def load(self, path):
         """Continue the run ``save`` wrote: the next ``run_mcmc(None, n)`` produces the iterations the original run
@@ -139,7 +149,8 @@ class DeviceEnsembleSampler:
                              % (tuple(z["shape"]), (self.E, self.nwalkers, self.ndim)))
         eng = self._bind()
         self.seed = int(z["seed"])
-        eng.ensemble_init(z["state_coords"], seed=self.seed, lc_of_ensemble=self.lc_of_ensemble)
+        self.index_base = int(z["index_base"]) if "index_base" in z.files else 0
+        self._init(eng, z["state_coords"])
         eng.ensemble_restore(int(z["iteration"]), z["state_log_prob"], z["state_naccept"], z["state_best_log_prob"],
                              z["state_best_coords"])
         if self.shard_group is not False:
@@ -162,13 +173,18 @@ class DeviceEnsembleSampler:
     def get_log_prob(self, flat=False, thin=1, discard=0, ensemble=0):
         return self._get(self._log_prob, flat, thin, discard, ensemble)
 
-    def get_autocorr_time(self, discard=0, thin=1, ensemble=0, **kwargs):
+    def get_autocorr_time(self, discard=0, thin=1, ensemble=0, broadcast=True, **kwargs):
+        """emcee's ``get_autocorr_time``.  In a walker-sharded run (``shard_group`` given) this is a COLLECTIVE: every
+        rank must call it, at the same point, or the callers wait for ever in the broadcast of rank 0's value (which
+        is what keeps the ranks' convergence decisions identical).  ``broadcast=False``: this rank's own value, no
+        communication -- for diagnostics from one rank only, never for a decision that changes what the ranks do
+        next."""
         chain = self.get_chain(discard=discard, thin=thin, ensemble=ensemble)
         if "acf" not in kwargs:
             tau = thin * _autocorr_time_where_it_is_cheapest(self._bind(), chain, kwargs)
         else:
             tau = thin * integrated_time(chain, **kwargs)
-        if self.shard_group is not False:
+        if self.shard_group is not False and broadcast:
             # every rank holds the same chain, but host and device FFTs agree to ~1e-11 only and a device failure
             # falls back to the host on that rank alone: the ranks must take the SAME convergence decision (one that
             # stops sampling while the others enter the next all-gather hangs the job), so rank 0's value is

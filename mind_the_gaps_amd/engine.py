@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_speculation", "mtg_last_solver",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
 
@@ -216,6 +216,8 @@ def load_library():
     lib.mtg_simulate_plan.argtypes = [c_vp, c_i64]
     lib.mtg_set_sort.restype = c_int
     lib.mtg_set_sort.argtypes = [c_vp, c_int]
+    lib.mtg_set_stream_base.restype = c_int
+    lib.mtg_set_stream_base.argtypes = [c_vp, ctypes.c_int64]
     lib.mtg_set_pipeline.restype = c_int
     lib.mtg_set_pipeline.argtypes = [c_vp, c_int]
     lib.mtg_set_speculation.restype = c_int
@@ -685,7 +687,8 @@ class Engine:
         return outs
 
     def set_time_parallel(self, mode):
-        """0 = throughput kernel only, 1 = time-parallel kernel whenever available, 2 = auto (default)."""
+        """0 = throughput kernel only, 1 = time-parallel kernel whenever available, 2 = auto (default), 3 = the one-wave
+        time-parallel kernel whatever the batch (0 and 3: a row's bits do not depend on the batch it travels in)."""
         self._check(self._lib.mtg_set_time_parallel(self._ctx, int(mode)))
 
     def set_tp_direct(self, enabled):
@@ -700,6 +703,10 @@ class Engine:
     def set_sort(self, mode):
         """Order of the throughput kernel's sweep: 0 the caller's, 1 sorted by (structure, light curve), 2 auto."""
         self._check(self._lib.mtg_set_sort(self._ctx, int(mode)))
+
+    def set_stream_base(self, first_index):
+        """Global index of this context's first ensemble / simulated series: random counters only (include/mtg.h)."""
+        self._check(self._lib.mtg_set_stream_base(self._ctx, int(first_index)))
 
     def set_pipeline(self, mode):
         """0: never the two-wave pipeline of the serial sweep, 1: whenever compiled, 2 (default): for batches of ~8e3 to

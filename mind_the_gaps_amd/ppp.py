@@ -286,7 +286,7 @@ class _DeviceBatch:
 
 def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit=True, seed=None,
                             device=0, store_chain=True, initial_params=None, quiet=False,
-                            evaluate=None, device_sampler=True, own_engine=False):
+                            evaluate=None, device_sampler=True, own_engine=False, index_base=None):
     """GPModelling(lc, kernel).derive_posteriors(...) for L light curves at once.
 
     times [N] (shared sampling, gpmodelling.py:538); Y, DY [L, N]; ``kernel`` a
@@ -297,6 +297,15 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     ``device_sampler`` keeps the L ensembles on the GPU between iterations
     (``mtg_ensemble_*``) instead of proposing and accepting on the host.  ``own_engine``: a device context for this
     call alone (closed before it returns), so that several calls can run side by side from different host threads.
+
+    ``index_base`` (an integer; needs ``seed`` and the device sampler): these are light curves [index_base,
+    index_base + L) of a larger set that is being fitted in blocks, and every one of them must get the result it
+    would get in ONE call for the whole set, bit for bit -- whatever the blocks.  Three things then stop depending on
+    L: the walkers' starting points (one generator per light curve, keyed by seed and global index), the sampler's
+    random numbers (Philox counters by global ensemble index, ``mtg_set_stream_base``) and the kernels (the number
+    of rows in a batch otherwise picks between kernels whose sums differ in the last bits: the starting fit runs on
+    the one-wave time-parallel kernel whatever the batch, the chains on the one-lane sweep and its pipelined form,
+    which agree bit for bit; ``mtg_set_time_parallel`` 3 and 0).
     """
     Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
     DY = np.atleast_2d(np.asarray(DY, dtype=np.float64))
@@ -326,25 +335,44 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     start = model.full[model.free_index] if initial_params is None else np.asarray(initial_params, float)
     centers = np.broadcast_to(start, (L, P)).copy()
     fit_x = fit_f = None
-    if fit:
-        fit_x, fit_f, _ = batched_minimize(lambda x, lc: -checked(x, lc, False), centers, lower, upper)
-        centers, fit_f = fit_x, -fit_f
-        clock.append(("fit", time.perf_counter()))
-    rng = np.random.default_rng(seed)
-    p0 = _spread(rng, centers, lower, upper, walkers)
-    clock.append(("spread", time.perf_counter()))
-    if device_sampler and ev is not None:
-        from .device_sampler import DeviceEnsembleSampler
-        dev = DeviceEnsembleSampler(lambda: ev._bind(model), walkers, P, n_ensembles=L,
-                                    seed=int(rng.integers(0, 2 ** 62)), store_chain=store_chain)
-        dev.run_mcmc(p0, max_steps)
-        if not quiet and dev.state["n_not_pd"]:
-            raise LinAlgError("failed to factorize or solve matrix")
-        sampler = _DeviceBatch(dev)
-    else:
-        sampler = EnsembleBatchSampler(L, walkers, P, lambda x, lc: checked(x, lc, True), seed=rng,
-                                       store_chain=store_chain)
-        sampler.run(p0, max_steps)
+    block_free = index_base is not None
+    if block_free and (seed is None or ev is None or not device_sampler):
+        raise ValueError("index_base needs a seed and the device-resident sampler on this call's own evaluator")
+
+    def kernels(mode):          # which kernel family the evaluator's engine may pick from (see the docstring)
+        if block_free:
+            ev._bind(model).set_time_parallel(mode)
+
+    try:
+        if fit:
+            kernels(3)
+            fit_x, fit_f, _ = batched_minimize(lambda x, lc: -checked(x, lc, False), centers, lower, upper)
+            centers, fit_f = fit_x, -fit_f
+            clock.append(("fit", time.perf_counter()))
+        kernels(0)
+        if block_free:
+            p0 = np.concatenate([_spread(np.random.default_rng([int(seed), 1, int(index_base) + l]), centers[l:l + 1],
+                                         lower, upper, walkers) for l in range(L)])
+            sampler_seed = int(np.random.default_rng([int(seed), 2]).integers(0, 2 ** 62))
+        else:
+            rng = np.random.default_rng(seed)
+            p0 = _spread(rng, centers, lower, upper, walkers)
+        clock.append(("spread", time.perf_counter()))
+        if device_sampler and ev is not None:
+            from .device_sampler import DeviceEnsembleSampler
+            dev = DeviceEnsembleSampler(lambda: ev._bind(model), walkers, P, n_ensembles=L,
+                                        seed=sampler_seed if block_free else int(rng.integers(0, 2 ** 62)),
+                                        store_chain=store_chain, index_base=index_base or 0)
+            dev.run_mcmc(p0, max_steps)
+            if not quiet and dev.state["n_not_pd"]:
+                raise LinAlgError("failed to factorize or solve matrix")
+            sampler = _DeviceBatch(dev)
+        else:
+            sampler = EnsembleBatchSampler(L, walkers, P, lambda x, lc: checked(x, lc, True), seed=rng,
+                                           store_chain=store_chain)
+            sampler.run(p0, max_steps)
+    finally:
+        kernels(2)
     clock.append(("sample", time.perf_counter()))
     if store_chain:
         tau = sampler.get_autocorr_time(tol=0)
@@ -367,7 +395,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
 
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
                    sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
-                   sharded=False, group=None, concurrent_refits=False, split="auto"):
+                   sharded=False, group=None, concurrent_refits=False, split="auto", reproducible=None):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -392,8 +420,17 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     0's posterior samples and ``T_obs`` are broadcast so that all ranks test the same thing.  ``sim_null``,
     ``sim_alt`` and ``lightcurves`` then hold the rank's own block.  ``split``: "lightcurves" as just described,
     "models" -- the first half of the ranks refits the null model, the second half the alternative, each over all the
-    light curves (a rank then holds ``sim_null`` or ``sim_alt``, not both; with two ranks the result equals the
-    unsharded one bit for bit) --, "auto" picks by the rows a half-step leaves each rank (``_split_by_model``).
+    light curves (a rank then holds ``sim_null`` or ``sim_alt``, not both) --, "auto" picks by the rows a half-step
+    leaves each rank (``_split_by_model``).
+
+    ``reproducible`` (default: on when ``sharded``): ``T_sim`` and the p-value do not depend on the number of ranks
+    or on the split -- a run on 8 GPUs can be CHECKED against a run on one, bit for bit.  Every simulated light curve
+    is then a function of (seed, its global index) alone: the simulator's noise stream and each refit's Philox
+    counters are keyed by global index (``mtg_set_stream_base``), the walkers start from a generator of the light
+    curve's own, and the refits keep to kernels whose results do not depend on the batch a row travels in
+    (``derive_posteriors_batch(index_base=...)``).  Off, every block draws from a stream of its own and small
+    batches take whichever kernel is fastest for their size: the same statistics, a few per cent faster where a
+    rank's batches are small, not the same numbers.  (The observed light curve's chains are rank 0's either way.)
     """
     from .gpmodelling import GPModelling
     from .simulator import Simulator
@@ -427,14 +464,20 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     # thinned chain is systematically smaller, the more so the more parameters a model has)
     t_obs = float(lrt_statistic(null.best_loglikelihood, alt.best_loglikelihood))
     samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
-    sim_seed, fit_seeds = int(rng.integers(0, 2 ** 31 - 1)), [int(rng.integers(0, 2 ** 62)) for _ in range(2)]
+    # (seeds below 2^52: they travel as float64 in the broadcast)
+    sim_seed, fit_seeds = int(rng.integers(0, 2 ** 31 - 1)), [int(rng.integers(0, 2 ** 52)) for _ in range(2)]
     sw = sim_walkers or walkers
     lo, hi, shard, models = 0, nsims, None, (0, 1)
+    reproducible = bool(sharded) if reproducible is None else bool(reproducible)
     if sharded:
         from .distributed import LightcurveShard, all_gather_rows, block_bounds, broadcast_array
         shard = LightcurveShard(nsims, group=group)
-        head = broadcast_array(np.concatenate([[t_obs], samples.ravel()]), group)   # rank 0's test, everybody's test
-        t_obs, samples = float(head[0]), head[1:].reshape(samples.shape)
+        # rank 0's test is everybody's test: its T_obs, its posterior samples and its seeds (every rank drew its own
+        # from its own chains' generator state; under the model split two ranks must simulate the SAME light curves)
+        head = broadcast_array(np.concatenate([[t_obs, float(sim_seed)], np.asarray(fit_seeds, dtype=np.float64),
+                                               samples.ravel()]), group)
+        t_obs, sim_seed, fit_seeds = float(head[0]), int(head[1]), [int(head[2]), int(head[3])]
+        samples = head[4:].reshape(samples.shape)
         if _split_by_model(split, nsims, sw, shard.world):
             # half of the ranks refit the null model, the other half the alternative, each half over ALL the light
             # curves: twice the rows per rank and one model's half-steps instead of both one after the other
@@ -448,18 +491,20 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
         else:
             block, bounds = shard.rank, shard.bounds
             lo, hi = shard.lo, shard.hi
-        sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)       # independent noise on every block (the two ranks
-        fit_seeds = [f + 7919 * block for f in fit_seeds]           # of a block under the model split draw the same)
+        if not reproducible:
+            sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)   # independent noise on every block (the two ranks
+            fit_seeds = [f + 7919 * block for f in fit_seeds]       # of a block under the model split draw the same)
     out, fits, best = None, [None, None], [np.empty(0), np.empty(0)]
     if hi > lo:
         sim.random_state = np.random.RandomState(sim_seed)
-        out = sim.simulate(samples[lo:hi, :null_kernel.vector_size])
+        out = sim.simulate(samples[lo:hi, :null_kernel.vector_size], index_base=lo if reproducible else 0)
         clock.append(time.perf_counter())
         def refit(k):
             kernel = (null_kernel, alt_kernel)[k]
             return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
                                            max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
-                                           store_chain=False, quiet=True, own_engine=concurrent_refits)
+                                           store_chain=False, quiet=True, own_engine=concurrent_refits,
+                                           index_base=lo if reproducible else None)
 
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -482,6 +527,14 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
         if len(models) == 2:
             best = [shard.gather(b) for b in best]
         else:
+            # the null rank and the alternative rank of a block pair lnL values of what must be the same light curves,
+            # simulated on two GPUs: a checksum per rank says so, or the test stops here
+            mine = np.array([float(np.sum(out["rates"])) + float(np.sum(out["dy"])) if out is not None else np.nan])
+            sums = all_gather_rows(mine, np.ones(shard.world, dtype=int), group)
+            for b in range(shard.world // 2):
+                if sums[b] != sums[b + shard.world // 2]:
+                    raise RuntimeError("ranks %d and %d simulated different light curves for block %d (checksums %r, %r)"
+                                       % (b, b + shard.world // 2, b, sums[b], sums[b + shard.world // 2]))
             half, sizes = shard.world // 2, np.diff(bounds)
             counts = [np.concatenate([sizes, 0 * sizes]), np.concatenate([0 * sizes, sizes])]
             if shard.world % 2:                                  # an odd rank out takes no part in the refits

@@ -209,10 +209,13 @@ class Simulator:
         return table[None, :]
 
     # -- simulation --------------------------------------------------------------------
-    def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None, nsims=None):
+    def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None, nsims=None,
+                 index_base=0):
         """Light curves for S kernel parameter vectors ``thetas`` [S][P] (default: the kernel's
         current one; with a callable PSD: ``nsims`` realisations of it) in one device call ->
-        dict(rates[S][N], dy[S][N], means[S], clean[S][N] | None)."""
+        dict(rates[S][N], dy[S][N], means[S], clean[S][N] | None).  ``index_base``: global index of the first of
+        these series (mtg_set_stream_base) -- with the same ``seed``, series [index_base, index_base + S) of a set
+        simulated in blocks are the ones a single call for the whole set would make (device noise kinds only)."""
         eng, model = self._engine()
         if seed is None:
             seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
@@ -220,6 +223,7 @@ class Simulator:
         kw = dict(noise_kind=0 if (host_side or not noise) else self._noise_kind, sigma_noise=self.sigma_noise,
                   exposures=self._exposures, want_clean=want_clean and not host_side,
                   make_resident=make_resident and not host_side, want_segments=self.pdf.lower() != "gaussian")
+        eng.set_stream_base(index_base)
         try:
             if model is None:
                 out = eng.simulate_tk95(int(nsims or 1), seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
@@ -230,6 +234,7 @@ class Simulator:
                 out = eng.simulate_tk95(thetas, seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
                                         self.win_lo, self.win_hi, **kw)
         finally:
+            eng.set_stream_base(0)
             if make_resident:
                 eng.bound_to = None    # whatever happened, the engine no longer holds this evaluator's dummy data
         if host_side:

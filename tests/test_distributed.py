@@ -323,7 +323,7 @@ def _protassov_worker(rank, world, port, out_dir, split="lightcurves"):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the box
     th = synth.truth(synth.ALT_MODEL)
-    t, y, dy = synth.make_lightcurves(200, 1, seed=43)
+    t, y, dy = synth.make_lightcurves(400, 1, seed=43)     # (long enough for the time-parallel kernels to be an option)
     lc = GappyLightcurve(t, y[0] + 50.0, dy[0], exposures=0.5 * np.diff(t).min())
     null = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)])
     alt = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)]) + Lorentzian(
@@ -331,7 +331,7 @@ def _protassov_worker(rank, world, port, out_dir, split="lightcurves"):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         res = protassov_test(lc, null, alt, nsims=5, walkers=16, max_steps=60, sim_steps=40, seed=11, sharded=world > 1,
-                             split=split)
+                             split=split, reproducible=True)
     n_local = 0 if res["lightcurves"] is None else len(res["lightcurves"]["rates"])
     both = res["sim_null"] is not None and res["sim_alt"] is not None
     local = (-2.0 * (res["sim_null"].max_loglikelihood - res["sim_alt"].max_loglikelihood)) if both else np.empty(0)
@@ -350,7 +350,9 @@ def _protassov_worker(rank, world, port, out_dir, split="lightcurves"):
 @pytest.mark.timeout(400)
 def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     """ppp.protassov_test(sharded=True) on two ranks (sharing the box's GPU, gloo): both end with the same T_obs,
-    T_sim and p-value; T_sim is rank 0's block of 3 followed by rank 1's block of 2, each the rank's own refits."""
+    T_sim and p-value; T_sim is rank 0's block of 3 followed by rank 1's block of 2, each the rank's own refits -- and
+    (reproducible mode, the default of a sharded run) the numbers are those of ONE process holding all five light
+    curves, to the last bit, for either split and for an odd number of ranks."""
     world = 2
     _spawn(_protassov_worker, (world, _free_port(), str(tmp_path)), world, tmp_path)
     r0, r1 = (np.load(tmp_path / ("ptl2_%d.npz" % r)) for r in range(world))
@@ -363,7 +365,10 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     _spawn(_protassov_worker, (1, _free_port(), str(tmp_path)), 1, tmp_path)
     single = np.load(tmp_path / "ptl1_0.npz")
     assert int(single["n_local"]) == 5 and np.all(np.isfinite(single["T_sim"]))
-    assert np.isclose(float(single["T_obs"]), float(r0["T_obs"]), rtol=1e-9)      # same seed, same observed chains
+    assert float(single["T_obs"]) == float(r0["T_obs"])                            # same seed, same observed chains
+    # split by light curve: blocks of 3 and 2 against all 5 in one process -- other batch sizes in every launch, the
+    # same numbers (noise and Philox streams keyed by global light-curve index, batch-independent kernels)
+    assert np.array_equal(r0["T_sim"], single["T_sim"]) and float(r0["p"]) == float(single["p"])
     # split by model: rank 0 refits the null model, rank 1 the alternative, each on all five light curves -- the same
     # light curves, seeds and batches as one process alone, hence its T_sim to the last bit
     _spawn(_protassov_worker, (world, _free_port(), str(tmp_path), "models"), world, tmp_path)
@@ -372,6 +377,11 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     assert (int(m0["n_local"]), int(m1["n_local"])) == (5, 5)
     assert np.array_equal(m0["T_sim"], m1["T_sim"]) and float(m0["p"]) == float(m1["p"])
     assert np.array_equal(m0["T_sim"], single["T_sim"]) and float(m0["T_obs"]) == float(single["T_obs"])
+    # three ranks, split by model: ranks 0 and 1 as above, the odd rank out takes no part in the refits but holds the result
+    _spawn(_protassov_worker, (3, _free_port(), str(tmp_path), "models"), 3, tmp_path)
+    o = [np.load(tmp_path / ("ptm3_%d.npz" % r)) for r in range(3)]
+    assert [int(x["n_local"]) for x in o] == [5, 5, 0]
+    assert all(np.array_equal(x["T_sim"], single["T_sim"]) and float(x["p"]) == float(single["p"]) for x in o)
 
 
 # ---- the device-resident sampler, walker-sharded (mtg_ensemble_shard_*) -------------------------------------

@@ -205,3 +205,45 @@ def test_invariances_at_the_bench_size(engine):
     out3, st3 = engine.loglike(theta, lc, add_prior=True)
     assert np.all(st3 == 0)
     assert np.max(np.abs(out3 - out) / np.abs(out)) < 1e-9
+
+
+def test_refits_in_blocks_are_the_refits_in_one_call():
+    """derive_posteriors_batch(index_base=...): seven light curves fitted in one call and in blocks of 4 + 3 (and
+    2 + 5) -- other batch sizes in every launch of the fit and of the chains -- give every light curve the same
+    starting fit, chain maximum and best sample to the last bit (walkers from a generator per light curve, Philox
+    counters by global ensemble index, kernels whose results do not depend on the batch)."""
+    N, L, W = 400, 7, 16
+    t, y, dy = synth.make_lightcurves(N, L, seed=77)
+    y += 3.0 * np.arange(L)[:, None]
+
+    def run(lo, hi, **kw):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return derive_posteriors_batch(t, y[lo:hi], dy[lo:hi], alt_kernel(), walkers=W, max_steps=60, fit=True, seed=5,
+                                           store_chain=False, quiet=True, **kw)
+    whole = run(0, L, index_base=0)
+    for cut in (4, 2):
+        a, b = run(0, cut, index_base=0), run(cut, L, index_base=cut)
+        for name in ("max_loglikelihood", "max_parameters", "fit_parameters", "fit_loglikelihood"):
+            assert np.array_equal(np.concatenate([getattr(a, name), getattr(b, name)]), getattr(whole, name)), (cut, name)
+    assert np.all(np.isfinite(whole.max_loglikelihood)) and np.all(whole.max_loglikelihood >= whole.fit_loglikelihood - 1.0)
+    # without index_base the blocks draw from streams of their own: other numbers (the same statistics)
+    plain = run(4, L)
+    assert not np.array_equal(plain.max_loglikelihood, whole.max_loglikelihood[4:])
+    with pytest.raises(ValueError):
+        derive_posteriors_batch(t, y[:2], dy[:2], alt_kernel(), walkers=W, max_steps=5, index_base=0)      # needs a seed
+
+
+def test_simulated_series_in_blocks_are_the_series_of_one_call():
+    """Simulator.simulate(index_base=...): the noise and cut streams are keyed by the global series index."""
+    from mind_the_gaps_amd.simulator import Simulator
+    rng = np.random.default_rng(3)
+    times = synth.make_times(300, rng)
+    sim = Simulator(null_kernel(), times, 0.04, 100.0, "Gaussian", sigma_noise=1.0, extension_factor=2, random_state=1)
+    thetas = synth.draw_thetas(synth.NULL_MODEL, 9, seed=8, percent=0.05)
+    whole = sim.simulate(thetas, seed=12345)
+    for lo, hi in ((0, 4), (4, 9), (7, 8)):
+        part = sim.simulate(thetas[lo:hi], seed=12345, index_base=lo)
+        for key in ("rates", "dy", "means"):
+            assert np.array_equal(part[key], whole[key][lo:hi]), (lo, hi, key)
+    assert not np.array_equal(sim.simulate(thetas[4:9], seed=12345)["rates"], whole["rates"][4:9])
