@@ -43,12 +43,13 @@ The JSON line also carries
   workflow_config3_sharded: (N > 1) ppp.protassov_test(sharded=True): every rank simulates and refits its block
                     of the 2000 light curves, one all-gather of the maxima per model; time = max over ranks;
                     (both N > 1 extras run after the timed region under --extras-timeout: if one of them fails or
-                    hangs on some rank, rank 0 still prints the line, with `multi_rank_extras_error` saying what
-                    happened; MTG_BENCH_FAIL_EXTRAS=<rank> rehearses that)
+                    hangs on some rank, rank 0 still prints the line -- the scaling number stands -- with
+                    `multi_rank_extras_error` saying what happened, and every rank then exits with code 3;
+                    MTG_BENCH_FAIL_EXTRAS=<rank> rehearses that)
   cpu_baseline    : oracle/celerite_ref.c (a plain-C port of celerite's algorithm, fused one-sweep
                     variant, built -O3 -march=native on this host) single thread and on all usable
                     cores, bounded sample (rank 0, N = 1 only).
-A side measurement that fails fails the bench (non-zero exit): nothing hides in an "error" key.
+A side measurement that fails fails the bench (non-zero exit, after the line where there is a timed region to report).
 """
 import argparse
 import json
@@ -68,7 +69,7 @@ FP64_PEAK_TFLOPS = 78.6
 # FP64 operations per sample and lane of the serial sweep's inner loop, mean-free variant (`scripts/loop_stats.py NR NC
 # NB0` on the compiled loop: 2 x fma + mul/add per step)
 FLOP_PER_SAMPLE = {"mtg_solve_kernel<1,2,1>": 2 * 91 + 53, "mtg_solve_kernel<1,1,0>": 2 * 47 + 28,
-                   "mtg_solve_kernel<2,1,0>": 2 * 66 + 39,
+                   "mtg_solve_kernel<2,1,0>": 2 * 66 + 39, "mtg_solve_kernel<0,3,0>": 2 * 123 + 68,
                    # every structure of the model in one launch (csrc/mtg_kernels_multi.hip): the bench's rows are all
                    # under-damped, i.e. the same sweep loop as the one-structure kernel's
                    "mtg_solve_kernel_multi<1,2,2,1>": 2 * 91 + 53, "mtg_solve_kernel_multi<1,1,2,0>": 2 * 47 + 28}
@@ -458,7 +459,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    scaling = args.scaling or ("strong" if grouped else "weak")
+    scaling = args.scaling or ("strong" if grouped else "weak")   # how the light curves are laid out over the ranks
+    scaling_label = scaling if world > 1 else "none"               # (one GPU: nothing scales)
 
     from mind_the_gaps_amd import synthetic as synth
     from mind_the_gaps_amd.distributed import block_bounds
@@ -562,7 +564,10 @@ def main():
                 rec = json.load(open(pmc))
                 if rec.get("N") == N and rec.get("B") == B:
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (%s), not measured in this run" % rec.get("round", "round 1")
+                    traffic_source = ("profiles/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                      "command (%s, commit %s, kernel %s), not measured in this run"
+                                      % (rec.get("round", "round 1"), str(rec.get("head", "unknown"))[:12],
+                                         str(rec.get("kernel", "?")).split("::")[-1].split("(")[0]))
             except Exception:
                 traffic = None
         line = {
@@ -574,7 +579,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": scaling,
+            "scaling": scaling_label,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -613,6 +618,10 @@ def main():
             },
         }
         line.update(extras)
+        if "hbm_copy_measured" in extras:    # the algorithmic rate against the copy bandwidth measured on this box
+            copy = extras["hbm_copy_measured"]["GB_per_s"]
+            line["roofline"]["hbm_copy_measured"] = copy
+            line["roofline"]["frac_of_copy_measured"] = achieved / copy
         if oversubscribed:
             line["oversubscribed"] = "%d ranks on %d GPU(s): rehearsal of the multi-rank path, not a scaling number" % (world, ndev)
         line.setdefault("cpu_baseline", None)
@@ -629,17 +638,38 @@ def main():
             # the timer below, rank 0 printing the line with what it has.
             import threading
             import traceback
+            EXTRAS_FAILED = 3      # exit code of a run whose timed region is fine and printed, but whose extras are not
 
-            def bail():
-                sys.stderr.write("bench: rank %d: multi-rank extras still running after %d s, giving up on them\n"
-                                 % (rank, args.extras_timeout))
+            def give_up(why):
+                """The line, with what there is, then a non-zero exit: the scaling number is on stdout, the failure in the
+                line ("multi_rank_extras_error") AND in the exit code."""
+                sys.stderr.write("bench: rank %d: multi-rank extras: %s\n" % (rank, why))
                 if rank == 0:
-                    extras["multi_rank_extras_error"] = "timed out after %d s" % args.extras_timeout
+                    extras["multi_rank_extras_error"] = why
                     print(json.dumps(headline_line()), flush=True)
                 sys.stdout.flush()
-                os._exit(0)
+                sys.stderr.flush()
+                os._exit(EXTRAS_FAILED)
 
-            timer = threading.Timer(args.extras_timeout, bail)
+            # a rank that fails says so in the job's key-value store; a watcher thread on every rank polls it, so that
+            # nobody waits out the whole --extras-timeout inside a collective the failed rank will never enter
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:
+                store = None
+            stop_watching = threading.Event()
+
+            def watch():
+                while store is not None and not stop_watching.wait(0.5):
+                    try:
+                        if store.check(["mtg_bench_extras_error"]):
+                            give_up(store.get("mtg_bench_extras_error").decode())
+                    except Exception:
+                        return
+
+            watcher = threading.Thread(target=watch, daemon=True)
+            watcher.start()
+            timer = threading.Timer(args.extras_timeout, lambda: give_up("timed out after %d s" % args.extras_timeout))
             timer.daemon = True
             timer.start()
             try:
@@ -648,7 +678,8 @@ def main():
                 if not args.no_workflow:
                     # configs[3] as a whole workflow, its simulated light curves cut into one block per rank (first: it
                     # needs torch.distributed's collectives only, the walker-sharded configs bring the library's own
-                    # RCCL communicator up)
+                    # RCCL communicator up).  Reproducible mode: T_sim and the p-value are those of the one-GPU run
+                    # (workflow_config3 of the N = 1 line), to the last bit.
                     dist.barrier()
                     t1 = time.perf_counter()
                     wf = workflow_probe().run(sharded=True, device=local_dev)
@@ -660,13 +691,18 @@ def main():
                 extras["walker_sharded"] = walker_sharded_configs(rank, world, local_dev, oversubscribed)
                 dist.barrier()        # every rank got through: nobody is left inside a collective
                 timer.cancel()
-            except BaseException as exc:     # this rank failed: the others find out at the timer
+                stop_watching.set()
+            except BaseException as exc:     # this rank failed: tell the others, let rank 0 print, leave
                 traceback.print_exc()
-                extras["multi_rank_extras_error"] = "rank %d: %r" % (rank, exc)
-                if rank == 0:
-                    print(json.dumps(headline_line()), flush=True)
-                    os._exit(0)
-                timer.join()                 # (rank 0 may be waiting for this rank inside a collective: let its timer print)
+                why = "rank %d: %r" % (rank, exc)
+                if store is not None:
+                    try:
+                        store.set("mtg_bench_extras_error", why)
+                    except Exception:
+                        pass
+                if rank != 0:
+                    time.sleep(3.0)          # rank 0's watcher prints the line before a launcher that sees this rank die stops it
+                give_up(why)
     if world == 1 and not args.no_extras:
         # (a) the same sweep through the host-pointer entry point: H2D theta + kernels + D2H lnP, status
         reps = max(3, min(args.steps, 10))
@@ -727,6 +763,82 @@ def main():
             "fp64_valu_frac": None if flop0 is None else n_ok0 * N * flop0 / s0 / 1e12 / FP64_PEAK_TFLOPS,
             "both_models_evals_per_s": 2 * B / (dt0 + elapsed / args.steps)}
         eng.set_model(kinds, full, free, bounds)
+        # (d) a model whose six ranks are all arithmetic -- three SHO terms, NR = 0, NC = 3 -- beside the headline, whose
+        # "J = 6" is five ranks of arithmetic (the Lorentzian's null real term is dropped)
+        skinds = [synth.K_SHO] * 3
+        sfull, sfree, sbounds = synth.model_spec(skinds, y, per_lc_mean=True)
+        sth = np.array([np.log(50.0), np.log(3.0), np.log(2 * np.pi / 7.0), np.log(30.0), np.log(8.0), np.log(2 * np.pi / 13.0),
+                        np.log(20.0), np.log(1.5), np.log(2 * np.pi / 31.0)])
+        sfull[:9] = sth
+        eng.set_model(skinds, sfull, sfree, sbounds)
+        d_theta6 = torch.from_numpy(sth * (1 + 0.03 * np.random.default_rng(20250704 + 42).standard_normal((B, 9)))).to(dev)
+        for _ in range(2):
+            sweep(B, d_theta6)
+        torch.cuda.synchronize(dev)
+        eng.profile_begin(reps)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sweep(B, d_theta6)
+        torch.cuda.synchronize(dev)
+        dt6 = (time.perf_counter() - t1) / reps
+        _, solve6 = eng.profile_read()
+        n_ok6 = int((d_status.cpu().numpy() == 0).sum())
+        k6, s6 = eng.last_solver, float(np.mean(solve6)) * 1e-3
+        flop6 = FLOP_PER_SAMPLE.get(k6)
+        if n_ok6 < B // 2:
+            raise SystemExit("bench: the three-SHO sweep rejected most of its rows")
+        extras["true_J6_sweep"] = {
+            "model": "3 x SHO, all under-damped (NR = 0, NC = 3: J = 6 of arithmetic, P = 9)", "evals_per_step": B,
+            "ms_per_step": dt6 * 1e3, "evals_per_s": B / dt6, "kernel": k6, "kernel_ms": s6 * 1e3, "evals_ok": n_ok6,
+            "algorithmic_hbm_frac": n_ok6 * (24 * N + 8 * 9 + 12) / s6 / 1e9 / HBM_PEAK_GBS,
+            "fp64_valu_frac": None if flop6 is None else n_ok6 * N * flop6 / s6 / 1e12 / FP64_PEAK_TFLOPS}
+        eng.set_model(kinds, full, free, bounds)
+        # (e) the mid-batch regime: one GPU's half-step at 8 GPUs -- 250 light curves x 128 proposals = 32 000 rows -- on
+        # the one-lane sweep and on its two-wave pipeline (csrc/mtg_kernels_pipe.hip), both models, device time
+        mid = {}
+        Lm, Wm = max(1, L // 8), W // 2
+        Bm = Lm * Wm
+        d_lc_mid = torch.from_numpy(np.repeat(np.arange(Lm, dtype=np.int32), Wm)).to(dev)
+        for label, mk, th_dev in (("alt_J5_arith", kinds, d_theta), ("null_J3", nkinds, d_theta0)):
+            mfull, mfree, mbounds = (full, free, bounds) if mk is kinds else (nfull, nfree, nbounds)
+            eng.set_model(mk, mfull, mfree, mbounds)
+            ms, names, outs = {}, {}, {}
+            for _ in range(4):
+                for mode in (0, 2):
+                    eng.set_pipeline(mode)
+                    eng.loglike_device(Bm, th_dev.data_ptr(), d_lc_mid.data_ptr(), d_out.data_ptr(), d_status.data_ptr(),
+                                       add_prior=True, stream=stream.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    ms[mode] = min(ms.get(mode, np.inf), eng.last_kernel_ms)
+                    names[mode] = eng.last_solver
+                    outs[mode] = d_out[:Bm].cpu().numpy()
+            if not np.array_equal(outs[0], outs[2]):
+                raise SystemExit("bench: the pipelined sweep and the one-lane sweep differ (%s)" % label)
+            mid[label] = {"rows": Bm, "one_lane_ms": ms[0], "one_lane_kernel": names[0], "pipeline_ms": ms[2],
+                          "pipeline_kernel": names[2], "bitwise_equal": True}
+        eng.set_pipeline(2)
+        eng.set_model(kinds, full, free, bounds)
+        mid["what"] = ("prepare + sort + solve of one half-step of %d light curves x %d proposals, N = %d: what one GPU of 8 "
+                       "runs 1002 times per model in the configs[3] workflow" % (Lm, Wm, N))
+        extras["mid_batch_half_step"] = mid
+        # (f) what HBM can actually stream on this box: a device-to-device copy of 2 GiB (read + write bytes / time),
+        # beside the vendor's 8 TB/s that `roofline.peak` quotes
+        nbytes = 1 << 31
+        src_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
+        dst_buf = torch.empty_like(src_buf)
+        for _ in range(2):
+            dst_buf.copy_(src_buf)
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best_ms = np.inf
+        for _ in range(5):
+            ev_a.record()
+            dst_buf.copy_(src_buf)
+            ev_b.record()
+            ev_b.synchronize()
+            best_ms = min(best_ms, ev_a.elapsed_time(ev_b))
+        del src_buf, dst_buf
+        extras["hbm_copy_measured"] = {"GB_per_s": 2 * nbytes / (best_ms * 1e-3) / 1e9, "bytes_each_way": nbytes,
+                                       "what": "hipMemcpyAsync device to device, read + write bytes over the fastest of 5"}
 
     if rank == 0:
         line = headline_line()
@@ -740,6 +852,11 @@ def main():
             line["other_configs"] = single_lightcurve_configs()
             if not args.no_workflow:
                 line["workflow_config3"] = workflow_probe().run()
+                # one GPU on the share of the workflow it gets at 8 GPUs, split by light curve: 250 simulated light curves,
+                # both models (the observed light curve's chains are not split: every rank runs them)
+                share = workflow_probe().run(nsims=max(1, args.lightcurves // 8))
+                line["workflow_config3_share_of_8"] = share
+                share["projected_speedup_at_8_gpus"] = line["workflow_config3"]["whole_test_s"] / share["whole_test_s"]
         print(json.dumps(line), flush=True)
 
     eng.close()

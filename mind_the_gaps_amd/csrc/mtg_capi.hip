@@ -857,8 +857,12 @@ MTG_API int mtg_loglike_batch_device(mtg_ctx *ctx, int64_t B, const double *d_th
     if (rc) return rc;
     ctx->lc_grouped_hint = 0;   // device-resident indices: the host cannot see their order
     rc = run_model_batch(ctx, B, d_theta, d_lc_index, add_prior, d_out, d_status, s);
-    if (rc) return rc;
-    return leave_stream(ctx, s);
+    // whatever happened: kernels may already be queued on the caller's stream, and the next call on another stream
+    // must wait for them before it touches the shared workspaces (the first error is the one reported)
+    const std::string first_error = ctx->err;
+    const int rc_leave = leave_stream(ctx, s);
+    if (rc) { ctx->err = first_error; return rc; }
+    return rc_leave;
 }
 
 MTG_API int mtg_loglike_batch(mtg_ctx *ctx, int64_t B, const double *theta, const int32_t *lc_index,
@@ -1549,11 +1553,16 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
 }
 
 // transforms per execution of the simulator's plan: a function of the length alone, so that one plan serves every
-// call (16 transforms of 10^6 points fill the GPU; short transforms are batched by the hundred)
+// call (16 transforms of 10^6 points fill the GPU; short transforms are batched by the hundred) -- as long as the
+// spectrum and series buffers of one execution, 16 nk + 8 nfft bytes per transform, stay within 2 GiB: a series of
+// 2^30 points (the longest mtg_simulate_plan accepts) is transformed one at a time
 static int sim_batch_for(int64_t nfft)
 {
     int64_t b = ((int64_t)1 << 24) / nfft;
-    return (int)(b < 16 ? 16 : b > 256 ? 256 : b);
+    b = b < 16 ? 16 : b > 256 ? 256 : b;
+    const int64_t fit = ((int64_t)1 << 31) / (16 * (nfft / 2 + 1) + 8 * nfft);
+    if (b > fit) b = fit;
+    return (int)(b < 1 ? 1 : b);
 }
 
 // the context's C2R plan of length nfft (made, or remade for another length, under sim_mu); no fail(): may run on a
@@ -1707,6 +1716,9 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     cleanup();
     yv_tmp.release();
+    // the plan's buffers stay with the context for the next call of the workflow -- unless they are large enough to be
+    // in somebody's way (a fine simulation grid: hundreds of MB per transform)
+    if (spec.cap + series.cap > ((size_t)1 << 30)) { spec.release(); series.release(); }
     if (e != hipSuccess) {
         // the resident set may have been freed or partly overwritten on the way: nothing is resident any more
         if (make_resident) { ctx->N = 0; ctx->L = 0; }

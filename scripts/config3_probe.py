@@ -18,9 +18,11 @@ from mind_the_gaps_amd.simulator import Simulator
 AMP, OTHER = (-10, 50), (-10, 10)
 
 
-def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurrent_refits=False):
+def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurrent_refits=False, reproducible=True):
     """-> dict (the JSON line of this script).  bench.py calls it for its `workflow_config3` entry; ``sharded``: inside
-    a torch.distributed job, the simulated light curves split over the ranks (ppp.protassov_test(sharded=True))."""
+    a torch.distributed job, the simulated light curves split over the ranks (ppp.protassov_test(sharded=True)).
+    ``reproducible`` (default): T_sim and the p-value do not depend on the number of ranks or the split -- the sharded
+    run of `bench.py --gpus N` must print the p-value of the one-GPU run."""
     th = synth.truth(synth.ALT_MODEL)
     rng = np.random.default_rng(20250704 + 3)
     times = synth.make_times(N, rng)
@@ -48,7 +50,7 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurre
         t0 = time.perf_counter()
         res = protassov_test(lc, null_kernel(), alt_kernel(), nsims=nsims, walkers=W, max_steps=1000, sim_walkers=W,
                              sim_steps=steps, sigma_noise=1.0, extension_factor=2, seed=1, device=device, sharded=sharded,
-                             concurrent_refits=concurrent_refits)
+                             concurrent_refits=concurrent_refits, reproducible=reproducible)
         el = time.perf_counter() - t0
     evals = 2 * nsims * W * (steps + 1)
     return {
@@ -57,7 +59,8 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurre
         "observed_lightcurve_s": t_obs_sim, "whole_test_s": el,
         "seconds": {k: float(v) for k, v in res["seconds"].items()}, "split": res["split"],
         "refit_evaluations": evals, "refit_evaluations_per_s_end_to_end": evals / el,
-        "T_obs": res["T_obs"], "p_value": res["p_value"],
+        "T_obs": res["T_obs"], "p_value": res["p_value"], "reproducible": bool(reproducible),
+        "T_sim_checksum": float(np.sum(res["T_sim"])),
         "T_sim_quantiles_50_90_99": [float(q) for q in np.quantile(res["T_sim"], [0.5, 0.9, 0.99])],
         "null_converged": bool(res["null"].converged), "alt_converged": bool(res["alt"].converged),
     }
