@@ -77,6 +77,16 @@ MTG_API int mtg_term_nparams(int kind);
  * (gpmodelling.py:245).  Returns NULL when `device` is not a usable GPU.
  */
 MTG_API mtg_ctx *mtg_create(int device);
+/*
+ * A context whose kernels run on one of `parts` (1 to 8) equal, disjoint slices of the device's compute units (CU i is
+ * in slice i mod parts; the context's stream carries the CU mask).  Two contexts on the two halves of a GPU run their
+ * launches side by side whatever order they arrive in: the null and the alternative model's refits of the Protassov
+ * loop (docs/notebooks/tutorial_ppp.ipynb:334-340, one after the other in the reference), each a half-step of
+ * ~32 000 rows at 8 GPUs -- one wave per SIMD on its half -- take max(t_null, t_alt) together instead of
+ * t_null + t_alt (ppp.protassov_test(concurrent_refits=True)).  Calls on a caller's stream
+ * (mtg_loglike_batch_device with a stream of the caller's) run wherever that stream runs.
+ */
+MTG_API mtg_ctx *mtg_create_on_slice(int device, int part, int parts);
 MTG_API void mtg_destroy(mtg_ctx *ctx);
 /* Message for the last non-zero return on this context (ctx may be NULL for
  * mtg_create failures). */

@@ -602,7 +602,7 @@ MTG_API int mtg_term_nparams(int kind) { return nparams(kind); }
 
 MTG_API int mtg_structure_supported(int jr, int jc) { return mtg_find_solver(jr, jc) ? 1 : 0; }
 
-MTG_API mtg_ctx *mtg_create(int device)
+static mtg_ctx *create_context(int device, int part, int parts)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -615,22 +615,48 @@ MTG_API mtg_ctx *mtg_create(int device)
         fail(nullptr, MTG_E_ARG, "device %d out of range [0, %d)", device, n);
         return nullptr;
     }
+    if (parts < 1 || parts > 8 || part < 0 || part >= parts) {
+        fail(nullptr, MTG_E_ARG, "slice %d of %d compute-unit slices: 1 to 8 slices", part, parts);
+        return nullptr;
+    }
     mtg_ctx *ctx = new (std::nothrow) mtg_ctx();
     if (!ctx) return nullptr;
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+    bool ok = hipSetDevice(device) == hipSuccess;
+    if (ok && (hipDeviceGetAttribute(&ctx->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->cus <= 0))
+        ctx->cus = 256;
+    if (ok && parts > 1) {
+        // a contiguous run of mask bits per slice (MTG_CU_SLICE_INTERLEAVED=1: bit i to slice i mod parts): the contexts
+        // of different slices run their kernels side by side on disjoint compute units (a queue's CU mask), whatever the
+        // order their launches arrive in.  (The driver deals the bits of a mask round over the XCDs: a contiguous run
+        // leaves every XCD with its share of enabled compute units, which a dispatch split over all XCDs needs.)
+        uint32_t mask[16] = {};
+        int mine = 0;
+        const bool interleaved = getenv("MTG_CU_SLICE_INTERLEAVED") && atoi(getenv("MTG_CU_SLICE_INTERLEAVED")) == 1;
+        const int per = ctx->cus / parts;
+        for (int i = 0; i < ctx->cus && i < 512; ++i)
+            if (interleaved ? i % parts == part : (i / per == part || (part == parts - 1 && i / per >= parts))) {
+                mask[i / 32] |= 1u << (i % 32);
+                ++mine;
+            }
+        ok = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)((ctx->cus + 31) / 32), mask) == hipSuccess;
+        ctx->cus = mine;
+    } else if (ok) {
+        ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    }
+    if (!ok || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->foreign_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->own_done, hipEventDisableTiming) != hipSuccess) {
         fail(nullptr, MTG_E_HIP, "could not create stream/events on device %d", device);
         delete ctx;
         return nullptr;
     }
-    if (hipDeviceGetAttribute(&ctx->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->cus <= 0)
-        ctx->cus = 256;
     return ctx;
 }
+
+MTG_API mtg_ctx *mtg_create(int device) { return create_context(device, 0, 1); }
+
+MTG_API mtg_ctx *mtg_create_on_slice(int device, int part, int parts) { return create_context(device, part, parts); }
 
 MTG_API void mtg_destroy(mtg_ctx *ctx)
 {

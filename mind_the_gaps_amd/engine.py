@@ -24,7 +24,7 @@ ST_OK, ST_PRIOR, ST_NOTPD, ST_NONFINITE = 0, 1, 2, 3
 E_ARG, E_NODEVICE, E_HIP, E_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
 
 EXPORTS = (
-    "mtg_device_count", "mtg_version", "mtg_term_nparams", "mtg_create", "mtg_destroy",
+    "mtg_device_count", "mtg_version", "mtg_term_nparams", "mtg_create", "mtg_create_on_slice", "mtg_destroy",
     "mtg_last_error", "mtg_set_lightcurves", "mtg_set_lightcurves_device", "mtg_set_model",
     "mtg_loglike_batch", "mtg_loglike_batch_device", "mtg_loglike_coeffs", "mtg_synchronize",
     "mtg_last_kernel_ms", "mtg_structure_supported", "mtg_profile_begin", "mtg_profile_read",
@@ -171,6 +171,8 @@ def load_library():
     lib.mtg_term_nparams.argtypes = [c_int]
     lib.mtg_create.restype = c_vp
     lib.mtg_create.argtypes = [c_int]
+    lib.mtg_create_on_slice.restype = c_vp
+    lib.mtg_create_on_slice.argtypes = [c_int, c_int, c_int]
     lib.mtg_destroy.restype = None
     lib.mtg_destroy.argtypes = [c_vp]
     lib.mtg_last_error.restype = ctypes.c_char_p
@@ -317,11 +319,16 @@ def _one_thread_at_a_time(method):
 class Engine:
     """One MI355X with resident light curves and a model (an ``mtg_ctx``)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, cu_slice=None):
+        """``cu_slice`` = (part, parts): the context's kernels keep to that slice of the GPU's compute units
+        (include/mtg.h: mtg_create_on_slice), so that contexts on different slices run side by side."""
         import threading
         self._busy = threading.RLock()
         self._lib = load_library()
-        self._ctx = self._lib.mtg_create(int(device))
+        if cu_slice is None:
+            self._ctx = self._lib.mtg_create(int(device))
+        else:
+            self._ctx = self._lib.mtg_create_on_slice(int(device), int(cu_slice[0]), int(cu_slice[1]))
         if not self._ctx:
             raise EngineUnavailable(
                 "mtg_create(%d) failed: %s" % (device, self._lib.mtg_last_error(None).decode()))

@@ -126,8 +126,8 @@ class LogProbEvaluator:
         self._bound_offset = None
         self._token = object()
         self._own = None
-        if own_engine:
-            self._own = _engine.Engine(device)
+        if own_engine:     # True, or (part, parts): a context of its own on that slice of the compute units
+            self._own = _engine.Engine(device, cu_slice=None if own_engine is True else tuple(own_engine))
             self._own.bound_to = None
 
     def close(self):

@@ -16,6 +16,7 @@ the burn-in / thinning arithmetic are those of `sampler.EnsembleSampler` and
 `GPModelling.derive_posteriors` (gpmodelling.py:197-286), applied per light curve;
 random numbers come from one vectorised generator instead of L private streams.
 """
+import os
 import warnings
 
 import numpy as np
@@ -286,7 +287,7 @@ class _DeviceBatch:
 
 def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit=True, seed=None,
                             device=0, store_chain=True, initial_params=None, quiet=False,
-                            evaluate=None, device_sampler=True, own_engine=False, index_base=None):
+                            evaluate=None, device_sampler=True, own_engine=False, index_base=None, before_sampling=None):
     """GPModelling(lc, kernel).derive_posteriors(...) for L light curves at once.
 
     times [N] (shared sampling, gpmodelling.py:538); Y, DY [L, N]; ``kernel`` a
@@ -297,6 +298,9 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     ``device_sampler`` keeps the L ensembles on the GPU between iterations
     (``mtg_ensemble_*``) instead of proposing and accepting on the host.  ``own_engine``: a device context for this
     call alone (closed before it returns), so that several calls can run side by side from different host threads.
+
+    ``before_sampling``: called once, between the starting fit and the chains (two calls that run side by side meet there,
+    so that their chains -- the long, regular part -- overlap from the first iteration to the last).
 
     ``index_base`` (an integer; needs ``seed`` and the device sampler): these are light curves [index_base,
     index_base + L) of a larger set that is being fitted in blocks, and every one of them must get the result it
@@ -358,6 +362,9 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
             rng = np.random.default_rng(seed)
             p0 = _spread(rng, centers, lower, upper, walkers)
         clock.append(("spread", time.perf_counter()))
+        if before_sampling is not None:
+            before_sampling()
+            clock.append(("wait", time.perf_counter()))
         if device_sampler and ev is not None:
             from .device_sampler import DeviceEnsembleSampler
             dev = DeviceEnsembleSampler(lambda: ev._bind(model), walkers, P, n_ensembles=L,
@@ -395,7 +402,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
 
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
                    sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
-                   sharded=False, group=None, concurrent_refits=False, split="auto", reproducible=None):
+                   sharded=False, group=None, concurrent_refits="auto", split="auto", reproducible=None):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -409,8 +416,12 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     wall time of the observed chains, the simulation and the two refits on this process.
 
     ``concurrent_refits``: the null and the alternative refits of step 3 side by side on the device (two contexts, two
-    host threads) instead of one after the other; the results are the same either way and so, within 0.3 %, is the
-    time (``seconds`` then gives the two refits' common wall time under "refit_null" and 0 under "refit_alt").
+    host threads) instead of one after the other; the results are the same either way (``seconds`` then gives the two
+    refits' common wall time under "refit_null" and 0 under "refit_alt").  "auto" (default): side by side when a
+    half-step leaves the GPU room -- at most ~40 000 rows, e.g. one GPU's 250 light curves x 128 proposals at 8 GPUs,
+    where the two models' launches interleave and their tails and sampler kernels overlap (7.1 ms per iteration of both
+    against 8.1 ms one after the other); with the GPU full (2000 x 128 rows) there is nothing to gain (26.30 s against
+    26.36 s) and the refits run one after the other.
 
     ``sharded`` (inside a ``torch.distributed`` job, one process per GPU, every rank calling with the same
     arguments and its own ``device``; BASELINE configs[3]): steps 2 and 3 -- the loop over simulated light curves
@@ -495,20 +506,30 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
             sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)   # independent noise on every block (the two ranks
             fit_seeds = [f + 7919 * block for f in fit_seeds]       # of a block under the model split draw the same)
     out, fits, best = None, [None, None], [np.empty(0), np.empty(0)]
+    # each model on a context of its own (MTG_PPP_CU_SLICES=1: and on its own half of the compute units,
+    # mtg_create_on_slice -- measured no faster: 7.24 against 7.14 ms per iteration)
+    side_by_side = len(models) == 2 and (concurrent_refits is True or
+                                         (concurrent_refits == "auto" and (hi - lo) * (sw // 2) <= 40000 and hi - lo > 1))
+    if side_by_side and os.environ.get("MTG_PPP_CU_SLICES") == "1":
+        side_by_side = "slices"
     if hi > lo:
         sim.random_state = np.random.RandomState(sim_seed)
         out = sim.simulate(samples[lo:hi, :null_kernel.vector_size], index_base=lo if reproducible else 0)
         clock.append(time.perf_counter())
+        import threading
+        meet = threading.Barrier(2) if side_by_side else None
+
         def refit(k):
             kernel = (null_kernel, alt_kernel)[k]
             return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
                                            max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
-                                           store_chain=False, quiet=True, own_engine=concurrent_refits,
-                                           index_base=lo if reproducible else None)
+                                           store_chain=False, quiet=True, own_engine=((k, 2) if side_by_side == "slices" else bool(side_by_side)),
+                                           index_base=lo if reproducible else None,
+                                           before_sampling=(lambda: meet.wait(timeout=600)) if meet is not None else None)
 
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            if concurrent_refits and len(models) == 2:
+            if side_by_side:
                 # The two models' refits are independent: each on its own context and stream, driven by its own host
                 # thread (the library calls release the GIL).  Measured at configs[3]'s sizes: 26.30 s side by side
                 # against 8.40 + 17.96 s one after the other -- both sweeps are bound by FP64 issue and a half-step

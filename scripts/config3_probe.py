@@ -18,7 +18,7 @@ from mind_the_gaps_amd.simulator import Simulator
 AMP, OTHER = (-10, 50), (-10, 10)
 
 
-def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurrent_refits=False, reproducible=True):
+def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurrent_refits="auto", reproducible=True):
     """-> dict (the JSON line of this script).  bench.py calls it for its `workflow_config3` entry; ``sharded``: inside
     a torch.distributed job, the simulated light curves split over the ranks (ppp.protassov_test(sharded=True)).
     ``reproducible`` (default): T_sim and the p-value do not depend on the number of ranks or the split -- the sharded
@@ -68,4 +68,5 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurre
 
 if __name__ == "__main__":
     args = [int(a) for a in sys.argv[1:5]]
-    print(json.dumps(run(*args, concurrent_refits=os.environ.get("MTG_C3_CONCURRENT_REFITS") == "1")), flush=True)
+    mode = {"1": True, "0": False}.get(os.environ.get("MTG_C3_CONCURRENT_REFITS", ""), "auto")
+    print(json.dumps(run(*args, concurrent_refits=mode)), flush=True)
