@@ -111,8 +111,11 @@ def rocfft_library_version():
 def _seed_rocfft_cache():
     """rocFFT compiles the kernels of every new transform length at run time (~1.2 s each on this ROCm build) and
     keeps them in the file ROCFFT_RTC_CACHE_PATH names -- by default under ~/.cache, which a fresh machine or an
-    ephemeral box does not have.  The package ships a SEED of that file with the power-of-two lengths
-    mtg_chain_autocorr uses (scripts/make_rocfft_cache.py).  The seed itself is never opened by rocFFT: every
+    ephemeral box does not have.  A SEED of that file with the power-of-two lengths mtg_chain_autocorr uses may lie
+    next to the library (generated on a GPU by scripts/make_rocfft_cache.py -- __graft_entry__.build() does it where a
+    GPU is visible --, git-ignored: 1.4 MB of code objects are not source).  Without it everything works: the
+    convergence check's transforms run on the host until a device plan has paid for itself
+    (device_sampler._autocorr_time_where_it_is_cheapest).  The seed itself is never opened by rocFFT: every
     process works on its own copy in the temporary directory (rocFFT writes to the file it is given -- eight ranks
     of a node must not share one, and the tracked file must not change under a run), removed at exit; the seed is
     skipped when it was made with another rocFFT build (version stamp next to it) or when the user chose a file."""
