@@ -294,6 +294,59 @@ def _gpu_chain_worker(rank, world, port, out_dir):
     guard.close()
 
 
+def _time_shard_worker(rank, world, port, out_dir):
+    """One rank of the time-sharded rank-10 likelihood (proto/time_shard.py): its eighth -- here: half or third -- of
+    the light curve for every row, one element per row, one all-gather, the combination on every rank."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import dense
+    from proto.kalman_scan import model_matrices
+    from proto import time_shard as ts
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kinds = [synth.K_SHO] * 5
+    N, rows = 1200, 3
+    t, y, dy = synth.make_lightcurves(N, 1, seed=5)
+    base = np.concatenate([[np.log(20.0 + 10 * i), np.log([3.0, 8.0, 10.0, 1.0, 0.8][i]), np.log(2 * np.pi / (5.0 + 6 * i))]
+                           for i in range(5)])
+    theta = base * (1 + 0.02 * np.random.default_rng(9).standard_normal((rows, 15)))     # the same rows on every rank
+    r, var = y[0] - y[0].mean(), (dy[0] + 1e-12) ** 2
+    bounds = ts.time_bounds(N, world)
+    mine = []
+    for th in theta:                                  # every row, this rank's stretch of time only
+        blocks, jitter = model_matrices(dense.build_coeffs(kinds, th))
+        mine.append(ts.pack(ts.shard_element(t, r, var, blocks, jitter, bounds[rank], bounds[rank + 1], nchunks=4)))
+    mine = torch.from_numpy(np.stack(mine))
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)                   # the one exchange: rows x 321 doubles per rank
+    lnl = np.array([ts.combine_shards([ts.unpack(gathered[g][i].numpy(), 10) for g in range(world)]) for i in range(rows)])
+    np.save(os.path.join(out_dir, "ts%d_%d.npy" % (world, rank)), lnl)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_time_sharded_likelihood_on_gloo_ranks(tmp_path, world):
+    """Time sharding of the rank-10 model (what would give BASELINE configs[4] its eighth per GPU): every rank
+    reduces its stretch of the light curve to one filtering element per row, one all-gather, every rank combines --
+    against the C oracle (celerite's algorithm) on the whole light curve."""
+    import torch.multiprocessing as mp
+    from oracle import celerite as oracle_c
+    mp.spawn(_time_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / ("ts%d_%d.npy" % (world, r))) for r in range(world)]
+    assert all(np.array_equal(got[0], g) for g in got[1:])           # every rank ends with the same numbers
+    kinds = [synth.K_SHO] * 5
+    t, y, dy = synth.make_lightcurves(1200, 1, seed=5)
+    base = np.concatenate([[np.log(20.0 + 10 * i), np.log([3.0, 8.0, 10.0, 1.0, 0.8][i]), np.log(2 * np.pi / (5.0 + 6 * i))]
+                           for i in range(5)])
+    theta = base * (1 + 0.02 * np.random.default_rng(9).standard_normal((3, 15)))
+    ref, st = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, np.full((3, 1), y[0].mean())]), add_prior=False)
+    assert np.all(st == 0)
+    assert np.max(np.abs(got[0] - ref) / np.abs(ref)) < 1e-10
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(400)
 def test_derive_posteriors_shard_walkers_two_ranks_one_gpu(tmp_path):
