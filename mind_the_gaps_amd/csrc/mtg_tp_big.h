@@ -25,6 +25,17 @@
 #include "mtg_timeparallel.h"
 #include "mtg_tp_scan.h"
 
+// byte masks of the table look-ups of the composition kernels.  -DMTG_DBG_TABLE_BROADCAST (measurements only, wrong
+// results): every lane reads entry 0 -- a broadcast, no bank conflict -- which tells the conflicts of the look-ups (64
+// random addresses per wave-instruction) from those of the rings (lane-strided doubles: conflict-free by construction)
+#ifdef MTG_DBG_TABLE_BROADCAST
+#define TPB_EXP_MASK 0
+#define TPB_TRIG_MASK 0
+#else
+#define TPB_EXP_MASK ((MTG_EXP_N - 1) * 8)
+#define TPB_TRIG_MASK ((MTG_TRIG_N - 1) * 16)
+#endif
+
 namespace {
 
 // tp_predict_dev with the real x real part scaled row by row (phi_i phi_j formed inside the entry's
@@ -97,7 +108,7 @@ __device__ __forceinline__ void tpb_transition(const TpModel<NR, NC> &M, double 
         const double w = __builtin_fma(-c, dxs, magic);
         const double q8 = w - magic;                                                // 8 rint(-c dx N / ln2)
         const int i8 = (int)q8;
-        et[i] = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+        et[i] = *(const double *)((const char *)tab->exp2_frac + (i8 & TPB_EXP_MASK));
         er[i] = __builtin_fma(-c, dx, q8 * -MTG_EXP_C1);
         ek[i] = i8 >> (3 + MTG_EXP_BITS);
     }
@@ -119,7 +130,7 @@ __device__ __forceinline__ void tpb_transition(const TpModel<NR, NC> &M, double 
         const double w = __builtin_fma(x, 0x1.45f306dc9c883p+1 * MTG_TRIG_N, tm);   // x 16 N / 2 pi
         const double md16 = w - tm;
         pr[k] = __builtin_fma(md16, -(0x1.921fb54442d18p-2 / MTG_TRIG_N), x);       // 2 pi / 16 N
-        pj[k] = *(const double2 *)((const char *)tab->cis + ((__double2loint(w) << 4) & ((MTG_TRIG_N - 1) * 16)));
+        pj[k] = *(const double2 *)((const char *)tab->cis + ((__double2loint(w) << 4) & TPB_TRIG_MASK));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -489,7 +500,7 @@ __device__ __forceinline__ void tpb_transition_part(const TpModel<NR, NC> &M, do
         const double w = __builtin_fma(-c, dxs, magic);
         const double q8 = w - magic;
         const int i8 = (int)q8;
-        et[i - T0] = *(const double *)((const char *)tab->exp2_frac + (i8 & ((MTG_EXP_N - 1) * 8)));
+        et[i - T0] = *(const double *)((const char *)tab->exp2_frac + (i8 & TPB_EXP_MASK));
         er[i - T0] = __builtin_fma(-c, dx, q8 * -MTG_EXP_C1);
         ek[i - T0] = i8 >> (3 + MTG_EXP_BITS);
     }
@@ -510,7 +521,7 @@ __device__ __forceinline__ void tpb_transition_part(const TpModel<NR, NC> &M, do
         const double w = __builtin_fma(x, 0x1.45f306dc9c883p+1 * MTG_TRIG_N, tm);
         const double md16 = w - tm;
         pr[k - C0] = __builtin_fma(md16, -(0x1.921fb54442d18p-2 / MTG_TRIG_N), x);
-        pj[k - C0] = *(const double2 *)((const char *)tab->cis + ((__double2loint(w) << 4) & ((MTG_TRIG_N - 1) * 16)));
+        pj[k - C0] = *(const double2 *)((const char *)tab->cis + ((__double2loint(w) << 4) & TPB_TRIG_MASK));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
