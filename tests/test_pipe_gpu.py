@@ -156,3 +156,70 @@ def test_models_without_a_pipeline_keep_the_one_lane_sweep(pipe):
         theta = synth.draw_thetas(kinds, 300, seed=1)
         out, st = pipe.loglike(theta, np.zeros(300, dtype=np.int32))
         assert "mtg_solve_kernel" in pipe.last_solver and np.all(st <= 1) and np.all(np.isfinite(out[st == 0])) and (st == 0).sum() > 100
+
+
+def test_a_rows_bits_do_not_depend_on_its_batch_under_modes_0_and_3(engine):
+    """What a job needs that cuts its rows over several GPUs and wants the one-GPU numbers (ppp.protassov_test(reproducible=
+    True)): under mtg_set_time_parallel 0 (one-lane sweep or its pipeline) and 3 (the one-wave time-parallel kernel
+    only) a row's value is the same whether it travels alone, with 200 or with 9000 others; under the automatic mode the
+    batch size picks between one, two and four waves per evaluation, whose sums differ in the last bits."""
+    kinds = K.ALT_MODEL
+    N, B = 4500, 9000
+    t, y, dy = synth.make_lightcurves(N, 1, seed=6)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    engine.set_model(kinds, full, free, bounds)
+    theta = synth.draw_thetas(kinds, B, seed=3, percent=0.05)
+    try:
+        seen = {}
+        for mode in (0, 3, 2):
+            engine.set_time_parallel(mode)
+            outs = {}
+            for rows in (1, 200, 600, B):
+                outs[rows], st = engine.loglike(theta[:rows], None, add_prior=True)
+                assert np.all(st == 0)
+                seen[(mode, rows)] = engine.last_solver
+            if mode in (0, 3):
+                for rows in (1, 200, 600):
+                    assert np.array_equal(outs[rows], outs[B][:rows]), (mode, rows, seen)
+            else:
+                assert any(not np.array_equal(outs[rows], outs[B][:rows]) for rows in (200, 600)), seen
+            ref = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta[:200], np.full((200, 1), y.mean())]), bounds=bounds,
+                                         add_prior=True, nthreads=8)[0]
+            assert np.max(np.abs(outs[200] - ref) / np.abs(ref)) <= 1e-8
+        assert "mtg_tp_kernel" in seen[(3, B)] or "mtg_tp_fused_kernel" in seen[(3, B)], seen      # one wave per evaluation, even for 9000 rows
+    finally:
+        engine.set_time_parallel(2)
+
+
+def test_context_on_a_slice_of_the_compute_units():
+    """mtg_create_on_slice: a context whose kernels keep to half of the GPU gives the numbers of an ordinary one (the pipeline
+    sizes itself by the slice: half the rows per round), and two of them work side by side from two threads."""
+    import threading
+    from mind_the_gaps_amd.engine import Engine
+    kinds = K.NULL_MODEL
+    N, L, W = 300, 40, 128
+    t, y, dy = synth.make_lightcurves(N, L, seed=4)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    theta = synth.draw_thetas(kinds, L * W, seed=5)
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    engines = [Engine(0), Engine(0, cu_slice=(0, 2)), Engine(0, cu_slice=(1, 2))]
+    try:
+        for eng in engines:
+            eng.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+            eng.set_model(kinds, full, free, bounds)
+        want, wst = engines[0].loglike(theta, lc)
+        got = {}
+
+        def work(i):
+            got[i] = engines[i].loglike(theta, lc)
+        threads = [threading.Thread(target=work, args=(i,)) for i in (1, 2)]
+        [th.start() for th in threads]
+        [th.join() for th in threads]
+        for i in (1, 2):
+            assert np.array_equal(got[i][1], wst) and np.array_equal(got[i][0], want)
+        with pytest.raises(Exception):
+            Engine(0, cu_slice=(2, 2))
+    finally:
+        for eng in engines:
+            eng.close()
