@@ -63,6 +63,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before anything initialises HIP (torch.cuda.* below does): eight hardware queues instead of four, so that the contexts
+# that work side by side in the workflow (two models' refits) do not end up sharing one (mind_the_gaps_amd/engine.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6

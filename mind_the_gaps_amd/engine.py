@@ -153,6 +153,11 @@ def _seed_rocfft_cache():
 
 
 def load_library():
+    # more hardware queues than HIP's default of four: contexts that work side by side (two models of the Protassov test,
+    # hipFFT's own streams, the fan-out streams of the structures) should not share one -- streams on one hardware queue
+    # run strictly one after the other.  Read by the HIP runtime when it initialises; a process that has initialised HIP
+    # before loading this library keeps what it had.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     """dlopen libmtg_hip.so and declare the prototypes (no GPU needed)."""
     global _lib
     if _lib is not None:

@@ -44,6 +44,24 @@ def get_engine(device=0):
     return eng
 
 
+_side_engines = {}
+
+
+def get_side_engine(device=0, k=0):
+    """The k-th extra context of a GPU, kept for the life of the process: work that runs BESIDE the process-wide engine's
+    (or beside another side engine's) from another host thread -- the two models of the Protassov test.  Kept and reused
+    rather than made per call: HIP deals its streams round the hardware queues in the order they are created (four queues
+    by default), and two contexts whose streams land on the same queue run their kernels strictly one after the other
+    (measured: the refits of a 250-light-curve block side by side 3.56 s, on one queue 4.09 s = one after the other)."""
+    key = (device, int(k))
+    eng = _side_engines.get(key)
+    if eng is None:
+        eng = _engine.Engine(device)
+        eng.bound_to = None
+        _side_engines[key] = eng
+    return eng
+
+
 def _inf_bounds(bounds):
     out = np.empty((len(bounds), 2), dtype=np.float64)
     for i, (lo, hi) in enumerate(bounds):
@@ -126,13 +144,20 @@ class LogProbEvaluator:
         self._bound_offset = None
         self._token = object()
         self._own = None
-        if own_engine:     # True, or (part, parts): a context of its own on that slice of the compute units
+        self._own_is_mine = False
+        if isinstance(own_engine, tuple) and own_engine and own_engine[0] == "side":
+            self._own = get_side_engine(device, own_engine[1])      # ("side", k): the process's k-th extra context, reused
+        elif own_engine:     # True, or (part, parts): a context of its own on that slice of the compute units
             self._own = _engine.Engine(device, cu_slice=None if own_engine is True else tuple(own_engine))
             self._own.bound_to = None
+            self._own_is_mine = True
 
     def close(self):
         if self._own is not None:
-            self._own.close()
+            if self._own_is_mine:
+                self._own.close()
+            elif self._own.bound_to is self._token:
+                self._own.bound_to = None       # a side engine goes back to the pool; its resident set is nobody's now
             self._own = None
 
     @property
@@ -183,7 +208,7 @@ class LogProbEvaluator:
 class GP(ModelSet):
     """celerite.GP look-alike; parameters are ``kernel:*`` then ``mean:*``."""
 
-    def __init__(self, kernel, mean=0.0, fit_mean=False, device=0):
+    def __init__(self, kernel, mean=0.0, fit_mean=False, device=0, own_engine=False):
         if not isinstance(kernel, Term):
             raise TypeError("kernel must be a mind_the_gaps_amd Term")
         try:
@@ -195,6 +220,7 @@ class GP(ModelSet):
             mean.freeze_all_parameters()
         super().__init__([("kernel", kernel), ("mean", mean)])
         self.device = device
+        self._own_engine = own_engine    # a device context of this GP's own (work that runs beside other work, from another thread)
         self._t = None
         self._yerr = None
         self._evaluator = None
@@ -228,6 +254,12 @@ class GP(ModelSet):
     def _device_model(self):
         return DeviceModel(self.kernel, self.mean, self.mean.unfrozen_mask)
 
+    def release_engine(self):
+        """Give a context of this GP's own back (``own_engine=True``); later calls use the process-wide engine."""
+        self._own_engine = False
+        if self._evaluator is not None:
+            self._evaluator.close()
+
     def _ensure_evaluator(self, y):
         if self._t is None:
             raise RuntimeError("you must call 'compute' first")
@@ -235,7 +267,9 @@ class GP(ModelSet):
         if y.shape != self._t.shape:
             raise ValueError("dimension mismatch")
         if self._evaluator is None or self._y_bound is None or not np.array_equal(self._y_bound, y):
-            self._evaluator = LogProbEvaluator(self._t, y, self._yerr, device=self.device)
+            if self._evaluator is not None:
+                self._evaluator.close()
+            self._evaluator = LogProbEvaluator(self._t, y, self._yerr, device=self.device, own_engine=self._own_engine)
             self._y_bound = y.copy()
         return self._evaluator
 

@@ -39,17 +39,22 @@ class GPModelling:
     meanmodels = ["linear", "constant", "gaussian"]
 
     def __init__(self, lightcurve: GappyLightcurve, kernel, mean_model: str = None, device: int = 0,
-                 quiet: bool = False):
+                 quiet: bool = False, random_state=None, own_engine: bool = False):
         """GP of ``kernel`` (a ``mind_the_gaps_amd.terms.Term``) on ``lightcurve``, factorised once with
         ``yerr = dy + 1e-12`` as the reference does (gpmodelling.py:54).
 
         ``mean_model``: None keeps the mean frozen at the light curve's average; "constant", "linear" or
         "gaussian" name a mean that is fitted along with the kernel (the table in ``_build_mean_model``).
         New and optional: ``device`` = GPU ordinal; ``quiet`` = a covariance that is not positive definite gives
-        -inf instead of ``LinAlgError`` (the reference raises, gpmodelling.py:152)."""
+        -inf instead of ``LinAlgError`` (the reference raises, gpmodelling.py:152); ``random_state`` = a
+        ``numpy.random.RandomState`` for the walkers' starting points and the device sampler's key instead of numpy's
+        global generator (the reference's and emcee's source; a private one lets two models be sampled from two threads
+        with the numbers ``np.random.seed`` would have given each); ``own_engine`` = a device context of this object's
+        own (``gp.release_engine()`` gives it back)."""
         self._lightcurve = lightcurve
         meanmodel, fit_mean = self._build_mean_model(mean_model)
-        self.gp = GP(kernel, mean=meanmodel, fit_mean=fit_mean, device=device)
+        self.gp = GP(kernel, mean=meanmodel, fit_mean=fit_mean, device=device, own_engine=own_engine)
+        self._random = random_state
         self.gp.compute(self._lightcurve.times, np.asarray(self._lightcurve.dy, dtype=np.float64) + 1e-12)
         self.initial_params = self.gp.get_parameter_vector()
         self._ndim = len(self.initial_params)
@@ -276,8 +281,9 @@ class GPModelling:
         model = self.gp._device_model()
         if not model.device_terms or model.mean_kind is None:
             raise ValueError("the device sampler needs device-expandable terms and a constant or linear mean")
+        seed = None if self._random is None else int(self._random.randint(0, 2 ** 62))   # (None: numpy's global generator)
         return DeviceEnsembleSampler(lambda: ev._bind(model), walkers, self._ndim, n_ensembles=1,
-                                     shard_group=shard_group)
+                                     shard_group=shard_group, seed=seed)
 
     def spread_walkers(self, walkers: int, parameters, bounds: List[Tuple[float, float]],
                        percent: float = 0.1, max_attempts: int = 20):
@@ -286,7 +292,8 @@ class GPModelling:
         reference)."""
         bounds = np.array([(-np.inf if lower is None else lower, np.inf if upper is None else upper)
                            for lower, upper in bounds], dtype=np.float64)
-        return _walkers.spread(np.random.normal, np.asarray(parameters, dtype=np.float64)[None, :], bounds[:, 0],
+        normal = np.random.normal if getattr(self, "_random", None) is None else self._random.normal
+        return _walkers.spread(normal, np.asarray(parameters, dtype=np.float64)[None, :], bounds[:, 0],
                                bounds[:, 1], walkers, percent=percent, max_attempts=max_attempts)[0]
 
     def standarized_residuals(self, include_noise: bool = True):

@@ -184,21 +184,27 @@ def batched_minimize(fun, x0, lower, upper, max_iter=60, history=8, fd_step=1e-6
         d = -np.where(blocked, 0.0, q)
         bad_dir = np.einsum("lp,lp->l", d, pg) >= 0                      # not a descent direction
         d[bad_dir] = -pg[bad_dir]
-        # backtracking (Armijo) on the projected path
-        step = np.ones(L)
+        # backtracking (Armijo) on the projected path: steps 1, 1/2, 1/4, ... (twenty of them), every problem takes
+        # the first that passes.  The steps are tried in THREE launches, not twenty -- 1; then 1/2, 1/4, 1/8 for whoever
+        # failed; then all the rest for the stubborn few -- because a round is a launch of a handful of rows (a
+        # latency, ~0.2 ms) and the stragglers of 250 light curves kept 13 rounds per iteration going: 715 of the 775
+        # launches of a fit.  Same trial points, same test, same choice as one step per round.
         x_new, f_new = x.copy(), f.copy()
         todo = active.copy()
-        for _ in range(20):
+        for ks in ((0,), (1, 2, 3), tuple(range(4, 20))):
             if not todo.any():
                 break
-            trial = np.clip(x[todo] + step[todo, None] * d[todo], lower, upper)
-            ft = fun(trial, lcs[todo])
-            ok = np.isfinite(ft) & (ft <= f[todo] + 1e-4 * np.einsum("lp,lp->l", pg[todo], trial - x[todo]))
             idx = np.flatnonzero(todo)
-            x_new[idx[ok]] = trial[ok]
-            f_new[idx[ok]] = ft[ok]
-            todo[idx[ok]] = False
-            step[todo] *= 0.5
+            steps = 0.5 ** np.asarray(ks, dtype=np.float64)
+            trial = np.clip(x[idx, None, :] + steps[None, :, None] * d[idx, None, :], lower, upper)      # [rows, steps, P]
+            ft = fun(trial.reshape(-1, P), np.repeat(lcs[idx], len(ks))).reshape(len(idx), len(ks))
+            ok = np.isfinite(ft) & (ft <= f[idx, None] + 1e-4 * np.einsum("lp,lkp->lk", pg[idx], trial - x[idx, None, :]))
+            passed = ok.any(axis=1)
+            first = np.argmax(ok, axis=1)                                 # the largest step that passes
+            rows = np.flatnonzero(passed)
+            x_new[idx[rows]] = trial[rows, first[rows]]
+            f_new[idx[rows]] = ft[rows, first[rows]]
+            todo[idx[rows]] = False
         active &= ~todo                                                   # line search failed: stop there
         f_old = f
         g_old = g
@@ -402,7 +408,8 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
 
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
                    sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
-                   sharded=False, group=None, concurrent_refits="auto", split="auto", reproducible=None):
+                   sharded=False, group=None, concurrent_refits="auto", split="auto", reproducible=None,
+                   observed_side_by_side=True):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -422,6 +429,10 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     where the two models' launches interleave and their tails and sampler kernels overlap (7.1 ms per iteration of both
     against 8.1 ms one after the other); with the GPU full (2000 x 128 rows) there is nothing to gain (26.30 s against
     26.36 s) and the refits run one after the other.
+
+    ``observed_side_by_side`` (default on; even walker counts): the observed light curve's two chains of step 1 from two
+    host threads, each model on a device context and a random generator of its own -- two single-light-curve chains
+    leave the GPU nearly empty; the chains are the ones that running them one after the other gives.
 
     ``sharded`` (inside a ``torch.distributed`` job, one process per GPU, every rank calling with the same
     arguments and its own ``device``; BASELINE configs[3]): steps 2 and 3 -- the loop over simulated light curves
@@ -448,15 +459,23 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     from .stats import lrt_pvalue, lrt_statistic
     rng = np.random.default_rng(seed)
 
-    def observed(kernel):
-        g = GPModelling(lightcurve, kernel, device=device)
+    seeds = [int(rng.integers(0, 2 ** 31 - 1)) for _ in range(2)]
+
+    def observed(kernel, seed, own_engine=False):
+        """The observed light curve's chain for one model, from a generator of its own (the stream np.random.seed(seed)
+        would give: nothing here touches numpy's global generator unless the walkers are odd -- the host-side sampler
+        copies the global state, as emcee does)."""
+        g = GPModelling(lightcurve, kernel, device=device, own_engine=own_engine,
+                        random_state=np.random.RandomState(seed) if walkers % 2 == 0 else None)
         state = np.random.get_state()
-        np.random.seed(int(rng.integers(0, 2 ** 31 - 1)))
+        if walkers % 2:
+            np.random.seed(seed)
         try:
             g.derive_posteriors(fit=True, max_steps=max_steps, walkers=walkers, progress=progress,
                                 device_sampler=walkers % 2 == 0)
         finally:
-            np.random.set_state(state)
+            if walkers % 2:
+                np.random.set_state(state)
         return g
 
     import time
@@ -468,7 +487,17 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     sim.warm_up()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        null, alt = observed(null_kernel), observed(alt_kernel)
+        if walkers % 2 == 0 and observed_side_by_side:
+            # two single-light-curve chains leave the GPU nearly empty: the two models side by side, each on a context
+            # and a generator of its own -- the same chains as one after the other
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                null, alt = pool.map(lambda a: observed(a[0], a[1], own_engine=("side", a[2])),
+                                     ((null_kernel, seeds[0], 0), (alt_kernel, seeds[1], 1)))
+            null.gp.release_engine()
+            alt.gp.release_engine()
+        else:
+            null, alt = observed(null_kernel, seeds[0]), observed(alt_kernel, seeds[1])
     clock.append(time.perf_counter())
     # one estimator on both sides of the test: the largest log-posterior over everything the chains
     # visited (the refits below store no chains and keep exactly that; the maximum over the burned-in,
@@ -523,7 +552,10 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
             kernel = (null_kernel, alt_kernel)[k]
             return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
                                            max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
-                                           store_chain=False, quiet=True, own_engine=((k, 2) if side_by_side == "slices" else bool(side_by_side)),
+                                           store_chain=False, quiet=True,
+                                           # side by side: model k on the process's k-th extra context (gp.get_side_engine)
+                                           own_engine=((k, 2) if side_by_side == "slices" else ("side", k) if side_by_side
+                                                       else False),
                                            index_base=lo if reproducible else None,
                                            before_sampling=(lambda: meet.wait(timeout=600)) if meet is not None else None)
 
