@@ -416,7 +416,9 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     bool pays;
     // (scripts/crossover_probe.py, serial sweep / time-parallel in ms: N = 1e4, J = 5: 3.4 / 0.35 at 1024 evaluations,
     // 3.4 / 1.0 at 4096, 3.4 / 1.8 at 8192, equal at 16 384; N = 1e3, J = 5: 0.36 / 0.29 at 4096, 0.36 / 0.51 at 8192)
-    if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= (ctx->N >= 4096 ? 8192 : 4096);
+    // (round 4, against the pipelined sweep that now takes over beyond: scripts/pipe_probe.py, N = 1e4, time-parallel / pipeline
+    // in ms: J = 3: 0.82 / 1.37 at 8192 rows, 1.20 / 1.39 at 12 288, 1.51 / 1.40 at 16 000; J = 5: 1.85 / 2.40 at 8192, 2.73 / 2.46 at 12 288)
+    if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= (ctx->N >= 4096 ? (Jmodel <= 3 ? 12288 : 8192) : 4096);
     else pays = ctx->N >= 1024 && Bw <= 8192;
     const bool small = ctx->tp_mode == 1 || ctx->tp_mode == 3 || (ctx->tp_mode == 2 && pays);
     sa.tp_ws = nullptr;
