@@ -604,10 +604,13 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
 
 def _split_by_model(split, nsims, walkers, world):
     """How protassov_test(sharded=True) divides the refits: by light curve (every rank refits both models on its block)
-    or by model (half of the ranks each).  A half-step of the serial sweep costs one wave's latency over the N samples
-    until a rank has about one wave per SIMD (65 536 rows), so with many ranks and few rows each, two half-steps of
-    both models one after the other take twice as long as one half-step of one model on twice the rows.  By model:
-    when asked for, or -- "auto" -- when the rows of a half-step per rank stay under that mark either way."""
+    or by model (half of the ranks each).  By light curve whenever a rank's half-step fits the pipelined sweep (at most
+    32 768 rows: one workgroup of 128 rows per compute unit): the two models' chains then run side by side on the rank
+    and its share of BASELINE configs[3] at 8 GPUs takes 3.8 s.  Beyond that a half-step of the
+    one-lane sweep costs one wave's latency over the N samples until a rank has about one wave per SIMD (65 536 rows),
+    so two half-steps of both models one after the other take twice as long as one half-step of one model on twice
+    the rows: by model, when asked for, or -- "auto" -- when the rows of a half-step per rank stay under that mark
+    either way (at 8 GPUs that share is ~4.2 s: the alternative's 64 000-row half-steps at 3.7 ms)."""
     if split == "models":
         if world < 2:
             raise ValueError("split='models' needs at least two ranks")
@@ -616,6 +619,9 @@ def _split_by_model(split, nsims, walkers, world):
         return False
     if split != "auto":
         raise ValueError("split must be 'auto', 'lightcurves' or 'models'")
+    rows_by_lightcurve = -(-nsims // world) * (walkers // 2)
+    if rows_by_lightcurve <= 32768:
+        return False
     rows_by_model = -(-nsims // (world // 2)) * (walkers // 2)
     return rows_by_model <= 70000
 
