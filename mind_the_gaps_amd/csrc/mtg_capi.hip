@@ -98,6 +98,7 @@ struct mtg_ctx {
     DevBuf ens_coords, ens_lnp, ens_perm, ens_q, ens_factor, ens_new, ens_st, ens_lc_full, ens_lc_half,
         ens_naccept, ens_best_lnp, ens_best_coords, ens_notpd, ens_chain, ens_lnp_chain;
     DevBuf ens_lc_spec;                 // light-curve index of the 3 E W/2 rows of a speculative iteration
+    DevBuf ens_perm_all;                // the splits of a whole speculative run, made before it ([steps][E][W])
     // walker sharding (mtg_ensemble_shard_*): this rank evaluates rows [shard_lo, shard_hi) of every
     // half-step's proposals; the exchange brings everybody's log-probabilities before the accept step
     int shard_kind = 0;  // 0 none, 1 RCCL all-gather on the stream, 2 host callback
@@ -669,7 +670,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     DevBuf *bufs[] = {&ctx->sort_keys, &ctx->sort_keys_out, &ctx->sort_order, &ctx->sort_tmp, &ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
                       &ctx->counts, &ctx->tp_ws, &ctx->sig, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
                       &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
-                      &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_lc_spec, &ctx->ens_naccept,
+                      &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_lc_spec, &ctx->ens_perm_all, &ctx->ens_naccept,
                       &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,
                       &ctx->ens_lnp_chain};
     for (DevBuf *b : bufs) b->release();
@@ -1420,10 +1421,24 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
             ctx->bank = bank_;
             return make_prep_args(ctx, rows3, ctx->ens_q.as<double>(), 1, ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>());
         };
+        // the splits of the whole run in one launch over the whole GPU, where they are small (an ensemble or a few): the
+        // sampler kernel of an iteration is one workgroup's chain of latencies and ranking W keys is 2-5 us of it
+        int32_t *perm_all = nullptr;
+        const size_t perm_bytes = (size_t)steps * EW * sizeof(int32_t);
+        if (perm_bytes <= ((size_t)64 << 20) && steps <= 65535) {
+            HIP_TRY(ctx, ctx->ens_perm_all.reserve(perm_bytes));
+            perm_all = ctx->ens_perm_all.as<int32_t>();
+            mtg_launch_split_all(g, ctx->ens_iteration, steps, perm_all, s);
+        }
+        g.perm_next = perm_all;   // (slice 0: the iteration the first launch proposes)
         mtg_launch_sampler_spec(g, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, ctx->ens_iteration, prep3(bank), s);
         for (int it = 0; it < steps; ++it) {
             const uint32_t iter = ctx->ens_iteration;
             ctx->bank = bank;
+            if (perm_all) {
+                g.perm = perm_all + (size_t)it * EW;                                   // this iteration's split, for the accept step
+                g.perm_next = it + 1 < steps ? perm_all + (size_t)(it + 1) * EW : nullptr;  // the next one's, for its proposals
+            }
             rc = solve_prepared(ctx, rows3, ctx->ens_lc_spec.as<int32_t>(), ctx->ens_new.as<double>(), ctx->ens_st.as<int32_t>(), s);
             if (rc) return rc;
             const bool more = it + 1 < steps;

@@ -166,6 +166,7 @@ struct MtgEnsembleArgs {
     uint32_t seed_lo, seed_hi;
     double a;             // stretch scale
     int32_t *perm;        // [E][W] red/blue split of the current iteration
+    const int32_t *perm_next = nullptr;   // [E][W] split of the iteration about to be proposed, made beforehand (or NULL: made in place)
     double *coords;       // [E][W][P]
     double *lnp;          // [E][W]
     double *factor;       // [E][W/2] (P - 1) ln z of the current proposals ([2][E][W/2] for a speculative iteration)
@@ -184,6 +185,8 @@ void mtg_launch_sampler_step(const MtgEnsembleArgs &g, int do_accept, int half, 
 void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t iteration, const double *new_lnp,
                              const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
                              uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t);
+// the splits of `steps` iterations from iteration0 on, perm_all[steps][E][W] (mtg_sampler.hip)
+void mtg_launch_split_all(const MtgEnsembleArgs &g, uint32_t iteration0, int steps, int32_t *perm_all, hipStream_t);
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
                              double *best_coords, hipStream_t);
 // TK95 light-curve simulation (mtg_simulate.hip)

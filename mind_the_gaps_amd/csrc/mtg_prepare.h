@@ -9,10 +9,16 @@
 
 #include <math.h>
 
-__device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e, bool live)
+// th_row: where this evaluation's theta row is to be READ from when it is not a.theta + e * P -- the sampler's
+// speculative kernel keeps the proposals it has just made in LDS as well (a global round trip per parameter, one after
+// the other through the term loop: 1.0-1.2 us of the 6-9 us the expansion takes in that kernel; the rest is the
+// arithmetic of ~8 exp, a sqrt and three divisions per row on the six waves that hold the rows)
+// (Not kept: the model's description read from a copy in LDS instead of the kernel arguments -- the expansion took as
+// long, and copying the description out of the argument segment with per-thread indices cost 27 us.)
+__device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e, bool live, const double *th_row = nullptr)
 {
     const MtgModel &m = a.model;
-    const double *th = a.theta + (live ? e : 0) * m.P;
+    const double *th = th_row ? th_row : a.theta + (live ? e : 0) * m.P;
     auto par = [&](int k) -> double {
         const int s = m.src[k];
         return s >= 0 ? th[s] : m.defaults[k];

@@ -65,24 +65,32 @@ enum { PURPOSE_SPLIT = 1, PURPOSE_PROPOSE = 2, PURPOSE_ACCEPT = 3 };
 // s_key: W 64-bit keys, then W ranks (int), in LDS.
 // The red/blue split of one iteration: a uniformly random permutation of 0..W-1 from ranked 64-bit Philox keys (see
 // mtg_propose_part); perm[e][0..W/2) is the first half.  Ends with a barrier: the permutation is readable.
-__device__ __forceinline__ void mtg_split_part(const MtgEnsembleArgs &g, uint32_t iteration, uint64_t *s_key)
+// The three steps of the split, callable apart (the speculative kernel runs the first two on its idle threads while the
+// first 256 take the accept step: the permutation of the coming iteration depends on nothing but its number).
+//   keys: one 64-bit Philox key per walker, ranks cleared            (all threads; barrier needed before the ranking)
+__device__ __forceinline__ void mtg_split_keys(const MtgEnsembleArgs &g, uint32_t iteration, uint64_t *s_key)
 {
     const int W = g.W;
     const int e = blockIdx.x;
-    int32_t *p = g.perm + (int64_t)e * W;
     int *s_rank = (int *)(s_key + W);
     for (int w = threadIdx.x; w < W; w += blockDim.x) {
         const Philox r = philox4x32_10(iteration, PURPOSE_SPLIT, (uint32_t)e + g.e_base, (uint32_t)w, g.seed_lo, g.seed_hi);
         s_key[w] = ((uint64_t)r.c[0] << 32) | r.c[1];
         s_rank[w] = 0;
     }
-    __syncthreads();
-    // rank of every key: W^2 comparisons spread over all the threads of the workgroup -- `parts` threads per
-    // walker, each counting over its share of the keys (one thread per walker and 512 serial comparisons were
-    // 12 us of the 25 us this kernel took at W = 256)
-    const int parts = blockDim.x >= (unsigned)W ? (int)blockDim.x / W : 1;
+}
+//   ranking: W^2 comparisons spread over threads [t0, t0 + nt) of the workgroup -- `parts` threads per walker, each
+//   counting over its share of the keys (one thread per walker and 512 serial comparisons were 12 us of the 25 us this
+//   kernel took at W = 256)                                          (barrier needed before the ranks are read)
+__device__ __forceinline__ void mtg_split_rank(const MtgEnsembleArgs &g, uint64_t *s_key, int t0, int nt)
+{
+    const int W = g.W;
+    int *s_rank = (int *)(s_key + W);
+    const int tid = (int)threadIdx.x - t0;
+    if (tid < 0 || tid >= nt) return;
+    const int parts = nt >= W ? nt / W : 1;
     const int span = (W + parts - 1) / parts;
-    for (int i = threadIdx.x; i < W * parts; i += blockDim.x) {
+    for (int i = tid; i < W * parts; i += nt) {
         const int w = i % W, part = i / W;
         const uint64_t mine = s_key[w];
         const int j0 = part * span, j1 = j0 + span < W ? j0 + span : W;
@@ -94,8 +102,23 @@ __device__ __forceinline__ void mtg_split_part(const MtgEnsembleArgs &g, uint32_
         if (parts > 1) atomicAdd(&s_rank[w], rank);
         else s_rank[w] = rank;
     }
-    __syncthreads();
+}
+//   the permutation itself                                            (barrier needed before it is read back)
+__device__ __forceinline__ void mtg_split_write(const MtgEnsembleArgs &g, uint64_t *s_key)
+{
+    const int W = g.W;
+    int32_t *p = g.perm + (int64_t)blockIdx.x * W;
+    const int *s_rank = (const int *)(s_key + W);
     for (int w = threadIdx.x; w < W; w += blockDim.x) p[s_rank[w]] = w;
+}
+
+__device__ __forceinline__ void mtg_split_part(const MtgEnsembleArgs &g, uint32_t iteration, uint64_t *s_key)
+{
+    mtg_split_keys(g, iteration, s_key);
+    __syncthreads();
+    mtg_split_rank(g, s_key, 0, (int)blockDim.x);
+    __syncthreads();
+    mtg_split_write(g, s_key);
     __syncthreads();  // the permutation is read back below (same workgroup: visible after the barrier)
 }
 
@@ -198,13 +221,28 @@ __device__ __forceinline__ void mtg_accept_part(const MtgEnsembleArgs &g, int ha
 // One solve and one launch of this kernel per iteration instead of two and two.  Same Philox counters as the
 // sequential form, hence the same chain to the last bit where the solver's arithmetic for a row does not depend on
 // the batch (tests/test_device_sampler_gpu.py compares the two).
-__device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint32_t iteration, const MtgPrepArgs &pa, uint64_t *s_key)
+// phase stamps of the speculative kernel (measurements only: -DMTG_SAMPLER_STAMPS prints, for iteration 100, the time
+// between the phase boundaries as thread 0 of workgroup 0 sees them, in 10 ns ticks of the constant-rate clock)
+#ifdef MTG_SAMPLER_STAMPS
+#define MTG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) mtg_stamps[k] = wall_clock64(); } while (0)
+__device__ unsigned long long mtg_stamps[16];
+#else
+#define MTG_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint32_t iteration, const MtgPrepArgs &pa, uint64_t *s_key,
+                                                 double *s_q)
 {
     const int W = g.W, P = g.P, H = W / 2;
     const int e = blockIdx.x;
     const int64_t EH = (int64_t)g.E * H;
-    const int32_t *p = g.perm + (int64_t)e * W;
-    mtg_split_part(g, iteration, s_key);
+    // the split of this iteration: made beforehand for the whole run where that is small (mtg_split_all_kernel: it depends
+    // on nothing but the iteration's number, and ranking W keys against each other is 2.3 (W = 128) to 5.0 us (W = 256) of
+    // ONE compute unit's time -- whatever the number of threads -- in a kernel that is nothing but latency), or made here
+    const int32_t *p = (g.perm_next ? g.perm_next : g.perm) + (int64_t)e * W;
+    MTG_STAMP(6);
+    if (!g.perm_next) mtg_split_part(g, iteration, s_key);
+    MTG_STAMP(7);
     double *q = const_cast<double *>(pa.theta);
     // the first half-step's proposals: one thread each
     for (int k = threadIdx.x; k < H; k += blockDim.x) {
@@ -217,11 +255,12 @@ __device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint3
         const int partner = p[H + (int)(u01(r.c[2], r.c[3]) * (double)H)];
         const double *s = g.coords + ((int64_t)e * W + w) * P;
         const double *c = g.coords + ((int64_t)e * W + partner) * P;
-        double *qo = q + i * P;
-        for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
+        double *qo = q + i * P, *ql = s_q + (int64_t)k * P;
+        for (int d = 0; d < P; ++d) { const double v = c[d] - (c[d] - s[d]) * z; qo[d] = v; ql[d] = v; }
         g.factor[i] = (double)(P - 1) * log(z);
     }
     __syncthreads();  // ... which other threads of this workgroup read as the partner's would-be place
+    MTG_STAMP(8);
     // the second half-step's two candidates: one thread per candidate
     for (int t = threadIdx.x; t < 2 * H; t += blockDim.x) {
         const int k = t % H, which = t / H;
@@ -233,18 +272,19 @@ __device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint3
         const int w = p[H + k];
         const int j = (int)(u01(r.c[2], r.c[3]) * (double)H);              // the partner's slot in the first half
         const double *s = g.coords + ((int64_t)e * W + w) * P;
-        const double *c = which ? q + ((int64_t)e * H + j) * P              // where its proposal would put it
+        const double *c = which ? s_q + (int64_t)j * P                      // where its proposal would put it (the LDS copy)
                                 : g.coords + ((int64_t)e * W + p[j]) * P;   // where it is
-        double *qo = q + ((which ? 2 * EH : EH) + i) * P;
-        for (int d = 0; d < P; ++d) qo[d] = c[d] - (c[d] - s[d]) * z;
+        double *qo = q + ((which ? 2 * EH : EH) + i) * P, *ql = s_q + ((int64_t)(1 + which) * H + k) * P;
+        for (int d = 0; d < P; ++d) { const double v = c[d] - (c[d] - s[d]) * z; qo[d] = v; ql[d] = v; }
         if (!which) g.factor[EH + i] = (double)(P - 1) * log(z);
     }
     __syncthreads();  // every row is expanded by the thread with its number, not by the one that wrote it
+    MTG_STAMP(9);
     for (int t0 = 0; t0 < 3 * H; t0 += blockDim.x) {  // uniform trip count: mtg_prepare_one votes per wave
         const int t = t0 + (int)threadIdx.x;
         const bool live = t < 3 * H;
         const int block = live ? t / H : 0, k = live ? t % H : 0;
-        mtg_prepare_one(pa, (int64_t)block * EH + (int64_t)e * H + k, live);
+        mtg_prepare_one(pa, (int64_t)block * EH + (int64_t)e * H + k, live, s_q + ((int64_t)block * H + k) * P);
     }
 }
 
@@ -287,6 +327,7 @@ __device__ __forceinline__ void mtg_accept_both(const MtgEnsembleArgs &g, uint32
                 }
             }
         __syncthreads();  // half 0: the accept flags; half 1: this workgroup's updates of the ensemble
+        MTG_STAMP(1 + half);
     }
     for (int off = 32; off > 0; off >>= 1) {
         const double ob = __shfl_down(my_best, off);
@@ -318,11 +359,23 @@ mtg_sampler_spec_kernel(MtgEnsembleArgs g, int do_accept, uint32_t iteration, co
     __shared__ double s_best[256];
     __shared__ int s_idx[256];
     int *s_acc = (int *)(s_key + g.W) + g.W;
+    // the 3 H proposals of the coming iteration, kept beside their global copy (mtg_prepare_one reads them from here)
+    double *s_q = (double *)(s_key + g.W + (3 * g.W / 2 + 1) / 2 + 1);
+    MTG_STAMP(0);
     if (do_accept) {
         mtg_accept_both(g, iteration, pa.theta, new_lnp, status, clear_counts, chain_row, lnp_chain_row, s_best, s_idx, s_acc);
         __syncthreads();
     }
-    if (do_propose) mtg_propose_both(g, next_iteration, pa, s_key);
+    MTG_STAMP(5);
+    if (do_propose) mtg_propose_both(g, next_iteration, pa, s_key, s_q);
+#ifdef MTG_SAMPLER_STAMPS
+    __syncthreads();
+    MTG_STAMP(10);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && iteration == 100)
+        printf("sampler stamps (10 ns ticks): accept0 %llu accept1 %llu best+chain %llu | split %llu propose1 %llu propose2 %llu expand %llu | total %llu\n",
+               mtg_stamps[1] - mtg_stamps[0], mtg_stamps[2] - mtg_stamps[1], mtg_stamps[5] - mtg_stamps[2], mtg_stamps[7] - mtg_stamps[6],
+               mtg_stamps[8] - mtg_stamps[7], mtg_stamps[9] - mtg_stamps[8], mtg_stamps[10] - mtg_stamps[9], mtg_stamps[10] - mtg_stamps[0]);
+#endif
 }
 
 // One kernel between two solves: the accept step of the half-step just evaluated, then -- do_propose -- the
@@ -375,6 +428,28 @@ void mtg_launch_sampler_step(const MtgEnsembleArgs &g, int do_accept, int half, 
                        next_iteration, pa);
 }
 
+// The red/blue splits of `steps` consecutive iterations, one workgroup per (ensemble, iteration): perm_all[s][e][W].
+__global__ void __launch_bounds__(1024)
+mtg_split_all_kernel(MtgEnsembleArgs g, uint32_t iteration0, int32_t *perm_all)
+{
+    extern __shared__ uint64_t s_key[];   // W keys, W ranks (int)
+    const uint32_t iteration = iteration0 + blockIdx.y;
+    mtg_split_keys(g, iteration, s_key);
+    __syncthreads();
+    mtg_split_rank(g, s_key, 0, (int)blockDim.x);
+    __syncthreads();
+    const int *s_rank = (const int *)(s_key + g.W);
+    int32_t *p = perm_all + ((int64_t)blockIdx.y * g.E + blockIdx.x) * g.W;
+    for (int w = threadIdx.x; w < g.W; w += blockDim.x) p[s_rank[w]] = w;
+}
+
+void mtg_launch_split_all(const MtgEnsembleArgs &g, uint32_t iteration0, int steps, int32_t *perm_all, hipStream_t s)
+{
+    const int threads = g.W > 64 ? 1024 : 256;
+    hipLaunchKernelGGL(mtg_split_all_kernel, dim3((unsigned)g.E, (unsigned)steps), dim3(threads),
+                       (size_t)g.W * (sizeof(uint64_t) + sizeof(int)), s, g, iteration0, perm_all);
+}
+
 void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t iteration, const double *new_lnp,
                              const int32_t *status, int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose,
                              uint32_t next_iteration, const MtgPrepArgs &pa, hipStream_t s)
@@ -384,7 +459,9 @@ void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t i
     // (measured, iterations/s with 256 / 1024 threads: W = 32 44.1e3 / 43.0e3, W = 128 18.2e3 / 19.0e3, W = 256 6.8e3 / 7.7e3)
     const int threads = do_propose && g.E <= 64 && g.W > 64 ? 1024 : 256;
     hipLaunchKernelGGL(mtg_sampler_spec_kernel, dim3((unsigned)g.E), dim3(threads),
-                       (size_t)g.W * (sizeof(uint64_t) + sizeof(int)) + (size_t)(g.W / 2) * sizeof(int), s, g, do_accept, iteration,
+                       // keys (8 W), ranks (4 W), accept flags (4 W/2), padding to 8 bytes, then 3 W/2 proposals of P doubles
+                       (size_t)(g.W + (3 * g.W / 2 + 1) / 2 + 1) * sizeof(uint64_t) + (size_t)(3 * (g.W / 2)) * g.P * sizeof(double), s,
+                       g, do_accept, iteration,
                        new_lnp, status, clear_counts, chain_row, lnp_chain_row, do_propose, next_iteration, pa);
 }
 
