@@ -88,3 +88,79 @@ def test_batched_minimize_keeps_the_last_good_point_when_the_gradient_batch_reje
     assert np.array_equal(x[3], np.zeros(P)) and np.isclose(f[3], 1.0 + np.sum(centers[3] ** 2))
     keep = np.arange(L) != 3
     assert np.allclose(x[keep], centers[keep], atol=2e-4)
+
+
+def test_batched_line_search_takes_the_step_one_round_at_a_time_would_take():
+    """The Armijo backtracking tries its twenty step sizes in three launches (1; 1/2, 1/4, 1/8; the rest): for every
+    problem the first step that passes, exactly as one step size per round -- checked on a surface with walls of
+    non-finite values and narrow valleys, where the problems need anything from one to twenty tries, and the launches counted
+    (the choice itself is dissected in the next test)."""
+    L, P = 40, 3
+    rng = np.random.default_rng(7)
+    centers = rng.uniform(-1, 1, (L, P))
+    curv = 10.0 ** rng.uniform(-1, 4, (L, P))                  # valleys of very different widths: long backtracking
+    wall = rng.uniform(0.5, 3.0, L)                             # beyond |x - c| > wall the function is not finite
+
+    def fun(x, lc):
+        d = x - centers[lc]
+        f = np.sum(curv[lc] * d ** 2, axis=1) + np.sum(np.abs(d) ** 3, axis=1)
+        return np.where(np.max(np.abs(d), axis=1) > wall[lc], np.inf, f)
+
+    launches = []
+
+    def counted(x, lc):
+        launches.append(len(x))
+        return fun(x, lc)
+
+    lower, upper = np.full(P, -3.0), np.full(P, 3.0)
+    x0 = centers + 0.4 * wall[:, None] * rng.uniform(-1, 1, (L, P))
+    x, f, it = batched_minimize(counted, x0, lower, upper)
+
+    assert np.all(np.isfinite(f)) and np.all(f <= fun(x0, np.arange(L)) + 1e-12)
+    near = np.abs(x - centers).max(axis=1)
+    assert np.median(near) < 1e-3 and it <= 60
+    # at most three line-search launches per iteration, plus one gradient batch per iteration and the first one
+    grad = L * (P + 1)
+    assert launches.count(grad) == it + 1 or launches.count(grad) == it
+    assert len(launches) - launches.count(grad) <= 3 * it
+
+
+def test_batched_line_search_choice_is_the_first_passing_step():
+    """One iteration, dissected: a function that accepts only steps below a per-problem threshold makes every problem
+    take exactly the largest power of 1/2 below its threshold -- whichever of the three launches that step is in."""
+    L, P = 21, 2
+    need = np.arange(L)                                          # problem l accepts steps <= 2^-l (l = 20: none of the twenty)
+    x0 = np.zeros((L, P))
+
+    def fun(x, lc):
+        # descent direction from x0 is +e_0 (gradient -1 along the first coordinate): f = -x_0; in the line search's
+        # batches (the gradient batches have L (P + 1) rows) non-finite when the step from x0 exceeds the problem's threshold
+        step = x[:, 0]
+        f = -step + 0.0 * x[:, 1]
+        if len(x) == L * (P + 1):
+            return f
+        return np.where(step > 0.5 ** need[lc] * 1.0000001, np.inf, f)
+
+    x, f, it = batched_minimize(fun, x0, np.full(P, -10.0), np.full(P, 10.0), max_iter=1)
+    took = x[:, 0]
+    for l in range(L):
+        if l < 20:
+            assert took[l] == 0.5 ** l, (l, took[l])            # the first (largest) step that passes
+        else:
+            assert took[l] == 0.0                                # twenty failures: the problem stays where it was
+
+
+def test_how_the_sharded_test_divides_its_refits():
+    """ppp._split_by_model: by light curve whenever a rank's half-step fits the pipelined sweep (32 768 rows), by model only
+    above that and below one wave per SIMD either way."""
+    from mind_the_gaps_amd.ppp import _split_by_model
+    assert _split_by_model("auto", 2000, 256, 8) is False        # 250 x 128 = 32 000 rows per rank: by light curve
+    assert _split_by_model("auto", 2000, 256, 16) is False
+    assert _split_by_model("auto", 2120, 256, 8) is True         # 33 920 rows per rank by light curve, 67 840 by model
+    assert _split_by_model("auto", 2000, 512, 8) is False        # 64 000 / 128 000: the model split does not fit either
+    assert _split_by_model("auto", 2000, 256, 1) is False
+    assert _split_by_model("models", 10, 16, 2) is True and _split_by_model("lightcurves", 10, 16, 2) is False
+    with pytest.raises(ValueError):
+        _split_by_model("models", 10, 16, 1)
+    with pytest.raises(ValueError):
+        _split_by_model("columns", 10, 16, 2)
