@@ -1,5 +1,7 @@
+"""Where the starting fit of a block of light curves goes (ppp.batched_minimize through derive_posteriors_batch, 250 light
+curves, alternative model, N = 1e4): launches by batch size, wall and kernel time.  python scripts/fit_probe.py"""
 import os, sys, time, warnings
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mind_the_gaps_amd import synthetic as synth, terms, ppp
 from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
