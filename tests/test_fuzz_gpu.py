@@ -95,3 +95,64 @@ def test_random_model_vs_oracle(engine, case):
     if ok.any():
         err = np.max(np.abs(out[ok] - ref[ok]) / np.abs(ref[ok]))
         assert err <= 1e-8, "%s: %.3g" % (label, err)
+
+
+@pytest.mark.parametrize("case", range(60))
+def test_random_model_pipeline_against_the_one_lane_sweep(engine, case):
+    """The same kind of sweep for the two-wave pipelined form of the serial sweep (mtg_set_pipeline(1): whenever the model
+    has the kernel): random models of rank 3-6 with one or two complex terms, light-curve lengths on all sides of the
+    four-sample hand-over and the twelve-sample trip, shared and per-light-curve sampling, fitted linear mean, prior on /
+    off, rejected rows, both SHO regimes -- bit for bit the one-lane sweep's values and statuses."""
+    case = case + OFFSET
+    rng = np.random.default_rng(77000 + case)
+    while True:
+        kinds = random_model(rng, 6, 2)
+        nr = sum(1 for k in kinds if RANK.get(k, 2) == 1)
+        nc = sum(1 for k in kinds if RANK.get(k, 2) == 2)
+        # the Lorentzian's null real term is dropped, so the rank of arithmetic is nr + 2 nc as counted here
+        if nc >= 1 and 3 <= nr + 2 * nc <= 6 and kinds.count(synth.K_SHO) <= 2:
+            break
+    linear_mean = bool(rng.integers(0, 3) == 0)
+    N = int(rng.choice([64, 65, 66, 67, 75, 76, 77, 100, 333, 1000, 1201, 4099]))
+    L = int(rng.integers(1, 6))
+    B = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 500, 1300]))
+    per_lc_t = bool(rng.integers(0, 2)) and L > 1
+    add_prior = bool(rng.integers(0, 2))
+    t, y, dy = synth.make_lightcurves(N, L, seed=2000 + case)
+    if per_lc_t:
+        t = np.vstack([synth.make_times(N, rng, offset=float(10 * i)) for i in range(L)])
+    if linear_mean:
+        y = y + 0.01 * (t - t.min())
+        full, free, bounds = synth.model_spec(kinds, y, mean_kind=1, fit_mean=True)
+        y_mean = None
+    else:
+        full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+        y_mean = y.mean(axis=1)
+    theta = synth.draw_thetas(kinds, B, seed=case, percent=0.25)
+    off = 0
+    for k in kinds:
+        if k == synth.K_SHO:
+            theta[rng.random(B) < 0.4, off + 1] = np.log(rng.uniform(0.05, 0.45))
+        off += synth.NPARAMS[k]
+    theta[rng.random(B) < 0.1, 0] = 60.0
+    lc = rng.integers(0, L, B).astype(np.int32)
+    if linear_mean:
+        theta = np.hstack([theta, 0.01 + 0.002 * rng.standard_normal((B, 1)), 100.0 + rng.standard_normal((B, 1))])
+    engine.set_lightcurves(t, y, dy + 1e-12, y_offset=y_mean)
+    engine.set_model(kinds, full, free, bounds, mean_kind=1 if linear_mean else 0)
+    label = "kinds=%s N=%d L=%d B=%d per_lc_t=%s prior=%s linear_mean=%s" % (kinds, N, L, B, per_lc_t, add_prior, linear_mean)
+    try:
+        engine.set_time_parallel(0)
+        engine.set_pipeline(0)
+        want, wst = engine.loglike(theta, lc, add_prior=add_prior)
+        assert "mtg_pipe" not in engine.last_solver
+        engine.set_pipeline(1)
+        got, gst = engine.loglike(theta, lc, add_prior=add_prior)
+        used = engine.last_solver
+    finally:
+        engine.set_time_parallel(2)
+        engine.set_pipeline(2)
+    if "mtg_pipe_kernel" not in used:        # (a model outside the compiled shapes -- three structures of rank > 6, ...: skipped)
+        pytest.skip("no pipeline for %s (%s)" % (kinds, used))
+    assert np.array_equal(gst, wst), label
+    assert np.array_equal(got, want), label                  # NaN-free by construction: -inf where rejected
