@@ -550,14 +550,19 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
 
         def refit(k):
             kernel = (null_kernel, alt_kernel)[k]
-            return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
-                                           max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
-                                           store_chain=False, quiet=True,
-                                           # side by side: model k on the process's k-th extra context (gp.get_side_engine)
-                                           own_engine=((k, 2) if side_by_side == "slices" else ("side", k) if side_by_side
-                                                       else False),
-                                           index_base=lo if reproducible else None,
-                                           before_sampling=(lambda: meet.wait(timeout=600)) if meet is not None else None)
+            try:
+                return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
+                                               max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
+                                               store_chain=False, quiet=True,
+                                               # side by side: model k on the process's k-th extra context (gp.get_side_engine)
+                                               own_engine=((k, 2) if side_by_side == "slices" else ("side", k) if side_by_side
+                                                           else False),
+                                               index_base=lo if reproducible else None,
+                                               before_sampling=(lambda: meet.wait(timeout=600)) if meet is not None else None)
+            except BaseException:
+                if meet is not None:
+                    meet.abort()        # the partner thread must not wait at the barrier for a refit that has failed
+                raise
 
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -565,7 +570,8 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                 # The two models' refits are independent: each on its own context and stream, driven by its own host
                 # thread (the library calls release the GIL).  Measured at configs[3]'s sizes: 26.30 s side by side
                 # against 8.40 + 17.96 s one after the other -- both sweeps are bound by FP64 issue and a half-step
-                # leaves no idle issue slots for the other model to fill.  Kept as an option, off by default.
+                # leaves no idle issue slots for the other model to fill; on a block that leaves the GPU room (a rank's
+                # 250 light curves at 8 GPUs) the two chains interleave and gain 16 %: "auto" (docstring).
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=2) as pool:
                     fits = list(pool.map(refit, (0, 1)))
