@@ -239,6 +239,8 @@ MTG_API int mtg_set_pipeline(mtg_ctx *ctx, int mode);
  * samples: <= 512 rows up to rank 5, <= 256 at rank 6; <= 1024 rows below), J <= 6, not walker-sharded.  The random numbers, hence the chain, are those of
  * the sequential form -- to the last bit where both forms run the same kernel (the batch size picks it: e.g. rank 5,
  * 256 walkers: four waves per evaluation for the 128 rows of a half-step, two for the 384 of a speculative iteration).
+ * Mode 2 is mode 1 with every iteration's split ranked inside its sampler launch instead of all of a run's splits in
+ * one launch up front (what mode 1 itself does once steps * E * W * 4 bytes pass 64 MiB): same chain, bit for bit.
  */
 MTG_API int mtg_set_speculation(mtg_ctx *ctx, int mode);
 /* Name of the kernel the last batch was dispatched to, e.g. "mtg_solve_kernel<1,2,1>" (first structure of the

@@ -142,7 +142,7 @@ struct mtg_ctx {
     // order of the serial sweep (mtg_sort.hip): 0 the caller's order, 1 always sorted by (structure, light curve),
     // 2 sorted unless the caller's order is known to be grouped already (host entry points look at lc_index)
     int sort_mode = 2;
-    int spec_mode = 1;                  // speculative iterations of small ensembles: 0 never, 1 where they pay (mtg_ensemble_run)
+    int spec_mode = 1;                  // speculative iterations of small ensembles: 0 never, 1 where they pay, 2 = 1 without the splits up front (mtg_ensemble_run)
     int lc_grouped_hint = 0;   // set by the host-pointer entry points for the call in flight
     DevBuf sort_keys, sort_keys_out, sort_order, sort_tmp;
     char last_solver[96] = "";   // what the last solve dispatched (mtg_last_solver)
@@ -1425,7 +1425,7 @@ MTG_API int mtg_ensemble_run(mtg_ctx *ctx, int steps, double *chain, double *lnp
         // sampler kernel of an iteration is one workgroup's chain of latencies and ranking W keys is 2-5 us of it
         int32_t *perm_all = nullptr;
         const size_t perm_bytes = (size_t)steps * EW * sizeof(int32_t);
-        if (perm_bytes <= ((size_t)64 << 20) && steps <= 65535) {
+        if (perm_bytes <= ((size_t)64 << 20) && steps <= 65535 && ctx->spec_mode != 2) {
             HIP_TRY(ctx, ctx->ens_perm_all.reserve(perm_bytes));
             perm_all = ctx->ens_perm_all.as<int32_t>();
             mtg_launch_split_all(g, ctx->ens_iteration, steps, perm_all, s);
@@ -1987,7 +1987,8 @@ MTG_API int mtg_set_tp_direct(mtg_ctx *ctx, int enabled)
 MTG_API int mtg_set_speculation(mtg_ctx *ctx, int mode)
 {
     if (!ctx) return MTG_E_ARG;
-    if (mode < 0 || mode > 1) return fail(ctx, MTG_E_ARG, "mtg_set_speculation: mode must be 0 (never) or 1 (where it pays)");
+    if (mode < 0 || mode > 2)
+        return fail(ctx, MTG_E_ARG, "mtg_set_speculation: mode must be 0 (never), 1 (where it pays) or 2 (as 1, splits ranked in the sampler kernel)");
     ctx->spec_mode = mode;
     return MTG_OK;
 }

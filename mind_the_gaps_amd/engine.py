@@ -712,7 +712,8 @@ class Engine:
 
     def set_speculation(self, mode):
         """0: every half-step of the device sampler gets its own solve; 1 (default): both half-steps of an iteration
-        in one batch where the GPU would otherwise idle (include/mtg.h: mtg_set_speculation)."""
+        in one batch where the GPU would otherwise idle; 2: as 1, with each iteration's split ranked inside its sampler
+        launch (the form long runs fall back to; same chain) (include/mtg.h: mtg_set_speculation)."""
         self._check(self._lib.mtg_set_speculation(self._ctx, int(mode)))
 
     def set_sort(self, mode):

@@ -195,7 +195,7 @@ def test_speculative_iterations_give_the_sequential_chain(engine, case):
         p0[:, ::3, 3] = np.log(0.3)                                  # some walkers start over-damped: two structures
     results = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):      # 2: speculative with each split ranked in its sampler launch (long runs' fallback)
             engine.set_speculation(mode)
             engine.ensemble_init(p0, seed=seed)
             chain, lnp_chain = engine.ensemble_run(steps, store_chain=True)
@@ -204,10 +204,11 @@ def test_speculative_iterations_give_the_sequential_chain(engine, case):
     finally:
         engine.set_speculation(1)
     a, b = results[0], results[1]
-    for x, y in zip(a[:4], b[:4]):
-        assert np.array_equal(x, y)
-    for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
-        assert np.array_equal(a[4][key], b[4][key]), key
+    for other in (results[1], results[2]):
+        for x, y in zip(a[:4], other[:4]):
+            assert np.array_equal(x, y)
+        for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
+            assert np.array_equal(a[4][key], other[4][key]), key
     assert a[4]["iteration"] == b[4]["iteration"] == steps + 7 and a[4]["n_not_pd"] == b[4]["n_not_pd"]
     assert 0.1 < a[4]["naccept"].mean() / (steps + 7) < 0.9
     if case == "drw_n1000_w32":                                   # and it is the chain the host replay makes
@@ -281,6 +282,30 @@ def test_speculative_and_sequential_forms_at_the_shipped_shapes(engine, case):
     assert np.array_equal(c0, c1)                                     # same decisions => the very same coordinates
     assert np.max(np.abs(l0 - l1) / np.abs(l0)) < 1e-12, (k0, k1)
     assert np.allclose(s0["best_log_prob"], s1["best_log_prob"], rtol=1e-12) and s0["iteration"] == s1["iteration"] == steps
+
+
+@pytest.mark.parametrize("case", sorted(SHIPPED))
+def test_splits_ranked_up_front_or_inside_the_sampler_launch(engine, case):
+    """The default run ranks every iteration's split in one launch before the first iteration; a run too long for that
+    (steps * E * W * 4 bytes > 64 MiB) ranks each split inside its sampler launch (mtg_set_speculation mode 2 forces
+    it).  Same counters, same kernels for the likelihood: the same chain to the last bit, also across a continuation."""
+    kinds, W, rows, p0, lnp0, oracle_lnp = _shipped_problem(engine, case, overdamped=case == "configs2_alt_w256")
+    steps, seed = 25, 0x5EED5EED
+    out = {}
+    try:
+        for mode in (1, 2):
+            engine.set_speculation(mode)
+            engine.ensemble_init(p0, seed=seed)
+            chain, lnp_chain = engine.ensemble_run(steps, store_chain=True)
+            more, more_lnp = engine.ensemble_run(5, store_chain=True)
+            out[mode] = (chain, lnp_chain, more, more_lnp, engine.ensemble_state())
+    finally:
+        engine.set_speculation(1)
+    for x, y in zip(out[1][:4], out[2][:4]):
+        assert np.array_equal(x, y)
+    for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
+        assert np.array_equal(out[1][4][key], out[2][4][key]), key
+    assert out[1][4]["iteration"] == out[2][4]["iteration"] == steps + 5
 
 
 def test_speculative_sampler_with_two_structures_in_a_384_row_batch(engine):
