@@ -287,14 +287,16 @@ class GPModelling:
 
     def spread_walkers(self, walkers: int, parameters, bounds: List[Tuple[float, float]],
                        percent: float = 0.1, max_attempts: int = 20):
-        """Spread the walkers with a Gaussian around ``parameters`` (gpmodelling.py:289-350;
-        the law is in ``walkers.spread``, draws from numpy's global generator like the
-        reference)."""
+        """Spread the walkers with a Gaussian around ``parameters`` (gpmodelling.py:289-350).
+        Draws from numpy's global generator in the reference's order (walker by walker,
+        ``walkers.spread_reference_order``): after ``np.random.seed(k)`` the array returned is
+        the reference's, value for value (tests/golden/spread_golden.npz, made by the
+        reference's function; tests/test_spread_golden.py)."""
         bounds = np.array([(-np.inf if lower is None else lower, np.inf if upper is None else upper)
                            for lower, upper in bounds], dtype=np.float64)
         normal = np.random.normal if getattr(self, "_random", None) is None else self._random.normal
-        return _walkers.spread(normal, np.asarray(parameters, dtype=np.float64)[None, :], bounds[:, 0],
-                               bounds[:, 1], walkers, percent=percent, max_attempts=max_attempts)[0]
+        return _walkers.spread_reference_order(normal, np.asarray(parameters, dtype=np.float64), bounds[:, 0],
+                                               bounds[:, 1], walkers, percent=percent, max_attempts=max_attempts)
 
     def standarized_residuals(self, include_noise: bool = True):
         """Standardised residuals (gpmodelling.py:353-370) need ``GP.predict`` -- outside
