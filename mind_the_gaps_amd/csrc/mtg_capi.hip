@@ -124,10 +124,9 @@ struct mtg_ctx {
     // of BASELINE configs[3] takes 0.9 s to build, as long as the 2000 simulations it then runs) and its buffers.
     // mtg_simulate_plan may build it from a helper thread while the context is busy elsewhere: sim_mu.
     std::mutex sim_mu;
-    hipfftHandle sim_plan = 0;
-    bool sim_have_plan = false;
-    int64_t sim_nfft = 0;
-    int sim_batch = 0;
+    // C2R plans of the simulator: [0] the bulk plan (sim_batch_for's batch for the length), [1] a short call's (fewer
+    // series than that batch: a single light curve runs ONE transform); each remade when its (length, batch) changes
+    struct SimPlan { hipfftHandle h = 0; bool have = false; int64_t nfft = 0; int batch = 0; } sim_plans[2];
     DevBuf sim_spec, sim_series;
 
     // side streams: the structures (signatures) of a small batch run next to each other
@@ -494,8 +493,8 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     if (small_ok && Jmodel > 6) {  // rank 10: every structure in one sequence of launches (mtg_tp_big.h)
         sa.list = nullptr;
         sa.count_ptr = nullptr;
-        snprintf(ctx->last_solver, sizeof ctx->last_solver, "%s (+ mtg_tpb_reduce_kernel<10>, C = %d)",
-                 mtg_tpb_compose_waves() == 2 ? "mtg_tpb_compose2_kernel" : mtg_tpb_compose_waves() == 8 ? "mtg_tpb_compose4_kernel" : "mtg_tpb_compose4q_kernel", sa.tp_chunks);
+        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tpb_compose4q_kernel (+ mtg_tpb_reduce_kernel<10>, C = %d)",
+                 sa.tp_chunks);
         mtg_launch_tp_big(sa, B, s);
     } else if (fused) {  // every signature in one launch
         sa.list = bank_lists(ctx);
@@ -678,7 +677,8 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     {
         std::lock_guard<std::mutex> plans(g_fft_plan_mu);
         if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
-        if (ctx->sim_have_plan) (void)hipfftDestroy(ctx->sim_plan);
+        for (auto &sp : ctx->sim_plans)
+            if (sp.have) (void)hipfftDestroy(sp.h);
     }
     ctx->sim_spec.release();
     ctx->sim_series.release();
@@ -1595,32 +1595,37 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
     return MTG_OK;
 }
 
-// transforms per execution of the simulator's plan: a function of the length alone, so that one plan serves every
-// call (16 transforms of 10^6 points fill the GPU; short transforms are batched by the hundred) -- as long as the
-// spectrum and series buffers of one execution, 16 nk + 8 nfft bytes per transform, stay within 2 GiB: a series of
-// 2^30 points (the longest mtg_simulate_plan accepts) is transformed one at a time
-static int sim_batch_for(int64_t nfft)
+// transforms per execution of the simulator's plan: for a full call a function of the length alone, so that one plan
+// serves every such call (16 transforms of 10^6 points fill the GPU; short transforms are batched by the hundred) -- as
+// long as the spectrum and series buffers of one execution, 16 nk + 8 nfft bytes per transform, stay within 2 GiB: a
+// series of 2^30 points (the longest mtg_simulate_plan accepts) is transformed one at a time.  A call of fewer series
+// than that (S: Simulator.generate_lightcurve() asks for ONE) gets a batch of S
+static int sim_batch_for(int64_t nfft, int64_t S = INT64_MAX)
 {
     int64_t b = ((int64_t)1 << 24) / nfft;
     b = b < 16 ? 16 : b > 256 ? 256 : b;
     const int64_t fit = ((int64_t)1 << 31) / (16 * (nfft / 2 + 1) + 8 * nfft);
     if (b > fit) b = fit;
+    if (b > S) b = S;   // fewer series than a full batch: no transforms of empty slots
     return (int)(b < 1 ? 1 : b);
 }
 
-// the context's C2R plan of length nfft (made, or remade for another length, under sim_mu); no fail(): may run on a
-// helper thread
-static int sim_plan_get(mtg_ctx *ctx, int64_t nfft)
+// the context's C2R plan of length nfft for a call of S series (made, or remade for another length or batch, under
+// sim_mu); no fail(): may run on a helper thread
+static int sim_plan_get(mtg_ctx *ctx, int64_t nfft, int64_t S, hipfftHandle *plan)
 {
     std::lock_guard<std::mutex> lock(ctx->sim_mu);
-    if (ctx->sim_have_plan && ctx->sim_nfft == nfft) return MTG_OK;
-    std::lock_guard<std::mutex> plans(g_fft_plan_mu);
-    if (ctx->sim_have_plan) { (void)hipfftDestroy(ctx->sim_plan); ctx->sim_have_plan = false; }
-    const int batch = sim_batch_for(nfft);
-    if (hipfftPlan1d(&ctx->sim_plan, (int)nfft, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS) return MTG_E_HIP;
-    ctx->sim_have_plan = true;
-    ctx->sim_nfft = nfft;
-    ctx->sim_batch = batch;
+    const int batch = sim_batch_for(nfft, S);
+    mtg_ctx::SimPlan &sp = ctx->sim_plans[batch == sim_batch_for(nfft) ? 0 : 1];
+    if (!(sp.have && sp.nfft == nfft && sp.batch == batch)) {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
+        if (sp.have) { (void)hipfftDestroy(sp.h); sp.have = false; }
+        if (hipfftPlan1d(&sp.h, (int)nfft, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS) return MTG_E_HIP;
+        sp.have = true;
+        sp.nfft = nfft;
+        sp.batch = batch;
+    }
+    if (plan) *plan = sp.h;
     return MTG_OK;
 }
 
@@ -1628,7 +1633,7 @@ MTG_API int mtg_simulate_plan(mtg_ctx *ctx, int64_t nfft)
 {
     if (!ctx || nfft < 4 || nfft > ((int64_t)1 << 30)) return MTG_E_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return MTG_E_HIP;   // (HIP's current device is per thread)
-    return sim_plan_get(ctx, nfft);
+    return sim_plan_get(ctx, nfft, INT64_MAX, nullptr);   // the bulk plan
 }
 
 MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, const double *psd_table, int64_t psd_rows,
@@ -1668,7 +1673,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     const int64_t nk = nfft / 2 + 1;
     // the simulations go through the context's plan `chunk` at a time (the last group may be short: the transforms of
     // the unused slots run on whatever the buffer holds and are not looked at)
-    const int64_t chunk = sim_batch_for(nfft);
+    const int64_t chunk = sim_batch_for(nfft, S);
     DevBuf &spec = ctx->sim_spec, &series = ctx->sim_series;
     DevBuf d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means, d_psd, d_seg;
     hipError_t e = hipSuccess;
@@ -1710,12 +1715,11 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     hipfftHandle plan = 0;
     if (e == hipSuccess) {
         what = "hipfftPlan1d";
-        if (sim_plan_get(ctx, nfft) != MTG_OK || hipfftSetStream(ctx->sim_plan, s) != HIPFFT_SUCCESS) {
+        if (sim_plan_get(ctx, nfft, S, &plan) != MTG_OK || hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
             cleanup();
             return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipFFT plan creation failed (nfft = %lld, batch = %lld)",
                         (long long)nfft, (long long)chunk);
         }
-        plan = ctx->sim_plan;
     }
     // irfft normalisation (hipFFT C2R is unnormalised) and the reference's power scaling
     const double scale = sqrt((double)nfft * sim_dt * sqrt(2.0 * M_PI)) / (double)nfft;

@@ -7,9 +7,9 @@
 // launch whatever the batch.  Here the passes are separate kernels, each with the geometry that suits
 // it, none with scratch memory, and the number of chunks follows the batch so that 32 evaluations fill
 // the GPU as well as 256 do (mtg_tp_big_chunks):
-//   compose  mtg_tpb_compose2_kernel<NR, NC>: the element of every chunk by the filter-from-zero
-//            recursion, TWO waves per 64 chunks (one keeps A, the other Dv, b, eta, Jm; see below); also
-//            the chunk's likelihood given x_in = 0 (kappa);
+//   compose  mtg_tpb_compose4q_kernel: the element of every chunk by the filter-from-zero recursion, FOUR
+//            waves per 64 chunks (two keep A's columns, two the symmetric matrices Dv and Jm; see below);
+//            also the chunk's likelihood given x_in = 0 (kappa);
 //   up-sweep mtg_tp_scan.h: combinations level by level down to four elements per evaluation, each J x J
 //            operation spread over 16 lanes with the operands in LDS -- no lane holds a matrix; the
 //            likelihood records (kappa and the combinations' contributions) travel along;
@@ -206,230 +206,14 @@ __device__ __forceinline__ double2 tpb_sample(const double2 *base, uint32_t byte
 }
 
 // ---------------------------------------------------------------------------------------------
-// Composition by TWO waves per 64 chunks (mtg_tpb_compose2_kernel).
+// Composition by FOUR waves per 64 chunks (mtg_tpb_compose4q_kernel).
 //
-// One lane per chunk holds the whole element in the unified register file only with A in the
-// accumulation half of it: a third of the single-wave kernel's vector instructions are v_accvgpr
-// copies (480 of 1420 per step, rocprofv3 SQ_INSTS_VALU).  Here the element of a chunk is shared by
-// the same lane of two waves, each of which keeps its part in directly addressable registers:
-//   wave 0 ("columns"):  A (100 doubles); per interval: transition of a step (exp / sincos) and the
-//                        update of A's ten columns with the gain of an earlier step;
-//   wave 1 ("filter"):   Dv, b, eta, Jm (130 doubles); per interval: the filter-from-zero step on
-//                        (b, Dv) that yields the gain, and eta += g z/D, Jm += g g^T/D of an earlier step.
-// They meet in three small LDS rings (entry-major, [..][lane]) and one workgroup barrier per interval;
-// the work is software pipelined so that nobody waits inside an interval.  In interval k
-//   wave 0 writes F(k),            reads F(k-2), ch(k-2), writes g(k-2)
-//   wave 1 reads F(k-1), writes ch(k-1) [ch = D kd, 1/D, z/D],   reads g(k-3)
-// so F lives three intervals (3 slots), ch and g two (2 slots each).  Chunks are `per` steps long; a lane
-// whose chunk is shorter (the end of the light curve) runs the remaining steps as no-ops: dx = 0 makes
-// the transition the identity exactly, and a measurement variance of 1e300 makes the gain vanish below
-// rounding.
-template <int J> struct TpbRing {
-    double F[3][J][64];
-    double ch[2][J + 2][64];
-    double g[2][J][64];
-};
-
-// wave 0
-template <int NR, int NC, class Tab>
-__device__ __forceinline__ void tpb2_columns(const MtgSolveArgs &a, const TpModel<NR, NC> &M, int64_t lc, const Tab *tab, bool fast,
-                                             TpbRing<NR + 2 * NC> &ring, double *slot, uint32_t lo, uint32_t hi, uint32_t per)
-{
-    constexpr int J = NR + 2 * NC;
-    const int lane = threadIdx.x & 63;
-    const double2 *dxt = a.dxt + lc * a.t_stride;
-    double A[J][J];
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) A[i][j] = i == j ? 1.0 : 0.0;
-    const uint32_t last = ((uint32_t)a.N - 1u) * 16u;
-    uint32_t off = lo * 16u;
-    double dxn = tpb_sample(dxt, off < last ? off : last).x;
-    for (uint32_t k = 0; k < per + 3u; ++k) {
-        if (k < per) {
-            const double dx = off < hi * 16u ? dxn : 0.0;
-            off += 16u;
-            dxn = tpb_sample(dxt, off < last ? off : last).x;
-            TpTrans<NR, NC> T;
-            tpb_transition<NR, NC>(M, dx, T, tab, fast);
-            double(*F)[64] = ring.F[k % 3u];
-#pragma unroll
-            for (int j = 0; j < NR; ++j) F[j][lane] = T.phi[j];
-#pragma unroll
-            for (int q = 0; q < NC; ++q) { F[NR + 2 * q][lane] = T.ec[q]; F[NR + 2 * q + 1][lane] = T.es[q]; }
-        }
-        if (k >= 2u && k < per + 2u) {
-            const uint32_t s = k - 2u;
-            const double(*F)[64] = ring.F[s % 3u];
-            const double(*G)[64] = ring.ch[s & 1u];
-            TpTrans<NR, NC> T;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) T.phi[j] = F[j][lane];
-#pragma unroll
-            for (int q = 0; q < NC; ++q) { T.ec[q] = F[NR + 2 * q][lane]; T.es[q] = F[NR + 2 * q + 1][lane]; }
-            double ch[J];
-#pragma unroll
-            for (int i = 0; i < J; ++i) ch[i] = G[i][lane];
-            const double inv = G[J][lane];
-            double(*gout)[64] = ring.g[s & 1u];
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                double col[J];
-#pragma unroll
-                for (int i = 0; i < J; ++i) col[i] = A[i][j];
-                tp_apply_F<NR, NC>(T, col);
-                const double gj = tp_h_dot<NR, NC>(col);
-                const double gs = gj * inv;
-#pragma unroll
-                for (int i = 0; i < J; ++i) A[i][j] = fma(-ch[i], gs, col[i]);
-                gout[j][lane] = gj;
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) slot[i * J + j] = A[i][j];
-}
-
-// wave 1
-template <int NR, int NC>
-__device__ __forceinline__ void tpb2_filter(const MtgSolveArgs &a, const TpModel<NR, NC> &M, double jitter, double slope, double icpt,
-                                            int64_t lc, TpbRing<NR + 2 * NC> &ring, double *slot, double *part, uint32_t lo,
-                                            uint32_t hi, uint32_t per)
-{
-    constexpr int J = NR + 2 * NC, MM = J * J;
-    const int lane = threadIdx.x & 63;
-    const double2 *yv = a.yv + lc * a.N, *dxt = a.dxt + lc * a.t_stride;
-    Sym<J> Dv, Jm;
-    double b[J], eta[J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) { b[i] = 0.0; eta[i] = 0.0; }
-#pragma unroll
-    for (int i = 0; i < J * (J + 1) / 2; ++i) { Dv.v[i] = 0.0; Jm.v[i] = 0.0; }
-    tp_sub_pinf<NR, NC, J>(M, Dv);  // C - P_inf, C = 0
-    double kap[3] = {0.0, 1.0, INFINITY};
-    int kexp = 0;
-    double inv1 = 0.0, zi1 = 0.0, inv2 = 0.0, zi2 = 0.0;
-    const uint32_t last = ((uint32_t)a.N - 1u) * 16u;
-    uint32_t off = lo * 16u;
-    double2 yn = tpb_sample(yv, off < last ? off : last);
-    double tn = tpb_sample(dxt, off < last ? off : last).y;
-    for (uint32_t k = 0; k < per + 3u; ++k) {
-        if (k >= 3u) {  // eta, Jm of step k - 3
-            const double(*G)[64] = ring.g[(k - 3u) & 1u];
-            double g[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) g[j] = G[j][lane];
-#pragma unroll
-            for (int j = 0; j < J; ++j) eta[j] = fma(g[j], zi2, eta[j]);
-#pragma unroll
-            for (int i = 0; i < J; ++i) {
-                const double gi = g[i] * inv2;
-#pragma unroll
-                for (int j = 0; j <= i; ++j) Jm(i, j) = fma(gi, g[j], Jm(i, j));
-            }
-        }
-        inv2 = inv1; zi2 = zi1;
-        inv1 = 0.0; zi1 = 0.0;
-        if (k >= 1u && k <= per) {  // the filter step of step k - 1
-            const uint32_t s = k - 1u;
-            const bool valid = off < hi * 16u;
-            const double r = valid ? fma(-slope, tn, yn.x - icpt) : 0.0, R = valid ? yn.y + jitter : 1.0e300;
-            off += 16u;
-            yn = tpb_sample(yv, off < last ? off : last);
-            tn = tpb_sample(dxt, off < last ? off : last).y;
-            const double(*F)[64] = ring.F[s % 3u];
-            TpTrans<NR, NC> T;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) T.phi[j] = F[j][lane];
-#pragma unroll
-            for (int q = 0; q < NC; ++q) { T.ec[q] = F[NR + 2 * q][lane]; T.es[q] = F[NR + 2 * q + 1][lane]; }
-            tpb_predict_dev<NR, NC, J>(T, Dv);
-            tp_apply_F<NR, NC>(T, b);
-            double ch[J];  // (P_inf + Dv) h
-#pragma unroll
-            for (int i = 0; i < J; ++i) {
-                double sum = i < NR ? M.ar[i < NR ? i : 0] : ((i - NR) & 1 ? -M.bc[i < NR ? 0 : (i - NR) / 2] : M.ac[i < NR ? 0 : (i - NR) / 2]);
-#pragma unroll
-                for (int j = 0; j < NR; ++j) sum += Dv(i, j);
-#pragma unroll
-                for (int q = 0; q < NC; ++q) sum += Dv(i, NR + 2 * q);
-                ch[i] = sum;
-            }
-            const double D = tp_h_dot<NR, NC>(ch) + R;
-            const double z = r - tp_h_dot<NR, NC>(b);
-            const double inv = mtg_rcp(D);
-            const double zi = z * inv;
-            double(*G)[64] = ring.ch[s & 1u];
-#pragma unroll
-            for (int i = 0; i < J; ++i) G[i][lane] = ch[i];
-            G[J][lane] = inv;
-            kap[0] = fma(z, zi, kap[0]);
-            const double pr = kap[1] * (valid ? D : 1.0);
-            kexp += __builtin_amdgcn_frexp_exp(pr);
-            kap[1] = __builtin_amdgcn_frexp_mant(pr);
-            kap[2] = fmin(kap[2], D);
-#pragma unroll
-            for (int i = 0; i < J; ++i) b[i] = fma(ch[i], zi, b[i]);
-#pragma unroll
-            for (int i = 0; i < J; ++i) {
-                const double ki = ch[i] * inv;
-#pragma unroll
-                for (int j = 0; j <= i; ++j) Dv(i, j) = fma(-ki, ch[j], Dv(i, j));
-            }
-            inv1 = inv; zi1 = zi;
-        }
-        __syncthreads();
-    }
-    tp_add_pinf<NR, NC, J>(M, Dv);
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        slot[MM + i] = b[i];
-        slot[MM + J + i] = eta[i];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            slot[MM + 2 * J + i * J + j] = Dv(i, j);
-            slot[2 * MM + 2 * J + i * J + j] = Jm(i, j);
-        }
-    }
-    part[0] = kap[0];
-    part[1] = log(kap[1]) + (double)kexp * 0.69314718055994530942;
-    part[2] = kap[2];
-}
-
-// One evaluation of structure <NR, NC> by this workgroup of 128 lanes: lane & 63 = chunk, lane >> 6 = role
-template <int NR, int NC>
-__device__ __forceinline__ void tpb2_compose_eval(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
-                                                  TpbRing<NR + 2 * NC> &ring, const MtgMathTables *tab)
-{
-    constexpr int J = NR + 2 * NC;
-    TpModel<NR, NC> M;
-    double jitter, slope, icpt;
-    int64_t lc;
-    bool fast;
-    if (!tpb_load_model<NR, NC>(a, ev, M, jitter, slope, icpt, lc, fast)) return;  // the finish kernel reports it
-    const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
-    uint32_t lo, hi;
-    tpb_chunk_range(a.N, C, c, lo, hi);
-    const uint32_t per = ((uint32_t)a.N - 1u + (uint32_t)C - 1u) / (uint32_t)C;
-    double *slot = elems + (ev * C + c) * MTG_TPB_ELEM(J);
-    if (threadIdx.x < 64) tpb2_columns<NR, NC>(a, M, lc, tab, fast, ring, slot, lo, hi, per);
-    else tpb2_filter<NR, NC>(a, M, jitter, slope, icpt, lc, ring, slot, parts + (ev * C + c) * 4, lo, hi, per);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Composition by FOUR waves per 64 chunks (mtg_tpb_compose4_kernel), round 3.
-//
-// What the two-wave kernel above pays: its waves hold 200 / 260 VGPRs of state plus temporaries, i.e. 434 registers
-// with the accumulation half, ONE wave per SIMD -- and a lone wave is handed one instruction of ANY kind per issue
-// slot: the ~290 v_accvgpr copies, ~150 LDS instructions and ~60 scalar ones of an interval cost as much as its
-// 991 FP64 ones (1498 slots, 3400 cycles per interval, profiles/r02_tp_pmc.txt).  Here the element of a chunk is
-// shared by the same lane of FOUR waves, each below 256 registers, two workgroups = eight waves per CU, two waves
-// per SIMD: nothing lives in accumulation registers and one wave's LDS / scalar / wait instructions issue under the
-// other's arithmetic.  Roles (wave = threadIdx.x >> 6):
+// One lane per chunk cannot hold the element (A, b, Dv, eta, Jm: 330 doubles) in directly addressable registers, and
+// a lone wave per SIMD is handed one instruction of ANY kind per issue slot: its register copies, LDS and scalar
+// instructions cost as much as its FP64 ones (rounds 1-2: one and two waves per 64 chunks, docs/HISTORY.md).  Here
+// the element of a chunk is shared by the same lane of FOUR waves, each below 256 registers, two workgroups = eight
+// waves per CU, two waves per SIMD: nothing lives in accumulation registers and one wave's LDS / scalar / wait
+// instructions issue under the other's arithmetic.  Roles:
 //   0 "columns, low"   columns 0..4 of A, eta[0..4], the transition of the first terms
 //   1 "columns, high"  columns 5..9 of A, eta[5..9], the transition of the other terms, the mean b and the residual z
 //   2, 3 "filter"      the symmetric matrices Dv and Jm, cut block by block of the term structure into two halves of
@@ -442,14 +226,14 @@ __device__ __forceinline__ void tpb2_compose_eval(const MtgSolveArgs &a, int64_t
 //   t = s + 3  waves 0, 1   A <- (I - K h) F A for the own columns, g = h F A      -> ring g[s & 1];  wave 1: b, z,
 //                           z / D -> ring zi[s & 1], eta[5..9]
 //   t = s + 4  waves 2, 3   Jm += g g^T / D on the own blocks;  wave 0: eta[0..4]
-// A workgroup is EIGHT waves: two such quartets (two blocks of 64 chunks, each with its own rings), the second with
-// its roles rotated by two.  Waves w and w + 4 of a workgroup share a SIMD (scripts/micro/simd_probe.hip), so every
-// SIMD runs one "columns" and one "filter" wave: whatever the imbalance between the two kinds, the four SIMDs carry the
-// same load, and a wave deep in LDS traffic shares its SIMD with one deep in arithmetic.  (Two four-wave workgroups
-// per CU pair their waves at random, role for role as often as not: 2.79 ms against 2.84 for the two-wave kernel.)
+// A workgroup is one such quartet; two of them share a CU with independent barriers, and a wave takes its role from
+// the SIMD it runs on (mtg_tp_big_compose4q.hip), so every SIMD runs one "columns" and one "filter" wave: whatever the
+// imbalance between the two kinds, the four SIMDs carry the same load, and a wave deep in LDS traffic shares its SIMD
+// with one deep in arithmetic.
 // Every hand-over crosses exactly one barrier and part A of step s + 1 follows part B of step s in the same
 // tick of the same wave (the only true recurrence, Dv, never waits for another wave inside a tick).  Chunks shorter
-// than `per` steps run the rest as no-ops exactly as above (dx = 0, measurement variance 1e300).
+// than `per` steps run the rest as no-ops: dx = 0 makes the transition the identity exactly, and a measurement variance
+// of 1e300 makes the gain vanish below rounding.
 // (measurements only: -DMTG_TPB4_NOSYNC times the arithmetic without its barriers -- the results are then wrong)
 #ifdef MTG_TPB4_NOSYNC
 #define TPB4_SYNC() __builtin_amdgcn_sched_barrier(0)
@@ -897,13 +681,6 @@ __device__ __forceinline__ void tpb_dispatch(int nr, Args &&...args)
     default: break;
     }
 }
-template <int NR, int NC> struct TpbComposeF {
-    static __device__ __forceinline__ void run(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
-                                               TpbRing<10> &ring, const MtgMathTables *tab)
-    {
-        tpb2_compose_eval<NR, NC>(a, ev, elems, parts, C, ring, tab);
-    }
-};
 template <int NR, int NC> struct TpbCompose4F {
     static __device__ __forceinline__ void run(const MtgSolveArgs &a, int64_t ev, double *elems, double *parts, int C,
                                                TpbRing4<10> &ring, const MtgMathTables *tab, uint32_t cb, int role)
@@ -926,8 +703,6 @@ __device__ __forceinline__ int tpb_nr(const MtgSolveArgs &a, int64_t ev) { retur
 // one wave per evaluation: the chunks' partial sums in a fixed order, plus the head (sample 0)
 void mtg_launch_tpb_finish(const MtgSolveArgs &a, const double *parts, const double *head, int C, int64_t nevals,
                            hipStream_t stream);
-// mtg_tp_big_compose.hip / mtg_tp_big_filter.hip: the two kernels that hold all six structures
-void mtg_launch_tpb_compose(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
-void mtg_launch_tpb_compose4(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
+// mtg_tp_big_compose4q.hip / mtg_tp_big_filter.hip: the two kernels that hold all six structures
 void mtg_launch_tpb_compose4q(const MtgSolveArgs &a, double *elems, double *parts, int C, int64_t nevals, hipStream_t stream);
 void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *parts, int C, int64_t nevals, hipStream_t stream);

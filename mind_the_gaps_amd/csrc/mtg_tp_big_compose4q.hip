@@ -2,7 +2,7 @@
 // workgroups of ONE quartet (256 lanes), two workgroups per CU with independent barriers, and the roles handed out by
 // SIMD so that every SIMD still runs one "columns" and one "filter" wave.
 //
-// In the eight-wave workgroups of mtg_tp_big_compose4.hip both quartets stop at the same barrier: every wave of the CU
+// With both quartets of a CU in one eight-wave workgroup (round 3) they stop at the same barrier: every wave of the CU
 // drains its LDS writes, waits and then fetches its first operands at the same moment, and the FP64 pipe idles
 // meanwhile (35 % of the SIMD cycles, profiles/r03_compose_pmc.txt).  Two independent workgroups drift apart and fill
 // each other's waits -- but left to the dispatcher their waves pair up at random, "columns" with "columns" as often as

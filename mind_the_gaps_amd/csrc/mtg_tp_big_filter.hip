@@ -4,8 +4,6 @@
 #define MTG_TRIG_BITS 10
 #include "mtg_tp_big.h"
 
-#include <stdlib.h>
-
 namespace {
 
 // grid (ceil(C / 256), evaluations), 256 lanes: lane = chunk; four waves share one set of tables
@@ -27,16 +25,6 @@ void mtg_launch_tpb_filter(const MtgSolveArgs &a, const double *states, double *
                        parts, C);
 }
 
-// Four waves per 64 chunks (round 3: no accumulation registers, two waves per SIMD, 13 % fewer vector instructions)
-// and the two-wave kernel of round 2 take the same time to within the box-to-box spread -- both keep the FP64 pipe
-// ~68 % busy and that pipe is saturated by ONE wave per SIMD (scripts/micro/fp64_waves.hip: 5.2 ticks per v_fma_f64
-// from one wave, 4.5 from two, 4.3 from four).  MTG_TPB_COMPOSE=2 selects the two-wave kernel for side-by-side runs.
-int mtg_tpb_compose_waves(void)
-{
-    static const int waves = !getenv("MTG_TPB_COMPOSE") ? 4 : atoi(getenv("MTG_TPB_COMPOSE")) == 2 ? 2 : atoi(getenv("MTG_TPB_COMPOSE")) == 8 ? 8 : 4;
-    return waves;   // 4: quartets as workgroups of their own (compose4q); 8: two quartets per workgroup (compose4); 2: round 2
-}
-
 // Every prepared evaluation of a rank-10 model (status OK; its structure in a.sig) in one sequence of
 // launches.  a.tp_direct: the likelihood from the composition pass and the up-sweep alone (mtg_tp_scan.h:
 // the elements carry their likelihood records); the down-sweep and the filter pass then run for the
@@ -49,9 +37,7 @@ void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t s)
     const int C = a.tp_chunks;
     const MtgTpBigPlan plan = mtg_tp_big_plan(J, a.B, C, a.tp_gsize);
     double *ws = a.tp_ws;
-    if (mtg_tpb_compose_waves() == 2) mtg_launch_tpb_compose(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
-    else if (mtg_tpb_compose_waves() == 8) mtg_launch_tpb_compose4(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
-    else mtg_launch_tpb_compose4q(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
+    mtg_launch_tpb_compose4q(a, ws + plan.elem_off[0], ws + plan.part_off, C, nevals, s);
     int *redo_list = (int *)(ws + plan.redo_off), *redo_count = redo_list + a.B;
     mtg_launch_tpb_up(J, a, plan, nevals, a.tp_direct, a.tp_direct ? redo_count : nullptr, s);
     MtgSolveArgs f = a;

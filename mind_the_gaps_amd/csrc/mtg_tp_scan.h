@@ -109,8 +109,6 @@ void mtg_launch_tpb_top_direct(int J, const MtgSolveArgs &a, const MtgTpBigPlan 
 void mtg_launch_tpb_down(int J, const MtgSolveArgs &a, const MtgTpBigPlan &plan, int64_t nevals, hipStream_t stream);
 // the whole path (mtg_tp_big_filter.hip): every prepared evaluation of a rank-10 model, whatever its structure
 void mtg_launch_tp_big(const MtgSolveArgs &a, int64_t nevals, hipStream_t stream);
-// waves per 64 chunks of the composition kernel in use: 4 (default) or 2 (MTG_TPB_COMPOSE=2 in the environment)
-int mtg_tpb_compose_waves(void);
 
 #ifdef __HIPCC__
 namespace tpg {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the configs[4] half-step (scripts/c5_one.py B): where the wave cycles of the compose / scan kernels go.
-# Run on the GPU box: gpurun -- bash scripts/c5_pmc.sh [B] [tag]     (MTG_TPB_COMPOSE=2 in the environment: two-wave kernel)
+# Run on the GPU box: gpurun -- bash scripts/c5_pmc.sh [B] [tag]
 B=${1:-256}
 TAG=${2:-c5}
 OUT=$PWD/gpurun_out/pmc_$TAG; mkdir -p $OUT; REPO=$PWD

@@ -223,3 +223,29 @@ def test_context_on_a_slice_of_the_compute_units():
     finally:
         for eng in engines:
             eng.close()
+
+
+@pytest.mark.parametrize("name", ["null_drw_sho", "alt_drw_sho_lorentzian"])
+def test_shipped_shape_against_the_oracle(pipe, name):
+    """The shape the pipeline exists for -- one GPU's half-step of BASELINE configs[3] at 8 GPUs: 250 light curves x 128
+    proposals = 32 000 rows, N = 1e4, both models -- compared with the ORACLE row by row (not only with the one-lane
+    sweep, which the tests above show it equals), through the default dispatch (mtg_set_pipeline 2: no forcing)."""
+    kinds = MODELS[name]
+    N, L, W = 10000, 250, 128
+    t, y, dy = synth.make_lightcurves(N, L, seed=20250704 + 4)
+    full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+    pipe.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+    pipe.set_model(kinds, full, free, bounds)
+    pipe.set_pipeline(2)
+    theta = synth.draw_thetas(kinds, L * W, seed=20250704 + 44)
+    theta[::1013, 0] = 60.0                                     # a few rows outside the prior box
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    got, gst = pipe.loglike(theta, lc, add_prior=True)
+    assert "mtg_pipe_kernel" in pipe.last_solver, pipe.last_solver
+    ref, rst = oracle_c.logprob_batch(t, y, dy, kinds, np.hstack([theta, y.mean(axis=1)[lc][:, None]]),
+                                      bounds=bounds, lc_index=lc, add_prior=True, nthreads=16)
+    assert np.array_equal(rst, gst)
+    ok = gst == 0
+    assert ok.sum() > 31000
+    assert np.all(np.isneginf(got[gst == 1]))
+    assert np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
