@@ -428,7 +428,10 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     sa.tp_nr0 = m.nr0; sa.tp_nc0 = m.nc0;
     sa.sig = ctx->sig.as<int32_t>();
     bool small_ok = small;
-    if (small && Jmodel > 6) {
+    // mode 3 promises bits that do not depend on the batch; the rank-10 path sizes its chunks and scan groups by the
+    // batch (mtg_tp_big_chunks), so under mode 3 such a model keeps the serial sweep
+    if (ctx->tp_mode == 3 && Jmodel > 6) small_ok = false;
+    if (small_ok && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
             if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
         const int C = mtg_tp_big_chunks(ctx->N, Bw);

@@ -259,6 +259,11 @@ class BatchPosteriors:
             self.median_parameters = None
 
 
+# rows per half-step of a WHOLE set of light curves up to which derive_posteriors_batch(index_base=...) keeps the chains on
+# the batch-independent time-parallel kernel (mtg_set_time_parallel 3); see its docstring
+REPRODUCIBLE_TP_ROWS = 16384
+
+
 def _spread(rng, centers, lower, upper, walkers, percent=0.1, max_attempts=20):
     """spread_walkers (gpmodelling.py:289-350) for every light curve at once."""
     return _walkers.spread(rng.normal, centers, lower, upper, walkers, percent=percent, max_attempts=max_attempts)
@@ -293,7 +298,8 @@ class _DeviceBatch:
 
 def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit=True, seed=None,
                             device=0, store_chain=True, initial_params=None, quiet=False,
-                            evaluate=None, device_sampler=True, own_engine=False, index_base=None, before_sampling=None):
+                            evaluate=None, device_sampler=True, own_engine=False, index_base=None, before_sampling=None,
+                            total_lightcurves=None):
     """GPModelling(lc, kernel).derive_posteriors(...) for L light curves at once.
 
     times [N] (shared sampling, gpmodelling.py:538); Y, DY [L, N]; ``kernel`` a
@@ -314,8 +320,13 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
     L: the walkers' starting points (one generator per light curve, keyed by seed and global index), the sampler's
     random numbers (Philox counters by global ensemble index, ``mtg_set_stream_base``) and the kernels (the number
     of rows in a batch otherwise picks between kernels whose sums differ in the last bits: the starting fit runs on
-    the one-wave time-parallel kernel whatever the batch, the chains on the one-lane sweep and its pipelined form,
-    which agree bit for bit; ``mtg_set_time_parallel`` 3 and 0).
+    the one-wave time-parallel kernel whatever the batch; the chains on the one-lane sweep and its pipelined form,
+    which agree bit for bit -- or, when the WHOLE set is small, on that one-wave kernel as well;
+    ``mtg_set_time_parallel`` 3 and 0).  ``total_lightcurves``: the size of the whole set, which is what that choice
+    may depend on (not L, the block's): up to ``REPRODUCIBLE_TP_ROWS`` rows per half-step of the whole set every
+    block, whatever the split, is inside the range where the time-parallel kernel is the fast one (0.35-3.6 ms against
+    2.4-3.4 ms for the sweep at N = 1e4); unknown or larger, the sweep.  Models of rank above 6 keep the sweep in
+    either mode (their time-parallel path sizes its chunks by the batch).
     """
     Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
     DY = np.atleast_2d(np.asarray(DY, dtype=np.float64))
@@ -353,13 +364,16 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
         if block_free:
             ev._bind(model).set_time_parallel(mode)
 
+    chain_mode = 3 if (total_lightcurves is not None
+                       and int(total_lightcurves) * (walkers // 2) <= REPRODUCIBLE_TP_ROWS) else 0
+
     try:
         if fit:
             kernels(3)
             fit_x, fit_f, _ = batched_minimize(lambda x, lc: -checked(x, lc, False), centers, lower, upper)
             centers, fit_f = fit_x, -fit_f
             clock.append(("fit", time.perf_counter()))
-        kernels(0)
+        kernels(chain_mode)
         if block_free:
             p0 = np.concatenate([_spread(np.random.default_rng([int(seed), 1, int(index_base) + l]), centers[l:l + 1],
                                          lower, upper, walkers) for l in range(L)])
@@ -419,7 +433,8 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     3. both kernels refitted to every simulated light curve in lock-step;
     4. p-value of ``T_obs`` in the simulated distribution.
 
-    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves, seconds, split) -- ``seconds``:
+    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves, seconds, split, reproducible) --
+    ``seconds``:
     wall time of the observed chains, the simulation and the two refits on this process.
 
     ``concurrent_refits``: the null and the alternative refits of step 3 side by side on the device (two contexts, two
@@ -445,14 +460,20 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     light curves (a rank then holds ``sim_null`` or ``sim_alt``, not both) --, "auto" picks by the rows a half-step
     leaves each rank (``_split_by_model``).
 
-    ``reproducible`` (default: on when ``sharded``): ``T_sim`` and the p-value do not depend on the number of ranks
-    or on the split -- a run on 8 GPUs can be CHECKED against a run on one, bit for bit.  Every simulated light curve
+    ``reproducible`` (default: on when ``sharded`` and it costs nothing, see below): ``T_sim`` and the p-value do not
+    depend on the number of ranks or on the split -- a run on 8 GPUs can be CHECKED against a run on one, bit for bit.  Every simulated light curve
     is then a function of (seed, its global index) alone: the simulator's noise stream and each refit's Philox
     counters are keyed by global index (``mtg_set_stream_base``), the walkers start from a generator of the light
     curve's own, and the refits keep to kernels whose results do not depend on the batch a row travels in
-    (``derive_posteriors_batch(index_base=...)``).  Off, every block draws from a stream of its own and small
-    batches take whichever kernel is fastest for their size: the same statistics, a few per cent faster where a
-    rank's batches are small, not the same numbers.  (The observed light curve's chains are rank 0's either way.)
+    (``derive_posteriors_batch(index_base=..., total_lightcurves=nsims)``; what the host draws -- Kraft noise, a
+    non-Gaussian flux PDF -- comes from a generator per light curve as well).  Off, every block draws from a stream of
+    its own and every batch takes whichever kernel is fastest for its size: the same statistics, not the same numbers.
+    The price of "on" is the kernel choice: a set beyond ``REPRODUCIBLE_TP_ROWS`` rows per half-step keeps its chains
+    on the sweep, which a rank whose own share is small (under ~8000 rows: the time-parallel kernels' range) pays
+    with 2.4-3.4 ms per half-step instead of 0.35-1.8 ms at N = 1e4.  The default is therefore "on" only where that
+    does not happen -- the set is small enough for the batch-independent time-parallel kernel everywhere, or every
+    rank's share is beyond the time-parallel range anyway (BASELINE configs[3]: 250 x 128 rows per rank) -- and the
+    returned dict says which it was (``reproducible``).  (The observed light curve's chains are rank 0's either way.)
     """
     from .gpmodelling import GPModelling
     from .simulator import Simulator
@@ -478,6 +499,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                 np.random.set_state(state)
         return g
 
+    import threading
     import time
     clock = [time.perf_counter()]
     # the simulator's transform plan is built beside the observed chains (its grid depends on the sampling alone)
@@ -508,10 +530,13 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     sim_seed, fit_seeds = int(rng.integers(0, 2 ** 31 - 1)), [int(rng.integers(0, 2 ** 52)) for _ in range(2)]
     sw = sim_walkers or walkers
     lo, hi, shard, models = 0, nsims, None, (0, 1)
-    reproducible = bool(sharded) if reproducible is None else bool(reproducible)
     if sharded:
         from .distributed import LightcurveShard, all_gather_rows, block_bounds, broadcast_array
         shard = LightcurveShard(nsims, group=group)
+        if reproducible is None:
+            reproducible = _reproducible_is_free(split, nsims, sw, shard.world)
+    reproducible = bool(reproducible)
+    if sharded:
         # rank 0's test is everybody's test: its T_obs, its posterior samples and its seeds (every rank drew its own
         # from its own chains' generator state; under the model split two ranks must simulate the SAME light curves)
         head = broadcast_array(np.concatenate([[t_obs, float(sim_seed)], np.asarray(fit_seeds, dtype=np.float64),
@@ -534,7 +559,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
         if not reproducible:
             sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)   # independent noise on every block (the two ranks
             fit_seeds = [f + 7919 * block for f in fit_seeds]       # of a block under the model split draw the same)
-    out, fits, best = None, [None, None], [np.empty(0), np.empty(0)]
+    out, fits, best, failure = None, [None, None], [np.empty(0), np.empty(0)], None
     # each model on a context of its own (MTG_PPP_CU_SLICES=1: and on its own half of the compute units,
     # mtg_create_on_slice -- measured no faster: 7.24 against 7.14 ms per iteration)
     side_by_side = len(models) == 2 and (concurrent_refits is True or
@@ -542,56 +567,75 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     if side_by_side and os.environ.get("MTG_PPP_CU_SLICES") == "1":
         side_by_side = "slices"
     if hi > lo:
-        sim.random_state = np.random.RandomState(sim_seed)
-        out = sim.simulate(samples[lo:hi, :null_kernel.vector_size], index_base=lo if reproducible else 0)
-        clock.append(time.perf_counter())
-        import threading
-        meet = threading.Barrier(2) if side_by_side else None
+        try:
+            sim.random_state = np.random.RandomState(sim_seed)
+            out = sim.simulate(samples[lo:hi, :null_kernel.vector_size], index_base=lo if reproducible else None)
+            clock.append(time.perf_counter())
+            meet = threading.Barrier(2) if side_by_side else None
 
-        def refit(k):
-            kernel = (null_kernel, alt_kernel)[k]
-            try:
-                return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
-                                               max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
-                                               store_chain=False, quiet=True,
-                                               # side by side: model k on the process's k-th extra context (gp.get_side_engine)
-                                               own_engine=((k, 2) if side_by_side == "slices" else ("side", k) if side_by_side
-                                                           else False),
-                                               index_base=lo if reproducible else None,
-                                               before_sampling=(lambda: meet.wait(timeout=600)) if meet is not None else None)
-            except BaseException:
-                if meet is not None:
-                    meet.abort()        # the partner thread must not wait at the barrier for a refit that has failed
+            def refit(k):
+                kernel = (null_kernel, alt_kernel)[k]
+                try:
+                    return derive_posteriors_batch(lightcurve.times, out["rates"], out["dy"], kernel, walkers=sw,
+                                                   max_steps=sim_steps, fit=True, seed=fit_seeds[k], device=device,
+                                                   store_chain=False, quiet=True,
+                                                   # side by side: model k on the process's k-th extra context (gp.get_side_engine)
+                                                   own_engine=((k, 2) if side_by_side == "slices" else ("side", k) if side_by_side
+                                                               else False),
+                                                   index_base=lo if reproducible else None,
+                                                   total_lightcurves=nsims if reproducible else None,
+                                                   # (no timeout: a partner that fails aborts the barrier, below)
+                                                   before_sampling=meet.wait if meet is not None else None)
+                except BaseException:
+                    if meet is not None:
+                        meet.abort()        # the partner thread must not wait at the barrier for a refit that has failed
+                    raise
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                if side_by_side:
+                    # The two models' refits are independent: each on its own context and stream, driven by its own host
+                    # thread (the library calls release the GIL).  Measured at configs[3]'s sizes: 26.30 s side by side
+                    # against 8.40 + 17.96 s one after the other -- both sweeps are bound by FP64 issue and a half-step
+                    # leaves no idle issue slots for the other model to fill; on a block that leaves the GPU room (a rank's
+                    # 250 light curves at 8 GPUs) the two chains interleave and gain 16 %: "auto" (docstring).
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=2) as pool:
+                        futures = [pool.submit(refit, k) for k in (0, 1)]
+                    errors = [f.exception() for f in futures if f.exception() is not None]
+                    if errors:   # the refit that failed, not the partner it left at the barrier
+                        real = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)]
+                        raise (real or errors)[0]
+                    fits = [f.result() for f in futures]
+                    clock += [time.perf_counter()] * 2
+                else:
+                    for k in (0, 1):
+                        if k in models:
+                            fits[k] = refit(k)
+                        clock.append(time.perf_counter())
+                best = [np.empty(0) if f is None else f.max_loglikelihood for f in fits]
+        except BaseException as exc:     # (simulation or refits)
+            failure = exc
+            if not sharded:
                 raise
-
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            if side_by_side:
-                # The two models' refits are independent: each on its own context and stream, driven by its own host
-                # thread (the library calls release the GIL).  Measured at configs[3]'s sizes: 26.30 s side by side
-                # against 8.40 + 17.96 s one after the other -- both sweeps are bound by FP64 issue and a half-step
-                # leaves no idle issue slots for the other model to fill; on a block that leaves the GPU room (a rank's
-                # 250 light curves at 8 GPUs) the two chains interleave and gain 16 %: "auto" (docstring).
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=2) as pool:
-                    fits = list(pool.map(refit, (0, 1)))
-                clock += [time.perf_counter()] * 2
-            else:
-                for k in (0, 1):
-                    if k in models:
-                        fits[k] = refit(k)
-                    clock.append(time.perf_counter())
-            best = [np.empty(0) if f is None else f.max_loglikelihood for f in fits]
-    if sharded:   # the only exchange of the loop: the maxima of lnL, one all-gather per model
+    if sharded:
+        # a rank whose refits failed says so BEFORE the gather: the others must not wait in it for maxima that will not come
+        failed = all_gather_rows(np.array([0.0 if failure is None else 1.0]), np.ones(shard.world, dtype=int), group)
+        if failure is not None:
+            raise failure
+        if failed.any():
+            raise RuntimeError("protassov_test: the refits failed on rank(s) %s" % np.flatnonzero(failed).tolist())
+        # the only exchange of the loop: the maxima of lnL, one all-gather per model
         if len(models) == 2:
             best = [shard.gather(b) for b in best]
         else:
             # the null rank and the alternative rank of a block pair lnL values of what must be the same light curves,
-            # simulated on two GPUs: a checksum per rank says so, or the test stops here
-            mine = np.array([float(np.sum(out["rates"])) + float(np.sum(out["dy"])) if out is not None else np.nan])
+            # simulated on two GPUs: a checksum per rank says so, or the test stops here (a block without light curves
+            # -- fewer of them than pairs of ranks -- has nothing to compare)
+            mine = np.array([float(np.sum(out["rates"])) + float(np.sum(out["dy"])) if out is not None else 0.0])
             sums = all_gather_rows(mine, np.ones(shard.world, dtype=int), group)
             for b in range(shard.world // 2):
-                if sums[b] != sums[b + shard.world // 2]:
+                if bounds[b + 1] > bounds[b] and sums[b] != sums[b + shard.world // 2]:
                     raise RuntimeError("ranks %d and %d simulated different light curves for block %d (checksums %r, %r)"
                                        % (b, b + shard.world // 2, b, sums[b], sums[b + shard.world // 2]))
             half, sizes = shard.world // 2, np.diff(bounds)
@@ -604,8 +648,18 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     seconds = dict(zip(("observed_chains", "simulate", "refit_null", "refit_alt", "gather"), np.diff(clock))) \
         if len(clock) == 6 else {"observed_chains": clock[1] - clock[0]}
     return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
-                sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds,
+                sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds, reproducible=reproducible,
                 split=None if not sharded else ("models" if len(models) < 2 else "lightcurves"))
+
+
+def _reproducible_is_free(split, nsims, walkers, world):
+    """protassov_test(sharded=True, reproducible=None): world-size-independent results by default exactly where they do not
+    cost a rank the time-parallel kernels (docstring there): the whole set is within ``REPRODUCIBLE_TP_ROWS`` rows per
+    half-step -- every block then runs the batch-independent time-parallel kernel --, or every rank's own share is beyond
+    the time-parallel range (8192 rows), where the sweep is what it would run anyway."""
+    by_model = _split_by_model(split, nsims, walkers, world)
+    rows_per_rank = -(-nsims // (world // 2 if by_model else world)) * (walkers // 2)
+    return bool(nsims * (walkers // 2) <= REPRODUCIBLE_TP_ROWS or rows_per_rank > 8192)
 
 
 def _split_by_model(split, nsims, walkers, world):

@@ -210,12 +210,14 @@ class Simulator:
 
     # -- simulation --------------------------------------------------------------------
     def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None, nsims=None,
-                 index_base=0):
+                 index_base=None):
         """Light curves for S kernel parameter vectors ``thetas`` [S][P] (default: the kernel's
         current one; with a callable PSD: ``nsims`` realisations of it) in one device call ->
         dict(rates[S][N], dy[S][N], means[S], clean[S][N] | None).  ``index_base``: global index of the first of
         these series (mtg_set_stream_base) -- with the same ``seed``, series [index_base, index_base + S) of a set
-        simulated in blocks are the ones a single call for the whole set would make (device noise kinds only)."""
+        simulated in blocks are the ones a single call for the whole set would make.  That holds for what is drawn on the
+        host as well (Kraft noise, a non-Gaussian flux PDF): given an ``index_base``, every series draws from a generator
+        of its own, keyed by (seed, global index), instead of this simulator's one ``random_state``."""
         eng, model = self._engine()
         if seed is None:
             seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
@@ -223,7 +225,7 @@ class Simulator:
         kw = dict(noise_kind=0 if (host_side or not noise) else self._noise_kind, sigma_noise=self.sigma_noise,
                   exposures=self._exposures, want_clean=want_clean and not host_side,
                   make_resident=make_resident and not host_side, want_segments=self.pdf.lower() != "gaussian")
-        eng.set_stream_base(index_base)
+        eng.set_stream_base(index_base or 0)
         try:
             if model is None:
                 out = eng.simulate_tk95(int(nsims or 1), seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
@@ -238,24 +240,42 @@ class Simulator:
             if make_resident:
                 eng.bound_to = None    # whatever happened, the engine no longer holds this evaluator's dummy data
         if host_side:
-            out = self._finish_on_host(out, noise, want_clean)
+            out = self._finish_on_host(out, noise, want_clean, None if index_base is None else (int(seed), int(index_base)))
             if make_resident:          # the refits want the set resident: upload what the host produced
                 eng.set_lightcurves(self._times, out["rates"], out["dy"] + 1e-12, y_offset=out["means"])
         out.pop("segments", None)
         return out
 
-    def _finish_on_host(self, out, noise, want_clean):
+    def _finish_on_host(self, out, noise, want_clean, keyed=None):
         """Flux-PDF adjustment of the fine-grid segments, down-sampling and noise for the cases the device
-        kernels do not cover (module docstring)."""
-        rates = out["rates"]
-        if self.pdf.lower() != "gaussian":
-            rates = np.array([self.downsample(self.segment_times, self._adjust_pdf(seg)) for seg in out["segments"]])
-        clean = rates.copy() if want_clean else None
-        dy = np.zeros_like(rates)
-        if noise:
-            noisy = [self.add_noise(r) for r in rates]
-            rates = np.array([r for r, _ in noisy])
-            dy = np.array([e for _, e in noisy])
+        kernels do not cover (module docstring).  ``keyed`` = (seed, index_base): series l draws from
+        RandomState([seed, index_base + l]) -- its values then do not depend on which block it was simulated in."""
+        S = len(out["rates"])
+        shared = self.random_state
+
+        def own_stream(l, phase):
+            if keyed is not None:
+                seed, g = keyed[0], keyed[1] + l
+                self.random_state = np.random.RandomState(np.array(
+                    [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, g & 0xFFFFFFFF, g >> 32, phase], dtype=np.uint32))
+
+        rates, dy = [out["rates"][l] for l in range(S)], []
+        try:
+            # (the adjustment of every series comes before the noise of any, as it always did on the shared generator)
+            if self.pdf.lower() != "gaussian":
+                for l in range(S):
+                    own_stream(l, 0)
+                    rates[l] = self.downsample(self.segment_times, self._adjust_pdf(out["segments"][l]))
+            clean = np.array(rates) if want_clean else None
+            if noise:
+                for l in range(S):
+                    own_stream(l, 1)
+                    rates[l], e = self.add_noise(rates[l])
+                    dy.append(e)
+        finally:
+            self.random_state = shared
+        rates = np.array(rates)
+        dy = np.array(dy) if noise else np.zeros_like(rates)
         return dict(rates=rates, dy=dy, means=rates.mean(axis=1), clean=clean)
 
     def _adjust_pdf(self, segment):

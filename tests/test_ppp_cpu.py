@@ -164,3 +164,47 @@ def test_how_the_sharded_test_divides_its_refits():
         _split_by_model("models", 10, 16, 1)
     with pytest.raises(ValueError):
         _split_by_model("columns", 10, 16, 2)
+
+
+def test_where_the_sharded_test_is_reproducible_by_default():
+    """ppp._reproducible_is_free: world-size-independent numbers are the default only where they do not take the
+    time-parallel kernels away from a rank whose share is small."""
+    from mind_the_gaps_amd.ppp import _reproducible_is_free
+    assert _reproducible_is_free("auto", 2000, 256, 8) is True       # configs[3]: 32 000 rows per rank, the sweep anyway
+    assert _reproducible_is_free("auto", 2000, 256, 1) is True
+    assert _reproducible_is_free("auto", 16, 256, 8) is True         # 2048 rows in all: the one-wave kernel everywhere
+    assert _reproducible_is_free("auto", 1000, 32, 8) is True        # 16 000 rows in all
+    assert _reproducible_is_free("auto", 2000, 32, 8) is False       # 32 000 in all, 4000 per rank: time-parallel range
+    assert _reproducible_is_free("auto", 2000, 32, 2) is True        # 16 000 per rank: beyond it
+
+
+def test_host_side_noise_is_keyed_by_series_when_an_index_base_is_given():
+    """Simulator._finish_on_host (Kraft noise: drawn on the host): with (seed, index_base) every series has a generator of
+    its own, so a block's series are the whole set's; on the simulator's one shared stream two blocks that start from the
+    same state draw the same noise -- the sharded Protassov test's ranks did exactly that."""
+    from mind_the_gaps_amd.simulator import Simulator
+    from mind_the_gaps_amd.models import DampedRandomWalk
+    times = np.cumsum(np.full(40, 1.0))
+    sim = Simulator(DampedRandomWalk(1.0, -1.0, bounds=[(-10, 50), (-10, 10)]), times, 0.5, 50.0, "Gaussian", bkg_rate=5.0,
+                    bkg_rate_err=0.5, extension_factor=2, random_state=3)
+    assert sim.noise_name == "Kraft"
+    clean = 50.0 + 5.0 * np.random.default_rng(0).standard_normal((5, 40))
+    clean[2:4] = clean[0:2]          # two blocks with the same clean series: what differs between them can only be the noise
+
+    def finish(lo, hi, keyed):
+        return sim._finish_on_host(dict(rates=clean[lo:hi].copy()), True, False,
+                                   None if not keyed else (123456789012, lo))
+    whole = finish(0, 5, True)
+    for lo, hi in ((0, 2), (2, 5), (4, 5)):
+        part = finish(lo, hi, True)
+        assert np.array_equal(part["rates"], whole["rates"][lo:hi]) and np.array_equal(part["dy"], whole["dy"][lo:hi])
+    assert not np.array_equal(whole["rates"][0:2], whole["rates"][2:4])    # keyed: every series its own noise
+    state = sim.random_state.get_state()
+    finish(0, 5, True)
+    assert np.array_equal(state[1], sim.random_state.get_state()[1])       # keyed draws leave the shared stream alone
+    sim.random_state = np.random.RandomState(7)
+    a = finish(0, 2, False)
+    sim.random_state = np.random.RandomState(7)
+    b = finish(2, 4, False)
+    assert np.array_equal(a["rates"], b["rates"])                          # one stream, same state: the SAME noise
+    assert not np.array_equal(a["rates"], whole["rates"][0:2])

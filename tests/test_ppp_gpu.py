@@ -247,3 +247,29 @@ def test_simulated_series_in_blocks_are_the_series_of_one_call():
         for key in ("rates", "dy", "means"):
             assert np.array_equal(part[key], whole[key][lo:hi]), (lo, hi, key)
     assert not np.array_equal(sim.simulate(thetas[4:9], seed=12345)["rates"], whole["rates"][4:9])
+
+
+@pytest.mark.parametrize("pdf", ["Gaussian", "Lognormal"])
+def test_host_drawn_noise_in_blocks_is_the_noise_of_one_call(pdf):
+    """A light curve with a background takes the Kraft noise model, a non-Gaussian flux PDF the iterative adjustment: both
+    are drawn on the HOST.  Given an index_base every series draws from a generator of its own (seed, global index), so
+    blocks -- ranks of a sharded Protassov test -- reproduce the whole set; without it they share one stream and do not."""
+    from mind_the_gaps_amd.simulator import Simulator
+    rng = np.random.default_rng(4)
+    times = synth.make_times(120, rng)
+    sim = Simulator(null_kernel(), times, 0.04, 400.0, pdf, bkg_rate=30.0, bkg_rate_err=2.0, extension_factor=2,
+                    random_state=1, max_iter=30)
+    assert sim.noise_name == "Kraft"
+    thetas = synth.draw_thetas(synth.NULL_MODEL, 6, seed=8, percent=0.05)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")       # (the PDF adjustment may stop at max_iter: not what is tested)
+        whole = sim.simulate(thetas, seed=777, index_base=0)
+        for lo, hi in ((0, 2), (2, 6), (5, 6)):
+            part = sim.simulate(thetas[lo:hi], seed=777, index_base=lo)
+            for key in ("rates", "dy", "means"):
+                assert np.array_equal(part[key], whole[key][lo:hi]), (lo, hi, key)
+        sim.random_state = np.random.RandomState(5)
+        shared_a = sim.simulate(thetas[2:6], seed=777)
+    assert np.all(np.isfinite(whole["rates"])) and np.all(whole["dy"] > 0)
+    assert not np.array_equal(shared_a["rates"], whole["rates"][2:6])
