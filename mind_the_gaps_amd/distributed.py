@@ -188,9 +188,9 @@ def broadcast_start(p0, seed, group=None):
     return objs[0], objs[1]
 
 
-def broadcast_array(values, group=None):
-    """Rank 0's float64 array to every rank (same shape everywhere): decisions that must not differ between the
-    ranks of a walker-sharded run -- the autocorrelation times behind the convergence test -- are taken from it."""
+def broadcast_array(values, group=None, src=0):
+    """Rank ``src``'s (default 0's) float64 array to every rank (same shape everywhere): decisions that must not differ
+    between the ranks of a walker-sharded run -- the autocorrelation times behind the convergence test -- are taken from it."""
     import torch
     import torch.distributed as dist
     values = np.ascontiguousarray(values, dtype=np.float64)
@@ -200,7 +200,7 @@ def broadcast_array(values, group=None):
     dev = _object_device(group)
     if dev is not None:
         buf = buf.to(dev)
-    dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    dist.broadcast(buf, src=dist.get_global_rank(group, int(src)) if group is not None else int(src), group=group)
     return buf.cpu().numpy().reshape(values.shape)
 
 

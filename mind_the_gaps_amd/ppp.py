@@ -423,7 +423,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
                    sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
                    sharded=False, group=None, concurrent_refits="auto", split="auto", reproducible=None,
-                   observed_side_by_side=True):
+                   observed_side_by_side=True, observed_split=True):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -453,9 +453,13 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     arguments and its own ``device``; BASELINE configs[3]): steps 2 and 3 -- the loop over simulated light curves
     of tutorial_ppp.ipynb:326-343 -- are cut into contiguous blocks, one per rank (``distributed.LightcurveShard``):
     rank r simulates and refits only its block, nothing is exchanged meanwhile, and ONE all-gather per model of the
-    maxima of lnL (8 bytes per light curve) gives every rank the whole ``T_sim``.  Step 1 runs on every rank; rank
-    0's posterior samples and ``T_obs`` are broadcast so that all ranks test the same thing.  ``sim_null``,
-    ``sim_alt`` and ``lightcurves`` then hold the rank's own block.  ``split``: "lightcurves" as just described,
+    maxima of lnL (8 bytes per light curve) gives every rank the whole ``T_sim``.  Step 1 is split by model
+    (``observed_split``, two ranks or more): rank 0 runs the null model's chain on the observed light curve, rank 1 the
+    alternative's, nobody else any; rank 1's maximum and rank 0's maximum, posterior samples and seeds are broadcast,
+    so that all ranks test the same thing -- the chains are the ones one process runs (each model has a generator of its
+    own), hence the same ``T_obs`` to the last bit.  The returned ``null`` is then rank 0's alone and ``alt`` rank 1's
+    (``None`` elsewhere); ``observed_split=False``: every rank runs both and keeps both, rank 0's are everybody's test.
+    ``sim_null``, ``sim_alt`` and ``lightcurves`` hold the rank's own block.  ``split``: "lightcurves" as just described,
     "models" -- the first half of the ranks refits the null model, the second half the alternative, each over all the
     light curves (a rank then holds ``sim_null`` or ``sim_alt``, not both) --, "auto" picks by the rows a half-step
     leaves each rank (``_split_by_model``).
@@ -507,9 +511,18 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                     lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
                     extension_factor=extension_factor, random_state=0, device=device)
     sim.warm_up()
+    shard = None
+    if sharded:
+        from .distributed import LightcurveShard, all_gather_rows, block_bounds, broadcast_array
+        shard = LightcurveShard(nsims, group=group)
+    by_model = shard is not None and shard.world >= 2 and bool(observed_split)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        if walkers % 2 == 0 and observed_side_by_side:
+        if by_model:
+            # one model's chain per rank (0: null, 1: alternative), on the process's own context
+            null = observed(null_kernel, seeds[0]) if shard.rank == 0 else None
+            alt = observed(alt_kernel, seeds[1]) if shard.rank == 1 else None
+        elif walkers % 2 == 0 and observed_side_by_side:
             # two single-light-curve chains leave the GPU nearly empty: the two models side by side, each on a context
             # and a generator of its own -- the same chains as one after the other
             from concurrent.futures import ThreadPoolExecutor
@@ -524,25 +537,33 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     # one estimator on both sides of the test: the largest log-posterior over everything the chains
     # visited (the refits below store no chains and keep exactly that; the maximum over the burned-in,
     # thinned chain is systematically smaller, the more so the more parameters a model has)
-    t_obs = float(lrt_statistic(null.best_loglikelihood, alt.best_loglikelihood))
-    samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
+    if by_model:
+        alt_best = float(broadcast_array(np.array([alt.best_loglikelihood if alt is not None else 0.0]), group, src=1)[0])
+        null_best = float(null.best_loglikelihood) if null is not None else 0.0     # (rank 0's goes out with the head below)
+        ndim_null = null_kernel.vector_size if null is None else null.mcmc_samples.shape[1]
+        samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)] if null is not None \
+            else np.zeros((nsims, ndim_null))
+    else:
+        null_best, alt_best = float(null.best_loglikelihood), float(alt.best_loglikelihood)
+        samples = null.mcmc_samples[rng.integers(len(null.mcmc_samples), size=nsims)]
+    t_obs = float(lrt_statistic(null_best, alt_best))
     # (seeds below 2^52: they travel as float64 in the broadcast)
     sim_seed, fit_seeds = int(rng.integers(0, 2 ** 31 - 1)), [int(rng.integers(0, 2 ** 52)) for _ in range(2)]
     sw = sim_walkers or walkers
-    lo, hi, shard, models = 0, nsims, None, (0, 1)
+    lo, hi, models = 0, nsims, (0, 1)
     if sharded:
-        from .distributed import LightcurveShard, all_gather_rows, block_bounds, broadcast_array
-        shard = LightcurveShard(nsims, group=group)
         if reproducible is None:
             reproducible = _reproducible_is_free(split, nsims, sw, shard.world)
     reproducible = bool(reproducible)
     if sharded:
         # rank 0's test is everybody's test: its T_obs, its posterior samples and its seeds (every rank drew its own
         # from its own chains' generator state; under the model split two ranks must simulate the SAME light curves)
-        head = broadcast_array(np.concatenate([[t_obs, float(sim_seed)], np.asarray(fit_seeds, dtype=np.float64),
-                                               samples.ravel()]), group)
-        t_obs, sim_seed, fit_seeds = float(head[0]), int(head[1]), [int(head[2]), int(head[3])]
-        samples = head[4:].reshape(samples.shape)
+        head = broadcast_array(np.concatenate([[null_best, float(sim_seed)], np.asarray(fit_seeds, dtype=np.float64),
+                                               [t_obs], samples.ravel()]), group)
+        sim_seed, fit_seeds = int(head[1]), [int(head[2]), int(head[3])]
+        # split observed chains: rank 0's null maximum with rank 1's alternative maximum; otherwise rank 0's own T_obs
+        t_obs = float(lrt_statistic(float(head[0]), alt_best)) if by_model else float(head[4])
+        samples = head[5:].reshape(samples.shape)
         if _split_by_model(split, nsims, sw, shard.world):
             # half of the ranks refit the null model, the other half the alternative, each half over ALL the light
             # curves: twice the rows per rank and one model's half-steps instead of both one after the other

@@ -390,7 +390,7 @@ def _protassov_worker(rank, world, port, out_dir, split="lightcurves"):
     local = (-2.0 * (res["sim_null"].max_loglikelihood - res["sim_alt"].max_loglikelihood)) if both else np.empty(0)
     np.savez(os.path.join(out_dir, "pt%s%d_%d.npz" % (split[0], world, rank)), T_obs=res["T_obs"], T_sim=res["T_sim"],
              p=res["p_value"], n_local=n_local, local=local, has_null=res["sim_null"] is not None,
-             has_alt=res["sim_alt"] is not None)
+             has_alt=res["sim_alt"] is not None, obs_null=res["null"] is not None, obs_alt=res["alt"] is not None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -412,12 +412,15 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     assert float(r0["T_obs"]) == float(r1["T_obs"]) and float(r0["p"]) == float(r1["p"])
     assert np.array_equal(r0["T_sim"], r1["T_sim"]) and r0["T_sim"].shape == (5,)
     assert (int(r0["n_local"]), int(r1["n_local"])) == (3, 2)
+    # the observed light curve's chains are split by model: rank 0 ran the null model's, rank 1 the alternative's
+    assert (bool(r0["obs_null"]), bool(r0["obs_alt"]), bool(r1["obs_null"]), bool(r1["obs_alt"])) == (True, False, False, True)
     assert np.allclose(r0["T_sim"][:3], r0["local"], rtol=1e-12) and np.allclose(r0["T_sim"][3:], r1["local"], rtol=1e-12)
     assert np.all(np.isfinite(r0["T_sim"])) and 0.0 <= float(r0["p"]) <= 1.0
     # one rank alone holds everything and the unsharded call is untouched by the new arguments
     _spawn(_protassov_worker, (1, _free_port(), str(tmp_path)), 1, tmp_path)
     single = np.load(tmp_path / "ptl1_0.npz")
     assert int(single["n_local"]) == 5 and np.all(np.isfinite(single["T_sim"]))
+    assert bool(single["obs_null"]) and bool(single["obs_alt"])
     assert float(single["T_obs"]) == float(r0["T_obs"])                            # same seed, same observed chains
     # split by light curve: blocks of 3 and 2 against all 5 in one process -- other batch sizes in every launch, the
     # same numbers (noise and Philox streams keyed by global light-curve index, batch-independent kernels)
@@ -434,6 +437,7 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     _spawn(_protassov_worker, (3, _free_port(), str(tmp_path), "models"), 3, tmp_path)
     o = [np.load(tmp_path / ("ptm3_%d.npz" % r)) for r in range(3)]
     assert [int(x["n_local"]) for x in o] == [5, 5, 0]
+    assert [(bool(x["obs_null"]), bool(x["obs_alt"])) for x in o] == [(True, False), (False, True), (False, False)]
     assert all(np.array_equal(x["T_sim"], single["T_sim"]) and float(x["p"]) == float(single["p"]) for x in o)
 
 
