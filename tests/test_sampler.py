@@ -123,3 +123,69 @@ def test_integrated_time_ar1():
         integrated_time(x[:200, :, None], tol=50)
     assert integrated_time(x[:200, :, None], tol=50, quiet=True).shape == (1,)
     assert integrated_time(x[:, 0]).shape == (1,)
+
+
+def _appendix_b_replay(log_prob, p0, iterations, a=2.0):
+    """SURVEY.md Appendix B transcribed line by line, independently of mind_the_gaps_amd/sampler.py: emcee 3.1.4's
+    ``EnsembleSampler.sample`` with the default ``StretchMove(a=2)``, one walker at a time where emcee vectorises, on a
+    private RandomState that starts as a COPY of numpy's global state.  emcee itself is not installed in this image: this
+    replay of its published per-iteration draw order -- shuffle, rand(Ns), randint(Nc, size=Ns), one rand() per walker --
+    (and the choice of the move, below) is what pins the host sampler's stream (gpmodelling.py:247-248)."""
+    rs = np.random.RandomState()
+    rs.set_state(np.random.get_state())                      # "initialised with a copy of the global np.random state"
+    coords = np.array(p0, dtype=np.float64)
+    W, ndim = coords.shape
+    lnp = np.array([log_prob(x) for x in coords])            # lnP of p0 once (W evaluations)
+    chain = []
+    for _ in range(iterations):
+        # (not in Appendix B: emcee picks every iteration's move with RandomState.choice(moves, p=weights) -- one uniform
+        # from the same stream even when the stretch move is the only one; made here through the real call)
+        rs.choice(np.array([0]), p=[1.0])
+        inds = np.arange(W) % 2
+        rs.shuffle(inds)
+        for split in (0, 1):
+            S = np.flatnonzero(inds == split)
+            C = np.flatnonzero(inds != split)
+            s, c = coords[S], coords[C]
+            Ns, Nc = len(S), len(C)
+            zz = ((a - 1.0) * rs.rand(Ns) + 1.0) ** 2 / a
+            factors = (ndim - 1.0) * np.log(zz)
+            rint = rs.randint(Nc, size=Ns)
+            q = np.empty((Ns, ndim))
+            for j in range(Ns):
+                q[j] = c[rint[j]] - (c[rint[j]] - s[j]) * zz[j]
+            new = np.array([log_prob(x) for x in q])         # the batch: W / 2 evaluations
+            for j in range(Ns):                              # one rand() per walker, drawn in order
+                if factors[j] + new[j] - lnp[S[j]] > np.log(rs.rand()):
+                    coords[S[j]] = q[j]                      # the state is updated before the second half is proposed
+                    lnp[S[j]] = new[j]
+        chain.append(coords.copy())
+    return np.array(chain)
+
+
+def test_chain_is_the_replay_of_the_published_draw_order():
+    """50 iterations x 12 walkers on a correlated quadratic log-probability: the host sampler's chain equals the
+    independent transcription of SURVEY Appendix B value for value, and continues to after an interruption."""
+    A = np.array([[2.0, 0.6, 0.0], [0.6, 1.0, -0.3], [0.0, -0.3, 0.5]])
+    mu = np.array([0.3, -1.0, 2.0])
+
+    def quadratic(x):
+        d = np.atleast_2d(x) - mu
+        out = -0.5 * np.einsum("bi,ij,bj->b", d, A, d)
+        return out if np.ndim(x) == 2 else float(out[0])
+
+    p0 = mu + 0.5 * np.random.default_rng(4).standard_normal((12, 3))
+    np.random.seed(2024)
+    want = _appendix_b_replay(quadratic, p0, 50)
+    np.random.seed(2024)
+    s = EnsembleSampler(12, 3, quadratic)                    # vectorised: one call per half-ensemble
+    s.run_mcmc(p0, 20)
+    s.run_mcmc(None, 30)
+    got = s.get_chain()
+    assert got.shape == want.shape == (50, 12, 3)
+    assert np.array_equal(got, want)
+    assert 0.2 < s.acceptance_fraction.mean() < 0.95         # it moved: the equality is not that of a frozen chain
+    np.random.seed(2025)                                     # another global seed, another chain
+    other = EnsembleSampler(12, 3, quadratic)
+    other.run_mcmc(p0, 5)
+    assert not np.array_equal(other.get_chain(), want[:5])
