@@ -751,12 +751,16 @@ def main():
                     wf["ranks"] = world
                     # every rank's phases (a whole_test_s above the one-GPU share has to be findable: which rank, which phase)
                     phases = ("observed_chains", "simulate", "refit_null", "refit_alt", "gather")
-                    mine = torch.tensor([wf["seconds"].get(k, 0.0) for k in phases] + [wf["whole_test_s"]], dtype=torch.float64,
-                                        device=gdev)
+                    flag = {None: -1.0, False: 0.0, True: 1.0}
+                    mine = torch.tensor([wf["seconds"].get(k, 0.0) for k in phases] + [wf["whole_test_s"], flag[wf["null_converged"]],
+                                         flag[wf["alt_converged"]]], dtype=torch.float64, device=gdev)
                     every = torch.empty(world * mine.numel(), dtype=torch.float64, device=gdev)
                     dist.all_gather_into_tensor(every, mine)
                     every = every.cpu().numpy().reshape(world, -1)
                     wf["seconds_by_rank"] = {k: [round(float(v), 4) for v in every[:, i]] for i, k in enumerate(phases + ("whole_test_s",))}
+                    # the observed light curve's chains ran on rank 0 (null) and rank 1 (alternative): their verdicts
+                    wf["null_converged"] = bool(every[0, -2] > 0)
+                    wf["alt_converged"] = bool(every[min(1, world - 1), -1] > 0)
                     extras["workflow_config3_sharded"] = wf
                     # World-size invariance CHECKED on this node, not only printed: 16 simulated light curves through the same
                     # sharded path (two per rank at 8), then the same 16 by rank 0 alone -- T_obs, every T_sim and the
