@@ -35,3 +35,14 @@ def test_bench_flag_table_matches_the_contract():
     assert res.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--extras-timeout", "--no-workflow"):
         assert flag in res.stdout
+
+
+def test_design_table_is_in_sync_with_the_bench_line_on_file():
+    """DESIGN.md section 8's measured column is generated (scripts/design_table.py) from profiles/rNN_bench_line.json:
+    a new bench line without a regenerated table fails here, so the document cannot go stale behind the numbers."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, os.path.join(root, "scripts", "design_table.py"), "--check"], capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr
+    assert os.path.getsize(os.path.join(root, "DESIGN.md")) <= 40 * 1024      # a current-state document, not a notebook
