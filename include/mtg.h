@@ -230,6 +230,21 @@ MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
  */
 MTG_API int mtg_set_pipeline(mtg_ctx *ctx, int mode);
 /*
+ * Two contexts on one device whose pipelined half-steps go out in ONE launch (csrc/mtg_kernels_pipe_pair.hip): the null
+ * and the alternative kernel of the posterior-predictive test, which the reference fits to every simulated light curve
+ * one after the other (docs/notebooks/tutorial_ppp.ipynb:326-343) and which here advance side by side, each context
+ * driven by a host thread of its own.  A pipelined sweep takes a whole compute unit (its tables and rings fill the LDS),
+ * so two contexts' launches alternate on the compute units and leave every SIMD one wave that issues ~60 % of the time;
+ * paired, a workgroup of eight waves runs 128 rows of each model on one table set, two waves per SIMD.  Each call that
+ * would dispatch mtg_pipe_kernel meets its partner's (on the host, bounded wait: MTG_PAIR_PATIENCE_MS, default 250);
+ * a partner that does not come, another sampling or a pair of model shapes without a compiled kernel break the pair for
+ * good and both go on alone.  Results are those of the unpaired kernels to the last bit.  mtg_pair_stats: launches that
+ * were shared / made alone since pairing, and whether the pair is broken.  mtg_destroy unpairs.
+ */
+MTG_API int mtg_pair_contexts(mtg_ctx *a, mtg_ctx *b);
+MTG_API int mtg_unpair_contexts(mtg_ctx *ctx);
+MTG_API int mtg_pair_stats(const mtg_ctx *ctx, int64_t *paired_launches, int64_t *solo_launches, int *broken);
+/*
  * Speculative iterations of mtg_ensemble_run (default 1 = where they pay, 0 = never).  The time-parallel solve of a
  * small batch takes as long for three times the rows -- most of the GPU is idle -- and the second half-step of a
  * stretch-move iteration depends on the first only through each partner's coordinates: where it is, or where its own

@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -157,6 +159,33 @@ struct mtg_ctx {
     // timing of the walker-sharded exchange (mtg_ensemble_shard_profile): event pairs around the first exchanges of a run
     std::vector<hipEvent_t> shard_ev;
     int shard_ev_cap = 0, shard_ev_n = 0;
+
+    // mtg_pair_contexts: the partner whose pipelined half-steps share a launch with this context's (MtgPair below)
+    struct MtgPair *pair = nullptr;
+    int pair_index = 0;
+};
+
+// Two contexts whose pipelined sweeps go out in ONE launch (mtg_kernels_pipe_pair.hip): the two models of the Protassov
+// test, each driven by a host thread of its own (mtg_ensemble_run: a loop of asynchronous launches).  Whoever reaches
+// a pipelined half-step first leaves its arguments here, records `ready` on its stream and waits -- on the HOST, for as
+// long as the partner takes to get to its own half-step, microseconds in steady state --; the second one makes its
+// stream wait for `ready`, launches both models' rows in one grid, records `done`, and the first one's stream waits
+// for that.  Nothing waits without a bound: a partner that does not come within `patience_ms` (its run is over, its
+// batch took another kernel) breaks the pair for good and everybody launches alone from then on.
+struct MtgPair {
+    std::mutex mu;
+    std::condition_variable cv;
+    mtg_ctx *members[2] = {nullptr, nullptr};
+    hipEvent_t ready[2] = {nullptr, nullptr}, done = nullptr;
+    bool waiting = false;     // the slot holds a half-step
+    int who = 0;              // ... of this member
+    MtgSolveArgs sa;
+    int64_t rows = 0;
+    MtgPipeShapeId shape{};
+    uint64_t launched = 0;    // pair launches so far (a waiter leaves when it moves)
+    bool broken = false;
+    int patience_ms = 250;
+    int64_t n_pair = 0, n_solo = 0;
 };
 
 namespace {
@@ -373,6 +402,64 @@ bool sweep_multi_enabled()
     return on;
 }
 
+// A pipelined half-step of a paired context (MtgPair): *paired = 1 when its rows went out -- or will go out, ordered
+// before anything that follows on `s` -- in a launch shared with the partner's; 0: the caller launches alone.
+int pair_launch(mtg_ctx *ctx, const MtgSolveArgs &sa, int64_t B, const MtgPipeShapeId &shape, hipStream_t s, int *paired)
+{
+    MtgPair *p = ctx->pair;
+    const int me = ctx->pair_index;
+    *paired = 0;
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->broken) { p->n_solo += 1; return MTG_OK; }
+    if (!p->waiting) {
+        HIP_TRY(ctx, hipEventRecord(p->ready[me], s));
+        p->sa = sa; p->rows = B; p->shape = shape; p->who = me; p->waiting = true;
+        const uint64_t seen = p->launched;
+        p->cv.wait_for(lk, std::chrono::milliseconds(p->patience_ms), [&] { return p->launched != seen || p->broken; });
+        if (p->launched != seen) {   // the partner launched both
+            HIP_TRY(ctx, hipStreamWaitEvent(s, p->done, 0));
+            *paired = 1;
+            return MTG_OK;
+        }
+        p->waiting = false;          // nobody came (or the pair has no kernel): alone, now and from now on
+        p->broken = true;
+        p->n_solo += 1;
+        return MTG_OK;
+    }
+    // the partner's half-step is waiting: both in one launch, on this stream
+    const MtgSolveArgs &other = p->sa;
+    mtg_pipe_pair_launcher fn = nullptr;
+    bool mine_first = false;
+    if (other.N == sa.N && p->who != me) {
+        // (member 0's model first, as the pairs are listed: null, alternative; then the other way round)
+        const bool other_is_0 = p->who == 0;
+        fn = other_is_0 ? mtg_find_pipe_pair_solver(p->shape, shape) : mtg_find_pipe_pair_solver(shape, p->shape);
+        mine_first = !other_is_0;
+        if (!fn) {
+            fn = other_is_0 ? mtg_find_pipe_pair_solver(shape, p->shape) : mtg_find_pipe_pair_solver(p->shape, shape);
+            mine_first = other_is_0;
+        }
+    }
+    if (!fn) {   // different samplings, or a pair of shapes that is not compiled: both go alone from now on
+        p->broken = true;
+        p->n_solo += 1;
+        lk.unlock();
+        p->cv.notify_all();
+        return MTG_OK;
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(s, p->ready[p->who], 0));
+    if (mine_first) fn(sa, B, other, p->rows, s);
+    else fn(other, p->rows, sa, B, s);
+    HIP_TRY(ctx, hipEventRecord(p->done, s));
+    p->waiting = false;
+    p->launched += 1;
+    p->n_pair += 1;
+    *paired = 1;
+    lk.unlock();
+    p->cv.notify_all();
+    return MTG_OK;
+}
+
 // Launch the solver(s) for B prepared evaluations living in ctx->coef (lists / counts filled).
 // may_sort: the caller's order is arbitrary (mtg_loglike_batch[_device]); the device sampler's batches are grouped
 // by ensemble, hence by light curve, by construction.
@@ -509,8 +596,18 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         sa.count_ptr = nullptr;
         sa.seg_counts = nsig > 1 ? bank_counts(ctx) : nullptr;
         sa.seg_k = 0;
-        snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_pipe_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0);
-        pipe(sa, B, s);
+        const MtgPipeShapeId shape{m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0};
+        int paired = 0;
+        if (ctx->pair) {
+            const int rc = pair_launch(ctx, sa, B, shape, s, &paired);
+            if (rc) return rc;
+        }
+        if (paired) {
+            snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_pipe_pair_kernel (this model: <%d,%d,%d,%d>)", m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0);
+        } else {
+            snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_pipe_kernel<%d,%d,%d,%d>", m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0);
+            pipe(sa, B, s);
+        }
     } else if (mtg_solve_launcher multi = sorted && nsig > 1 && sa.yv_bytes <= sa.window_bytes && sweep_multi_enabled()
                                               ? mtg_find_multi_solver(m.nr0, m.nc0, nsig, m.last_b0) : nullptr) {
         // every structure of the sorted order in one launch of identical workgroups (mtg_kernels_multi.hip)
@@ -663,9 +760,12 @@ MTG_API mtg_ctx *mtg_create(int device) { return create_context(device, 0, 1); }
 
 MTG_API mtg_ctx *mtg_create_on_slice(int device, int part, int parts) { return create_context(device, part, parts); }
 
+MTG_API int mtg_unpair_contexts(mtg_ctx *ctx);
+
 MTG_API void mtg_destroy(mtg_ctx *ctx)
 {
     if (!ctx) return;
+    (void)mtg_unpair_contexts(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->foreign_pending) (void)hipEventSynchronize(ctx->foreign_done);
@@ -2008,6 +2108,62 @@ MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode)
 }
 
 MTG_API const char *mtg_last_solver(const mtg_ctx *ctx) { return ctx ? ctx->last_solver : ""; }
+
+MTG_API int mtg_unpair_contexts(mtg_ctx *ctx)
+{
+    if (!ctx) return MTG_E_ARG;
+    MtgPair *p = ctx->pair;
+    if (!p) return MTG_OK;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->broken = true;      // (nobody may be inside a paired call now: the callers' threads have returned)
+    }
+    p->cv.notify_all();
+    for (mtg_ctx *m : p->members)
+        if (m) { m->pair = nullptr; m->pair_index = 0; }
+    for (hipEvent_t e : {p->ready[0], p->ready[1], p->done})
+        if (e) (void)hipEventDestroy(e);
+    delete p;
+    return MTG_OK;
+}
+
+MTG_API int mtg_pair_contexts(mtg_ctx *a, mtg_ctx *b)
+{
+    if (!a || !b || a == b) return MTG_E_ARG;
+    if (a->device != b->device) return fail(a, MTG_E_ARG, "mtg_pair_contexts: the two contexts are on different devices");
+    if (a->pair || b->pair) return fail(a, MTG_E_STATE, "mtg_pair_contexts: a context is paired already (mtg_unpair_contexts first)");
+    int rc = use_device(a);
+    if (rc) return rc;
+    MtgPair *p = new (std::nothrow) MtgPair();
+    if (!p) return fail(a, MTG_E_HIP, "mtg_pair_contexts: out of memory");
+    bool ok = true;
+    for (hipEvent_t *e : {&p->ready[0], &p->ready[1], &p->done})
+        ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (const char *env = getenv("MTG_PAIR_PATIENCE_MS")) p->patience_ms = atoi(env) > 0 ? atoi(env) : p->patience_ms;
+    p->members[0] = a; p->members[1] = b;
+    a->pair = p; a->pair_index = 0;
+    b->pair = p; b->pair_index = 1;
+    if (!ok) {
+        mtg_unpair_contexts(a);
+        return fail(a, MTG_E_HIP, "mtg_pair_contexts: event creation failed");
+    }
+    return MTG_OK;
+}
+
+MTG_API int mtg_pair_stats(const mtg_ctx *ctx, int64_t *paired_launches, int64_t *solo_launches, int *broken)
+{
+    if (!ctx) return MTG_E_ARG;
+    MtgPair *p = ctx->pair;
+    if (paired_launches) *paired_launches = 0;
+    if (solo_launches) *solo_launches = 0;
+    if (broken) *broken = 0;
+    if (!p) return MTG_OK;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (paired_launches) *paired_launches = p->n_pair;
+    if (solo_launches) *solo_launches = p->n_solo;
+    if (broken) *broken = p->broken ? 1 : 0;
+    return MTG_OK;
+}
 
 MTG_API int mtg_synchronize(mtg_ctx *ctx)
 {

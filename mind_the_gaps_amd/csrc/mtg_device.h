@@ -154,6 +154,11 @@ mtg_solve_launcher mtg_find_multi_solver(int nr0, int nc0, int nsig, int last_b0
 // mtg_find_solver's kernels, nsig > 1: the sorted order and seg_counts as for mtg_find_multi_solver's
 mtg_solve_launcher mtg_find_pipe_solver(int nr0, int nc0, int nsig, int last_b0);
 #define MTG_PIPE_ROWS_PER_CU 128
+// two models' pipelined sweeps in ONE launch (mtg_kernels_pipe_pair.hip): a workgroup of eight waves runs a quartet of
+// each, two waves per SIMD sharing one table set; shapes as for mtg_find_pipe_solver; NULL = this pair is not compiled
+struct MtgPipeShapeId { int nr0, nc0, nsig, last_b0; };
+typedef void (*mtg_pipe_pair_launcher)(const MtgSolveArgs &a, int64_t nlanes_a, const MtgSolveArgs &b, int64_t nlanes_b, hipStream_t);
+mtg_pipe_pair_launcher mtg_find_pipe_pair_solver(const MtgPipeShapeId &a, const MtgPipeShapeId &b);
 // does mtg_find_solver(nr, nc, last_b0) return the b = 0 specialisation?
 int mtg_solver_uses_b0(int nr, int nc, int last_b0);
 void mtg_launch_lc_setup(int64_t N, int64_t L, int64_t t_rows, const double *t, const double *y,

@@ -12,79 +12,17 @@
 
 namespace {
 
-template <int NR, int NC, int LASTB0>
-struct PipeB0 { static constexpr int value = (LASTB0 && NC > 0 && NR < 5 && NC < 4 && NR + 2 * NC <= 6) ? 1 : 0; };
-
-template <int NR, int NC, int NB0, int CH>
-__device__ __forceinline__ void pipe_rows(const MtgSolveArgs &a, int64_t e, bool active, int wave, double2 *ring,
-                                          const MtgMathTables *tab)
-{
-    // the row's light curve (inside the one descriptor window: the launcher checks yv_bytes <= window_bytes)
-    uint32_t lc = a.lc_index ? (uint32_t)a.lc_index[e] : 0u;
-    const uint64_t lc_bytes = (uint64_t)a.N * 16u;
-    bool lost = false;
-    if (((uint64_t)lc + 1u) * lc_bytes > a.yv_bytes) { lost = active; lc = 0; active = false; }
-    const uint32_t yoff = (uint32_t)((uint64_t)lc * lc_bytes);
-    const uint32_t toff = a.t_stride ? yoff : 0u;
-    if (wave < 2) {
-        // table or libm sincos: decided per 64 rows exactly as mtg_solve_row decides it per wave
-        double dmax = 0.0;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) dmax = fmax(dmax, fabs(a.coef[e + a.lay.dc(k) * a.cstride]));
-        const bool fast = !__any(active && !(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
-        if (fast) mtg_pipe_produce<NR, NC, true, CH>(a, e, toff, ring, tab);
-        else mtg_pipe_produce<NR, NC, false, CH>(a, e, toff, ring, tab);
-    } else {
-        if (lost) {  // a device-side lc_index outside the resident set: no likelihood (as mtg_solve_row)
-            a.out[e] = -INFINITY;
-            a.status[e] = MTG_ST_NONFINITE;
-        }
-        if (a.has_mean) mtg_pipe_consume<NR, NC, NB0, true, CH>(a, e, active, yoff, toff, ring);
-        else mtg_pipe_consume<NR, NC, NB0, false, CH>(a, e, active, yoff, toff, ring);
-    }
-}
-
-template <int NR0, int NC0, int NSIG, int LASTB0, int CH, int S = 0>
-__device__ __forceinline__ void pipe_dispatch(int k, const MtgSolveArgs &a, int64_t e, bool active, int wave,
-                                              double2 *ring, const MtgMathTables *tab)
-{
-    if (k == S) pipe_rows<NR0 + 2 * S, NC0 - S, PipeB0<NR0 + 2 * S, NC0 - S, LASTB0>::value, CH>(a, e, active, wave, ring, tab);
-    else if constexpr (S + 1 < NSIG) pipe_dispatch<NR0, NC0, NSIG, LASTB0, CH, S + 1>(k, a, e, active, wave, ring, tab);
-}
-
 template <int NR0, int NC0, int NSIG, int LASTB0>
 __global__ void __launch_bounds__(MTG_PIPE_BLOCK, 1) mtg_pipe_kernel(MtgSolveArgs a)
 {
     constexpr int N2 = MtgPipeShape<NR0, NC0>::N2;   // the widest hand-over: the structure with every SHO under-damped
-    // workgroup -> (structure, first row of the workgroup inside the structure's segment)
-    int64_t block = blockIdx.x, first = 0, count = 0;
-    int k = 0;
-    if (NSIG > 1) {
-        for (; k < NSIG; ++k) {
-            count = a.seg_counts[k];
-            const int64_t blocks = (count + MTG_PIPE_ROWS - 1) / MTG_PIPE_ROWS;
-            if (block < blocks) break;
-            block -= blocks;
-            first += count;
-        }
-        if (k == NSIG) return;  // the grid is sized for the worst padding
-    } else {
-        count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
-        if (block * MTG_PIPE_ROWS >= count) return;
-    }
-    __shared__ MtgMathTables tab;
     constexpr int CH = mtg_pipe_chunk(N2);
-    __shared__ double2 ring[2][MTG_PIPE_RING * CH * N2 * 64];
+    __shared__ MtgMathTables tab;
+    __shared__ double2 ring[2 * MTG_PIPE_RING * CH * N2 * 64];
+    if (!mtg_pipe_has_block<NSIG>(a, blockIdx.x)) return;
     mtg_fill_tables(&tab, threadIdx.x, MTG_PIPE_BLOCK);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, pair = wave & 1, lane = threadIdx.x & 63;
-    const int64_t gid = block * MTG_PIPE_ROWS + pair * 64 + lane;
-    bool active = gid < count;
-    // idle lanes walk along on row 0 of the batch (any row with readable coefficients) and store nothing
-    int64_t e = 0;
-    if (active) e = a.list ? (int64_t)a.list[first + gid] : gid;
-    if (active && a.status[e] != MTG_ST_OK) active = false;  // prior said -inf, or another rank's row
-    pipe_dispatch<NR0, NC0, NSIG, LASTB0, CH>(k, a, e, active, wave, &ring[pair][lane], &tab);
+    mtg_pipe_quartet<NR0, NC0, NSIG, LASTB0, CH>(a, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, ring, &tab);
 }
 
 template <int NR0, int NC0, int NSIG, int LASTB0>

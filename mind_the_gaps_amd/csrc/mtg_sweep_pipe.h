@@ -372,4 +372,95 @@ __device__ __forceinline__ void mtg_pipe_consume(const MtgSolveArgs &a, int64_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One QUARTET (producers of pair 0 and 1, consumers of pair 0 and 1; 128 rows) of a launch over all structures of a
+// model -- the body of mtg_pipe_kernel (mtg_kernels_pipe.hip) and of either half of mtg_pipe_pair_kernel
+// (mtg_kernels_pipe_pair.hip: two models' quartets in one workgroup).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NR, int NC, int LASTB0>
+struct MtgPipeB0 { static constexpr int value = (LASTB0 && NC > 0 && NR < 5 && NC < 4 && NR + 2 * NC <= 6) ? 1 : 0; };
+
+template <int NR, int NC, int NB0, int CH>
+__device__ __forceinline__ void mtg_pipe_rows(const MtgSolveArgs &a, int64_t e, bool active, int wave, double2 *ring,
+                                              const MtgMathTables *tab)
+{
+    // the row's light curve (inside the one descriptor window: the launcher checks yv_bytes <= window_bytes)
+    uint32_t lc = a.lc_index ? (uint32_t)a.lc_index[e] : 0u;
+    const uint64_t lc_bytes = (uint64_t)a.N * 16u;
+    bool lost = false;
+    if (((uint64_t)lc + 1u) * lc_bytes > a.yv_bytes) { lost = active; lc = 0; active = false; }
+    const uint32_t yoff = (uint32_t)((uint64_t)lc * lc_bytes);
+    const uint32_t toff = a.t_stride ? yoff : 0u;
+    if (wave < 2) {
+        // table or libm sincos: decided per 64 rows exactly as mtg_solve_row decides it per wave
+        double dmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) dmax = fmax(dmax, fabs(a.coef[e + a.lay.dc(k) * a.cstride]));
+        const bool fast = !__any(active && !(dmax * *a.dxmax <= MTG_TRIG_FAST_MAX));
+        if (fast) mtg_pipe_produce<NR, NC, true, CH>(a, e, toff, ring, tab);
+        else mtg_pipe_produce<NR, NC, false, CH>(a, e, toff, ring, tab);
+    } else {
+        if (lost) {  // a device-side lc_index outside the resident set: no likelihood (as mtg_solve_row)
+            a.out[e] = -INFINITY;
+            a.status[e] = MTG_ST_NONFINITE;
+        }
+        if (a.has_mean) mtg_pipe_consume<NR, NC, NB0, true, CH>(a, e, active, yoff, toff, ring);
+        else mtg_pipe_consume<NR, NC, NB0, false, CH>(a, e, active, yoff, toff, ring);
+    }
+}
+
+template <int NR0, int NC0, int NSIG, int LASTB0, int CH, int S = 0>
+__device__ __forceinline__ void mtg_pipe_dispatch(int k, const MtgSolveArgs &a, int64_t e, bool active, int wave,
+                                                  double2 *ring, const MtgMathTables *tab)
+{
+    if (k == S) mtg_pipe_rows<NR0 + 2 * S, NC0 - S, MtgPipeB0<NR0 + 2 * S, NC0 - S, LASTB0>::value, CH>(a, e, active, wave, ring, tab);
+    else if constexpr (S + 1 < NSIG) mtg_pipe_dispatch<NR0, NC0, NSIG, LASTB0, CH, S + 1>(k, a, e, active, wave, ring, tab);
+}
+
+// workgroup `block` -> (structure k, index of the block inside the structure's segment, rows before the segment, rows
+// of the segment); false: the grid is sized for the worst padding and this block has no rows
+template <int NSIG>
+__device__ __forceinline__ bool mtg_pipe_locate(const MtgSolveArgs &a, int64_t &block, int &k, int64_t &first, int64_t &count)
+{
+    k = 0; first = 0; count = 0;
+    if (NSIG > 1) {
+        for (; k < NSIG; ++k) {
+            count = a.seg_counts[k];
+            const int64_t blocks = (count + MTG_PIPE_ROWS - 1) / MTG_PIPE_ROWS;
+            if (block < blocks) break;
+            block -= blocks;
+            first += count;
+        }
+        return k < NSIG;
+    }
+    count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    return block * MTG_PIPE_ROWS < count;
+}
+template <int NSIG>
+__device__ __forceinline__ bool mtg_pipe_has_block(const MtgSolveArgs &a, int64_t block)
+{
+    int k;
+    int64_t first, count;
+    return mtg_pipe_locate<NSIG>(a, block, k, first, count);
+}
+
+// wave 0..3 of the quartet (0, 1 producers; 2, 3 consumers), ring = [2 pairs][MTG_PIPE_RING * CH * N2 * 64] slots
+template <int NR0, int NC0, int NSIG, int LASTB0, int CH>
+__device__ __forceinline__ void mtg_pipe_quartet(const MtgSolveArgs &a, int64_t block, int wave, int lane, double2 *ring,
+                                                 const MtgMathTables *tab)
+{
+    constexpr int N2 = MtgPipeShape<NR0, NC0>::N2;
+    int k;
+    int64_t first, count;
+    if (!mtg_pipe_locate<NSIG>(a, block, k, first, count)) return;
+    const int pair = wave & 1;
+    const int64_t gid = block * MTG_PIPE_ROWS + pair * 64 + lane;
+    bool active = gid < count;
+    // idle lanes walk along on row 0 of the batch (any row with readable coefficients) and store nothing
+    int64_t e = 0;
+    if (active) e = a.list ? (int64_t)a.list[first + gid] : gid;
+    if (active && a.status[e] != MTG_ST_OK) active = false;  // prior said -inf, or another rank's row
+    mtg_pipe_dispatch<NR0, NC0, NSIG, LASTB0, CH>(k, a, e, active, wave, ring + pair * (MTG_PIPE_RING * CH * N2 * 64) + lane, tab);
+}
+
 #endif  // MTG_SWEEP_PIPE_H

@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
 
@@ -247,6 +247,12 @@ def load_library():
     lib.mtg_fft_warmup.argtypes = [c_vp]
     lib.mtg_simulate_plan.restype = c_int
     lib.mtg_simulate_plan.argtypes = [c_vp, c_i64]
+    lib.mtg_pair_contexts.restype = c_int
+    lib.mtg_pair_contexts.argtypes = [c_vp, c_vp]
+    lib.mtg_unpair_contexts.restype = c_int
+    lib.mtg_unpair_contexts.argtypes = [c_vp]
+    lib.mtg_pair_stats.restype = c_int
+    lib.mtg_pair_stats.argtypes = [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]
     lib.mtg_set_sort.restype = c_int
     lib.mtg_set_sort.argtypes = [c_vp, c_int]
     lib.mtg_set_stream_base.restype = c_int
@@ -751,6 +757,20 @@ class Engine:
         """0: never the two-wave pipeline of the serial sweep, 1: whenever compiled, 2 (default): for batches of ~8e3 to
         128 rows per compute unit (include/mtg.h: mtg_set_pipeline)."""
         self._check(self._lib.mtg_set_pipeline(self._ctx, int(mode)))
+
+    def pair_with(self, other):
+        """This context's pipelined half-steps and ``other``'s go out in one launch from now on (include/mtg.h:
+        mtg_pair_contexts): the two models of the Protassov test refitted side by side, each from a thread of its own."""
+        self._check(self._lib.mtg_pair_contexts(self._ctx, other._ctx))
+
+    def unpair(self):
+        self._check(self._lib.mtg_unpair_contexts(self._ctx))
+
+    def pair_stats(self):
+        """{"paired": launches shared with the partner, "solo": pipelined launches made alone, "broken": bool} since pairing."""
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+        self._check(self._lib.mtg_pair_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"paired": int(a.value), "solo": int(b.value), "broken": bool(c.value)}
 
     @property
     def last_solver(self):

@@ -580,7 +580,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
         if not reproducible:
             sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)   # independent noise on every block (the two ranks
             fit_seeds = [f + 7919 * block for f in fit_seeds]       # of a block under the model split draw the same)
-    out, fits, best, failure = None, [None, None], [np.empty(0), np.empty(0)], None
+    out, fits, best, failure, pair_stats = None, [None, None], [np.empty(0), np.empty(0)], None, None
     # each model on a context of its own (MTG_PPP_CU_SLICES=1: and on its own half of the compute units,
     # mtg_create_on_slice -- measured no faster: 7.24 against 7.14 ms per iteration)
     side_by_side = len(models) == 2 and (concurrent_refits is True or
@@ -621,8 +621,20 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                     # leaves no idle issue slots for the other model to fill; on a block that leaves the GPU room (a rank's
                     # 250 light curves at 8 GPUs) the two chains interleave and gain 16 %: "auto" (docstring).
                     from concurrent.futures import ThreadPoolExecutor
-                    with ThreadPoolExecutor(max_workers=2) as pool:
-                        futures = [pool.submit(refit, k) for k in (0, 1)]
+                    from .gp import get_side_engine
+                    # ... and, the two contexts paired, the two models' pipelined half-steps go out in ONE launch
+                    # (mtg_pair_contexts: eight waves per compute unit on one table set, two per SIMD -- a pipelined
+                    # sweep alone takes the whole compute unit, so unpaired launches alternate rather than share SIMDs)
+                    paired = side_by_side is True and os.environ.get("MTG_PPP_PAIR", "1") != "0"
+                    if paired:
+                        get_side_engine(device, 0).pair_with(get_side_engine(device, 1))
+                    try:
+                        with ThreadPoolExecutor(max_workers=2) as pool:
+                            futures = [pool.submit(refit, k) for k in (0, 1)]
+                    finally:
+                        if paired:
+                            pair_stats = get_side_engine(device, 0).pair_stats()
+                            get_side_engine(device, 0).unpair()
                     errors = [f.exception() for f in futures if f.exception() is not None]
                     if errors:   # the refit that failed, not the partner it left at the barrier
                         real = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)]
@@ -670,6 +682,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
         if len(clock) == 6 else {"observed_chains": clock[1] - clock[0]}
     return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
                 sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds, reproducible=reproducible,
+                paired_launches=pair_stats,
                 split=None if not sharded else ("models" if len(models) < 2 else "lightcurves"))
 
 

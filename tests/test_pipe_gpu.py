@@ -249,3 +249,100 @@ def test_shipped_shape_against_the_oracle(pipe, name):
     assert ok.sum() > 31000
     assert np.all(np.isneginf(got[gst == 1]))
     assert np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
+
+
+def _two_models(N=1000, L=9, W=40, seed=3):
+    """Two contexts on the same light curves: DRW + SHO (null) and DRW + SHO + Lorentzian (alternative)."""
+    from mind_the_gaps_amd.engine import Engine
+    t, y, dy = synth.make_lightcurves(N, L, seed=seed)
+    engines, thetas, kinds_of = [], [], (MODELS["null_drw_sho"], MODELS["alt_drw_sho_lorentzian"])
+    lc = np.repeat(np.arange(L, dtype=np.int32), W)
+    for i, kinds in enumerate(kinds_of):
+        eng = Engine(0)
+        full, free, bounds = synth.model_spec(kinds, y, per_lc_mean=True)
+        eng.set_lightcurves(t, y, dy + 1e-12, y_offset=y.mean(axis=1))
+        eng.set_model(kinds, full, free, bounds)
+        eng.set_time_parallel(0)
+        eng.set_pipeline(1)
+        th = synth.draw_thetas(kinds, L * W, seed=seed + 10 + i, percent=0.5)     # both SHO regimes
+        th[::53, 0] = 60.0                                                       # a few rows outside the prior box
+        engines.append(eng)
+        thetas.append(th)
+    return engines, thetas, lc
+
+
+def _both_at_once(engines, thetas, lc, rounds=1):
+    """Every engine's batch from a thread of its own, `rounds` times -> [(lnP, status, solver) of the last round]."""
+    import threading
+    out = [None, None]
+
+    def run(i):
+        for _ in range(rounds):
+            got = engines[i].loglike(thetas[i], lc, add_prior=True)
+            out[i] = (got[0], got[1], engines[i].last_solver)
+    threads = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    return out
+
+
+@pytest.mark.parametrize("N", [64, 70, 1001])
+def test_paired_contexts_share_a_launch_and_keep_every_bit(N):
+    """mtg_pair_contexts: the pipelined half-steps of two models in one launch of eight-wave workgroups
+    (csrc/mtg_kernels_pipe_pair.hip).  Same rows, same bits as each model's own mtg_pipe_kernel -- odd and even numbers of
+    two-sample chunks, both SHO regimes, prior rejections, grids of different sizes (the models' segments pad
+    differently) --, in either order of pairing, repeatedly."""
+    engines, thetas, lc = _two_models(N=N)
+    try:
+        alone = [engines[i].loglike(thetas[i], lc, add_prior=True) + (engines[i].last_solver,) for i in (0, 1)]
+        assert all("mtg_pipe_kernel" in a[2] for a in alone)
+        for first, second in ((0, 1), (1, 0)):
+            engines[first].pair_with(engines[second])
+            got = _both_at_once(engines, thetas, lc, rounds=3)
+            stats = engines[0].pair_stats()
+            engines[0].unpair()
+            assert stats == {"paired": 3, "solo": 0, "broken": False}, stats
+            for i in (0, 1):
+                assert "mtg_pipe_pair_kernel" in got[i][2], got[i][2]
+                assert np.array_equal(got[i][1], alone[i][1])
+                assert np.array_equal(got[i][0], alone[i][0])          # -inf where rejected, bit for bit elsewhere
+        assert engines[1].pair_stats() == {"paired": 0, "solo": 0, "broken": False}     # unpaired: nothing to report
+    finally:
+        for eng in engines:
+            eng.close()
+
+
+def test_a_partner_that_does_not_come_breaks_the_pair_not_the_run(monkeypatch):
+    """A paired context whose partner never reaches a pipelined half-step waits MTG_PAIR_PATIENCE_MS once, launches alone
+    and never waits again; a pair of shapes without a compiled kernel goes alone as well.  Same results."""
+    import time
+    monkeypatch.setenv("MTG_PAIR_PATIENCE_MS", "40")
+    engines, thetas, lc = _two_models(N=300)
+    try:
+        alone = engines[1].loglike(thetas[1], lc, add_prior=True)
+        engines[0].pair_with(engines[1])
+        t0 = time.perf_counter()
+        got = engines[1].loglike(thetas[1], lc, add_prior=True)        # the partner never calls
+        waited = time.perf_counter() - t0
+        again = engines[1].loglike(thetas[1], lc, add_prior=True)
+        stats = engines[1].pair_stats()
+        engines[1].unpair()
+        assert "mtg_pipe_kernel" in engines[1].last_solver
+        assert np.array_equal(got[0], alone[0]) and np.array_equal(again[0], alone[0])
+        assert stats == {"paired": 0, "solo": 2, "broken": True} and 0.03 < waited < 2.0
+        # the same model twice is not a pair the library has a kernel for: both go alone, at once
+        full_kinds = MODELS["alt_drw_sho_lorentzian"]
+        t, y, dy = synth.make_lightcurves(300, 9, seed=3)
+        full, free, bounds = synth.model_spec(full_kinds, y, per_lc_mean=True)
+        engines[0].set_model(full_kinds, full, free, bounds)
+        engines[0].pair_with(engines[1])
+        both = _both_at_once(engines, [thetas[1], thetas[1]], lc)
+        stats = engines[0].pair_stats()
+        engines[0].unpair()
+        assert stats["paired"] == 0 and stats["broken"] and stats["solo"] == 2
+        assert np.array_equal(both[0][0], alone[0]) and np.array_equal(both[1][0], alone[0])
+    finally:
+        for eng in engines:
+            eng.close()
