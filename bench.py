@@ -912,6 +912,15 @@ def main():
         eng.set_model(kinds, full, free, bounds)
         mid["what"] = ("prepare + sort + solve of one half-step of %d light curves x %d proposals, N = %d: what one GPU of 8 "
                        "runs 1002 times per model in the configs[3] workflow" % (Lm, Wm, N))
+        # ... and both models' half-steps at once, as the side-by-side refits run them: from two contexts, and with the
+        # contexts paired (one launch of eight-wave workgroups: csrc/mtg_kernels_pipe_pair.hip)
+        import importlib.util
+        spec_pp = importlib.util.spec_from_file_location("pair_probe", os.path.join(ROOT, "scripts", "pair_probe.py"))
+        pair_probe = importlib.util.module_from_spec(spec_pp)
+        spec_pp.loader.exec_module(pair_probe)
+        mid["both_models"] = pair_probe.run(L=Lm, W=Wm, N=N, device=local_dev)
+        if not mid["both_models"]["bitwise_equal_to_unpaired"]:
+            raise SystemExit("bench: the paired launch of both models differs from the unpaired kernels")
         extras["mid_batch_half_step"] = mid
         # (f) what HBM can actually stream on this box: a device-to-device copy of 2 GiB (read + write bytes / time),
         # beside the vendor's 8 TB/s that `roofline.peak` quotes

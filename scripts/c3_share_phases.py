@@ -14,7 +14,9 @@ def traced(*a, **k):
           {x: round(v, 3) for x, v in r.seconds.items()}, t0 - T0, time.perf_counter() - T0), flush=True)
     return r
 ppp.derive_posteriors_batch = traced
-for mode in (False, "auto", False, "auto"):
+for mode, pair in ((False, "1"), ("auto", "0"), ("auto", "1"), ("auto", "0"), ("auto", "1")):
+    os.environ["MTG_PPP_PAIR"] = pair       # side by side: the two contexts' pipelined half-steps in one launch (1) or not (0)
     T0 = time.perf_counter()
     d = probe.run(250, concurrent_refits=mode)
-    print("mode %r: whole %.3f s, refits %.3f s" % (mode, d["whole_test_s"], d["seconds"]["refit_null"] + d["seconds"]["refit_alt"]), flush=True)
+    print("mode %r pair %s: whole %.3f s, refits %.3f s, p = %.10f, T_sim checksum %.12f" % (
+        mode, pair, d["whole_test_s"], d["seconds"]["refit_null"] + d["seconds"]["refit_alt"], d["p_value"], d["T_sim_checksum"]), flush=True)
