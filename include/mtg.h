@@ -218,6 +218,14 @@ MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode);
  * mtg_simulate_tk95; enters random counters only, never an address.
  */
 MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index);
+/*
+ * mtg_simulate_tk95 transforms a grid length with large prime factors (the reference's grid arithmetic, simulator.py:259-262,
+ * gives BASELINE configs[3] 1 087 853 = 13^2 x 41 x 157 points) on power-of-two transforms by hand (chirp-z), two real
+ * series per complex transform: hipFFT's own plan for such a length takes 0.9 s to build.  on = 0: one series per
+ * transform, so that a series' values do not depend on which other series the call holds -- what a set simulated in
+ * blocks over several GPUs needs to be the set of one call, bit for bit (with mtg_set_stream_base); default 1.
+ */
+MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on);
 MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
 /*
  * The serial sweep as a two-wave pipeline (csrc/mtg_kernels_pipe.hip): 0 = never, 1 = whenever the model has the

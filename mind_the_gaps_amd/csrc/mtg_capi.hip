@@ -130,6 +130,16 @@ struct mtg_ctx {
     // series than that batch: a single light curve runs ONE transform); each remade when its (length, batch) changes
     struct SimPlan { hipfftHandle h = 0; bool have = false; int64_t nfft = 0; int batch = 0; } sim_plans[2];
     DevBuf sim_spec, sim_series;
+    // ... and the hand-made chirp-z transform for lengths hipFFT would take through a Bluestein plan (0.9 s to build
+    // against 15 ms for the power-of-two plans this needs; mtg_simulate.hip): chirp w [nfft], transform of the wrapped
+    // conjugate chirp [m], work area [pairs][m], Z2Z plans of length m ([0] the bulk batch, [1] a short call's)
+    struct SimCzt {
+        bool tables = false;
+        bool pairs_on = true;   // two series per complex transform (mtg_set_simulate_pairs)
+        int64_t nfft = 0, m = 0;
+        DevBuf chirp, bhat, work;
+        struct { hipfftHandle h = 0; bool have = false; int64_t m = 0; int pairs = 0; } plans[2];
+    } czt;
 
     // side streams: the structures (signatures) of a small batch run next to each other
     hipStream_t side[MTG_MAX_J / 2] = {};
@@ -781,6 +791,8 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
         std::lock_guard<std::mutex> plans(g_fft_plan_mu);
         if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
         for (auto &sp : ctx->sim_plans)
+            if (sp.have) (void)hipfftDestroy(sp.h);
+        for (auto &sp : ctx->czt.plans)
             if (sp.have) (void)hipfftDestroy(sp.h);
     }
     ctx->sim_spec.release();
@@ -1698,15 +1710,17 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
     return MTG_OK;
 }
 
-// transforms per execution of the simulator's plan: for a full call a function of the length alone, so that one plan
-// serves every such call (16 transforms of 10^6 points fill the GPU; short transforms are batched by the hundred) -- as
-// long as the spectrum and series buffers of one execution, 16 nk + 8 nfft bytes per transform, stay within 2 GiB: a
-// series of 2^30 points (the longest mtg_simulate_plan accepts) is transformed one at a time.  A call of fewer series
-// than that (S: Simulator.generate_lightcurve() asks for ONE) gets a batch of S
+// transforms per execution of the simulator's hipFFT plan (lengths hipFFT transforms natively; the others take the
+// chirp-z path below): a function of the length alone for a full call, so that one plan serves every such call (16
+// transforms of 10^6 points fill the GPU; short transforms are batched by the hundred; MTG_SIM_BATCH overrides, for
+// measurements) -- as long as the spectrum and series buffers of one execution, 16 nk + 8 nfft bytes per transform, stay
+// within 2 GiB.  A call of fewer series than that (Simulator.generate_lightcurve() asks for ONE) gets a plan of its own
+// size in the context's second slot: no transforms of empty slots, and a native plan costs milliseconds to build.
 static int sim_batch_for(int64_t nfft, int64_t S = INT64_MAX)
 {
     int64_t b = ((int64_t)1 << 24) / nfft;
     b = b < 16 ? 16 : b > 256 ? 256 : b;
+    if (const char *env = getenv("MTG_SIM_BATCH")) b = atoi(env) > 0 ? atoi(env) : b;
     const int64_t fit = ((int64_t)1 << 31) / (16 * (nfft / 2 + 1) + 8 * nfft);
     if (b > fit) b = fit;
     if (b > S) b = S;   // fewer series than a full batch: no transforms of empty slots
@@ -1732,10 +1746,83 @@ static int sim_plan_get(mtg_ctx *ctx, int64_t nfft, int64_t S, hipfftHandle *pla
     return MTG_OK;
 }
 
+// ---- the chirp-z path (mtg_simulate.hip) ----
+static int64_t czt_length(int64_t nfft)
+{
+    int64_t m = 1;
+    while (m < 2 * nfft - 1) m <<= 1;
+    return m;
+}
+// lengths hipFFT transforms natively (radices 2 .. 13) keep its Z2D plan; anything with a larger prime factor goes through
+// power-of-two transforms -- while one pair's work area (16 m bytes) stays within 2 GiB.  MTG_SIM_CZT=0 / 1 forces.
+static bool sim_wants_czt(int64_t nfft)
+{
+    if (const char *env = getenv("MTG_SIM_CZT")) return atoi(env) != 0 && czt_length(nfft) * 16 <= ((int64_t)1 << 31);
+    int64_t r = nfft;
+    for (int64_t f : {2, 3, 5, 7, 11, 13})
+        while (r % f == 0) r /= f;
+    return r > 1 && czt_length(nfft) * 16 <= ((int64_t)1 << 31);
+}
+// complex transforms per execution (each carries `per` = 2 series, or 1 with pairing off): up to 1 GiB of work area, no more
+// than the call needs
+static int czt_pairs_for(int64_t m, int64_t S = INT64_MAX, int per = 2)
+{
+    int64_t pairs = ((int64_t)1 << 30) / (m * 16);
+    pairs = pairs < 1 ? 1 : pairs > 128 ? 128 : pairs;
+    const int64_t need = S == INT64_MAX ? pairs : (S + per - 1) / per;
+    return (int)(pairs < need ? pairs : need);
+}
+static int czt_plan_get(mtg_ctx *ctx, int64_t m, int pairs, hipfftHandle *plan)
+{
+    std::lock_guard<std::mutex> lock(ctx->sim_mu);
+    auto &sp = ctx->czt.plans[pairs == czt_pairs_for(m) ? 0 : 1];
+    if (!(sp.have && sp.m == m && sp.pairs == pairs)) {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
+        if (sp.have) { (void)hipfftDestroy(sp.h); sp.have = false; }
+        if (hipfftPlan1d(&sp.h, (int)m, HIPFFT_Z2Z, pairs) != HIPFFT_SUCCESS) return MTG_E_HIP;
+        sp.have = true;
+        sp.m = m;
+        sp.pairs = pairs;
+    }
+    if (plan) *plan = sp.h;
+    return MTG_OK;
+}
+// chirp and transformed wrapped chirp of length nfft, made on `s` the first time a length is used
+static int czt_tables_get(mtg_ctx *ctx, int64_t nfft, hipStream_t s)
+{
+    mtg_ctx::SimCzt &z = ctx->czt;
+    const int64_t m = czt_length(nfft);
+    if (z.tables && z.nfft == nfft) return MTG_OK;
+    z.tables = false;
+    if (z.chirp.reserve((size_t)nfft * 16) != hipSuccess || z.bhat.reserve((size_t)m * 16) != hipSuccess) return MTG_E_HIP;
+    mtg_launch_czt_tables(nfft, m, z.chirp.as<double2>(), z.bhat.as<double2>(), s);
+    hipfftHandle one = 0;
+    {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
+        if (hipfftPlan1d(&one, (int)m, HIPFFT_Z2Z, 1) != HIPFFT_SUCCESS) return MTG_E_HIP;
+    }
+    bool ok = hipfftSetStream(one, s) == HIPFFT_SUCCESS &&
+              hipfftExecZ2Z(one, (hipfftDoubleComplex *)z.bhat.p, (hipfftDoubleComplex *)z.bhat.p, HIPFFT_FORWARD) == HIPFFT_SUCCESS;
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;    // (the plan's own work area goes with the plan)
+    {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
+        (void)hipfftDestroy(one);
+    }
+    if (!ok) return MTG_E_HIP;
+    z.tables = true;
+    z.nfft = nfft;
+    z.m = m;
+    return MTG_OK;
+}
+
 MTG_API int mtg_simulate_plan(mtg_ctx *ctx, int64_t nfft)
 {
     if (!ctx || nfft < 4 || nfft > ((int64_t)1 << 30)) return MTG_E_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return MTG_E_HIP;   // (HIP's current device is per thread)
+    if (sim_wants_czt(nfft)) {   // the bulk plan of the power-of-two transforms (milliseconds); the tables at first use
+        const int64_t m = czt_length(nfft);
+        return czt_plan_get(ctx, m, czt_pairs_for(m), nullptr);
+    }
     return sim_plan_get(ctx, nfft, INT64_MAX, nullptr);   // the bulk plan
 }
 
@@ -1776,7 +1863,11 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     const int64_t nk = nfft / 2 + 1;
     // the simulations go through the context's plan `chunk` at a time (the last group may be short: the transforms of
     // the unused slots run on whatever the buffer holds and are not looked at)
-    const int64_t chunk = sim_batch_for(nfft, S);
+    const bool czt = sim_wants_czt(nfft);
+    const int64_t czt_m = czt ? czt_length(nfft) : 0;
+    const int czt_per = ctx->czt.pairs_on ? 2 : 1;   // series per complex transform
+    const int czt_pairs = czt ? czt_pairs_for(czt_m, S, czt_per) : 0;
+    const int64_t chunk = czt ? czt_per * (int64_t)czt_pairs : sim_batch_for(nfft, S);
     DevBuf &spec = ctx->sim_spec, &series = ctx->sim_series;
     DevBuf d_lo, d_hi, d_expo, d_clean, d_rates, d_dy, d_sig, d_means, d_psd, d_seg;
     hipError_t e = hipSuccess;
@@ -1818,7 +1909,10 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     hipfftHandle plan = 0;
     if (e == hipSuccess) {
         what = "hipfftPlan1d";
-        if (sim_plan_get(ctx, nfft, S, &plan) != MTG_OK || hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
+        const int prc = czt ? (czt_tables_get(ctx, nfft, s) != MTG_OK || ctx->czt.work.reserve((size_t)czt_pairs * czt_m * 16) != hipSuccess
+                                   ? MTG_E_HIP : czt_plan_get(ctx, czt_m, czt_pairs, &plan))
+                            : sim_plan_get(ctx, nfft, S, &plan);
+        if (prc != MTG_OK || hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
             cleanup();
             return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipFFT plan creation failed (nfft = %lld, batch = %lld)",
                         (long long)nfft, (long long)chunk);
@@ -1832,12 +1926,30 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         mtg_launch_tk95_spectrum(sc, s0, ctx->stream_base, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
                                  d_sig.as<int32_t>(), psd_table ? d_psd.as<double>() : nullptr, psd_rows, seed,
                                  spec.as<double2>(), s);
-        if (sc < chunk)  // a short last group: the unused slots transform zeros
-            e = hipMemsetAsync((char *)spec.p + (size_t)sc * nk * 16, 0, (size_t)(chunk - sc) * nk * 16, s);
-        if (e != hipSuccess) break;
-        if (hipfftExecZ2D(plan, (hipfftDoubleComplex *)spec.p, series.as<double>()) != HIPFFT_SUCCESS) {
-            cleanup();
-            return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");  // (the resident set is untouched so far)
+        if (czt) {
+            // pairs of series through two power-of-two complex transforms (a short last group packs zeros into the
+            // pairs it does not fill: the plan's batch is fixed)
+            double2 *work = ctx->czt.work.as<double2>();
+            mtg_launch_czt_pack(sc, czt_per, nfft, czt_m, spec.as<double2>(), ctx->czt.chirp.as<double2>(), work, s);
+            const int64_t used = (sc + czt_per - 1) / czt_per;
+            if (used < czt_pairs) e = hipMemsetAsync(work + used * czt_m, 0, (size_t)(czt_pairs - used) * czt_m * 16, s);
+            if (e != hipSuccess) break;
+            bool ok = hipfftExecZ2Z(plan, (hipfftDoubleComplex *)work, (hipfftDoubleComplex *)work, HIPFFT_FORWARD) == HIPFFT_SUCCESS;
+            if (ok) mtg_launch_czt_mul(used, czt_m, ctx->czt.bhat.as<double2>(), work, s);
+            ok = ok && hipfftExecZ2Z(plan, (hipfftDoubleComplex *)work, (hipfftDoubleComplex *)work, HIPFFT_BACKWARD) == HIPFFT_SUCCESS;
+            if (!ok) {
+                cleanup();
+                return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2Z failed");  // (the resident set is untouched so far)
+            }
+            mtg_launch_czt_unpack(sc, czt_per, nfft, czt_m, work, ctx->czt.chirp.as<double2>(), series.as<double>(), s);
+        } else {
+            if (sc < chunk)  // a short last group: the unused slots transform zeros
+                e = hipMemsetAsync((char *)spec.p + (size_t)sc * nk * 16, 0, (size_t)(chunk - sc) * nk * 16, s);
+            if (e != hipSuccess) break;
+            if (hipfftExecZ2D(plan, (hipfftDoubleComplex *)spec.p, series.as<double>()) != HIPFFT_SUCCESS) {
+                cleanup();
+                return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");  // (the resident set is untouched so far)
+            }
         }
         mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
                                 d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
@@ -1868,7 +1980,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     yv_tmp.release();
     // the plan's buffers stay with the context for the next call of the workflow -- unless they are large enough to be
     // in somebody's way (a fine simulation grid: hundreds of MB per transform)
-    if (spec.cap + series.cap > ((size_t)1 << 30)) { spec.release(); series.release(); }
+    if (spec.cap + series.cap + ctx->czt.work.cap > ((size_t)1 << 30)) { spec.release(); series.release(); ctx->czt.work.release(); }
     if (e != hipSuccess) {
         // the resident set may have been freed or partly overwritten on the way: nothing is resident any more
         if (make_resident) { ctx->N = 0; ctx->L = 0; }
@@ -2065,6 +2177,13 @@ MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 3) return MTG_E_ARG;
     ctx->tp_mode = mode;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on)
+{
+    if (!ctx) return MTG_E_ARG;
+    ctx->czt.pairs_on = on != 0;
     return MTG_OK;
 }
 

@@ -206,6 +206,11 @@ void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, in
                              uint64_t seed, double *clean, double *rates, double *dy, hipStream_t);
 void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const double *dy, double2 *yv, double *means,
                               hipStream_t);
+// inverse real transform of a length with large prime factors on power-of-two transforms (chirp-z; mtg_simulate.hip)
+void mtg_launch_czt_tables(int64_t n, int64_t m, double2 *chirp, double2 *b, hipStream_t);
+void mtg_launch_czt_pack(int64_t S, int per, int64_t n, int64_t m, const double2 *X, const double2 *chirp, double2 *a, hipStream_t);
+void mtg_launch_czt_mul(int64_t pairs, int64_t m, const double2 *bhat, double2 *a, hipStream_t);
+void mtg_launch_czt_unpack(int64_t S, int per, int64_t n, int64_t m, const double2 *c, const double2 *chirp, double *series, hipStream_t);
 void mtg_launch_predict(const void *predict_args, hipStream_t);
 void mtg_launch_apply_inverse(const double *work, int64_t N, int J, int64_t M, double *x, hipStream_t);
 void mtg_launch_math_probe(int64_t n, const double *x, double *e, double *s, double *c, double *rcp,

@@ -228,6 +228,103 @@ mtg_tk95_resident_kernel(int64_t N, const double *rates, const double *dy, doubl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Inverse real transform of a length with large prime factors, by hand (chirp-z / Bluestein on power-of-two transforms).
+//
+// The simulator's grid is what the reference's arithmetic makes it (simulator.py:259-262): 1 087 853 = 13^2 x 41 x 157
+// points for BASELINE configs[3].  hipFFT takes such a length through its own Bluestein path, and BUILDING that plan costs
+// 0.9 s every time (2.0 s the first time in a process; scripts/plan_time_probe.py) against 15 ms for a power of two --
+// on the critical path of every Protassov test, a fifth of one GPU's share at 8 GPUs.  So:
+//   x_j = sum_k Y_k e^{+2 pi i jk/n},  jk = (j^2 + k^2 - (j - k)^2) / 2,  w_l = e^{i pi l^2 / n}:
+//   x_j = w_j sum_k (Y_k w_k) conj(w_{j-k})   -- a convolution, done with two complex transforms of m = 2^p >= 2n - 1.
+// Two series share one complex transform: both are real, so IDFT(Y1 + i Y2) = x1 + i x2.  The chirp's phase is reduced
+// in integers (l^2 mod 2n), so w is accurate to an ulp however long the series.  Y is the Hermitian extension of the
+// half spectrum hipFFT's Z2D would have read (imaginary parts of the k = 0 and Nyquist entries ignored likewise).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mtg_czt_chirp_kernel(int64_t n, double2 *chirp)
+{
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n) return;
+    const uint64_t q = ((uint64_t)l * (uint64_t)l) % (uint64_t)(2 * n);   // l < 2^30: l^2 < 2^60
+    double sn, cs;
+    sincospi((double)q / (double)n, &sn, &cs);
+    chirp[l] = make_double2(cs, sn);
+}
+
+// b_l = conj(w_l) / m for |l| < n, wrapped into [0, m) (the 1 / m of the unnormalised inverse transform rides along)
+__global__ void __launch_bounds__(256) mtg_czt_b_kernel(int64_t n, int64_t m, const double2 *chirp, double2 *b)
+{
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= m) return;
+    const int64_t d = l < n ? l : (m - l < n ? m - l : -1);
+    const double inv = 1.0 / (double)m;
+    b[l] = d < 0 ? make_double2(0.0, 0.0) : make_double2(chirp[d].x * inv, -chirp[d].y * inv);
+}
+
+// a[p][k] = (Y1_k + i Y2_k) w_k for k < n, 0 up to m; series per p and per p + 1 of the call's chunk (per = 2; the second may
+// not exist) -- or, per = 1, one series per transform (Y2 = 0: a series' values then do not depend on its neighbour)
+__global__ void __launch_bounds__(256) mtg_czt_pack_kernel(int64_t S, int per, int64_t n, int64_t m, const double2 *X, const double2 *chirp, double2 *a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pairs = (S + per - 1) / per;
+    if (i >= pairs * m) return;
+    const int64_t p = i / m, k = i % m, nk = n / 2 + 1;
+    double2 out = make_double2(0.0, 0.0);
+    if (k < n) {
+        const int64_t kk = k <= n / 2 ? k : n - k;
+        const bool edge = k == 0 || 2 * k == n;          // entries Z2D takes as real
+        double2 y1 = X[(per * p) * nk + kk];
+        double2 y2 = per == 2 && 2 * p + 1 < S ? X[(2 * p + 1) * nk + kk] : make_double2(0.0, 0.0);
+        if (kk != k) { y1.y = -y1.y; y2.y = -y2.y; }
+        if (edge) { y1.y = 0.0; y2.y = 0.0; }
+        const double zr = y1.x - y2.y, zi = y1.y + y2.x;  // Y1 + i Y2
+        const double2 w = chirp[k];
+        out = make_double2(zr * w.x - zi * w.y, zr * w.y + zi * w.x);
+    }
+    a[p * m + k] = out;
+}
+
+__global__ void __launch_bounds__(256) mtg_czt_mul_kernel(int64_t pairs, int64_t m, const double2 *bhat, double2 *a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pairs * m) return;
+    const double2 u = a[i], v = bhat[i % m];
+    a[i] = make_double2(u.x * v.x - u.y * v.y, u.x * v.y + u.y * v.x);
+}
+
+// series[per p][j] + i series[per p + 1][j] = w_j c[p][j]
+__global__ void __launch_bounds__(256) mtg_czt_unpack_kernel(int64_t S, int per, int64_t n, int64_t m, const double2 *c, const double2 *chirp, double *series)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pairs = (S + per - 1) / per;
+    if (i >= pairs * n) return;
+    const int64_t p = i / n, j = i % n;
+    const double2 u = c[p * m + j], w = chirp[j];
+    series[(per * p) * n + j] = u.x * w.x - u.y * w.y;
+    if (per == 2 && 2 * p + 1 < S) series[(2 * p + 1) * n + j] = u.x * w.y + u.y * w.x;
+}
+
+void mtg_launch_czt_tables(int64_t n, int64_t m, double2 *chirp, double2 *b, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mtg_czt_chirp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, chirp);
+    hipLaunchKernelGGL(mtg_czt_b_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, n, m, chirp, b);
+}
+void mtg_launch_czt_pack(int64_t S, int per, int64_t n, int64_t m, const double2 *X, const double2 *chirp, double2 *a, hipStream_t stream)
+{
+    const int64_t total = ((S + per - 1) / per) * m;
+    hipLaunchKernelGGL(mtg_czt_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, per, n, m, X, chirp, a);
+}
+void mtg_launch_czt_mul(int64_t pairs, int64_t m, const double2 *bhat, double2 *a, hipStream_t stream)
+{
+    const int64_t total = pairs * m;
+    hipLaunchKernelGGL(mtg_czt_mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pairs, m, bhat, a);
+}
+void mtg_launch_czt_unpack(int64_t S, int per, int64_t n, int64_t m, const double2 *c, const double2 *chirp, double *series, hipStream_t stream)
+{
+    const int64_t total = ((S + per - 1) / per) * n;
+    hipLaunchKernelGGL(mtg_czt_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, per, n, m, c, chirp, series);
+}
+
 void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const double *dy, double2 *yv, double *means,
                               hipStream_t st)
 {

@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
 
@@ -247,6 +247,8 @@ def load_library():
     lib.mtg_fft_warmup.argtypes = [c_vp]
     lib.mtg_simulate_plan.restype = c_int
     lib.mtg_simulate_plan.argtypes = [c_vp, c_i64]
+    lib.mtg_set_simulate_pairs.restype = c_int
+    lib.mtg_set_simulate_pairs.argtypes = [c_vp, c_int]
     lib.mtg_pair_contexts.restype = c_int
     lib.mtg_pair_contexts.argtypes = [c_vp, c_vp]
     lib.mtg_unpair_contexts.restype = c_int
@@ -752,6 +754,11 @@ class Engine:
     def set_stream_base(self, first_index):
         """Global index of this context's first ensemble / simulated series: random counters only (include/mtg.h)."""
         self._check(self._lib.mtg_set_stream_base(self._ctx, int(first_index)))
+
+    def set_simulate_pairs(self, on):
+        """False: one series per transform in simulate_tk95's chirp-z path -- a series' values then do not depend on the
+        other series of the call (include/mtg.h: mtg_set_simulate_pairs)."""
+        self._check(self._lib.mtg_set_simulate_pairs(self._ctx, 1 if on else 0))
 
     def set_pipeline(self, mode):
         """0: never the two-wave pipeline of the serial sweep, 1: whenever compiled, 2 (default): for batches of ~8e3 to

@@ -226,6 +226,7 @@ class Simulator:
                   exposures=self._exposures, want_clean=want_clean and not host_side,
                   make_resident=make_resident and not host_side, want_segments=self.pdf.lower() != "gaussian")
         eng.set_stream_base(index_base or 0)
+        eng.set_simulate_pairs(index_base is None)   # blocks of a larger set: no series shares a transform with a neighbour
         try:
             if model is None:
                 out = eng.simulate_tk95(int(nsims or 1), seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,
@@ -237,6 +238,7 @@ class Simulator:
                                         self.win_lo, self.win_hi, **kw)
         finally:
             eng.set_stream_base(0)
+            eng.set_simulate_pairs(True)
             if make_resident:
                 eng.bound_to = None    # whatever happened, the engine no longer holds this evaluator's dummy data
         if host_side:

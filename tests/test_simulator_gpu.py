@@ -193,3 +193,27 @@ def test_closed_form_spectra_drive_the_simulator_like_their_terms():
     m52 = Simulator(psd.Matern52(), times, exposure, 10.0, "Gaussian", sigma_noise=1.0, extension_factor=3, random_state=1)
     r52 = m52.simulate(noise=False, nsims=3)["rates"]
     assert r52.shape == (3, len(times)) and np.all(np.isfinite(r52)) and r52.std() > 0
+
+
+@pytest.mark.parametrize("nsims", [1, 2, 5])
+def test_chirp_z_transform_is_the_library_transform(monkeypatch, nsims):
+    """A grid length with large prime factors is transformed by hand on power-of-two transforms (csrc/mtg_simulate.hip,
+    chirp-z: hipFFT's own plan for such a length takes 0.9 s to BUILD); forced on and off (MTG_SIM_CZT) for the same seed the
+    two paths give the same series -- odd and even numbers of series (two share a complex transform), one alone."""
+    rng = np.random.default_rng(11)
+    times = synth.make_times(157, rng)                    # (the grid length is whatever the reference's arithmetic makes it)
+    kernel = DampedRandomWalk(np.log(100.0), np.log(2 * np.pi / 10), bounds=[(-10, 50), (-10, 10)]) + \
+        Lorentzian(np.log(50.0), np.log(20.0), np.log(2 * np.pi / 3.0), bounds=[(-10, 50), (-10, 10), (-10, 10)])
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MTG_SIM_CZT", mode)
+        sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=3, random_state=4)
+        thetas = np.tile(sim._engine()[1].full[sim._engine()[1].free_index][None, :], (nsims, 1))
+        got[mode] = (sim.fftndatapoints, sim.simulate(thetas, seed=2468, want_clean=True))
+    n = got["1"][0]
+    assert n == got["0"][0]
+    a, b = got["1"][1], got["0"][1]
+    scale = np.std(b["clean"])
+    assert scale > 0
+    assert np.max(np.abs(a["clean"] - b["clean"])) <= 1e-11 * scale
+    assert np.max(np.abs(a["rates"] - b["rates"])) <= 1e-11 * scale
