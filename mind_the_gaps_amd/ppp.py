@@ -593,6 +593,21 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
             out = sim.simulate(samples[lo:hi, :null_kernel.vector_size], index_base=lo if reproducible else None)
             clock.append(time.perf_counter())
             meet = threading.Barrier(2) if side_by_side else None
+            # side by side AND paired: from the chains on, the two contexts' pipelined half-steps go out in ONE launch
+            # (mtg_pair_contexts: eight waves per compute unit on one table set, two per SIMD -- a pipelined sweep alone
+            # takes the whole compute unit, so unpaired launches alternate rather than share SIMDs).  Paired between the
+            # starting fits and the chains: the fits' batches come at each model's own pace and must not wait for each other.
+            paired = side_by_side is True and os.environ.get("MTG_PPP_PAIR", "1") != "0"
+
+            def meet_then_pair():
+                first = meet.wait() == 0
+                if paired:
+                    if first:
+                        from .gp import get_side_engine
+                        for k in (0, 1):
+                            get_side_engine(device, k).unpair()      # (whatever an interrupted run may have left)
+                        get_side_engine(device, 0).pair_with(get_side_engine(device, 1))
+                    meet.wait()
 
             def refit(k):
                 kernel = (null_kernel, alt_kernel)[k]
@@ -606,7 +621,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                                                    index_base=lo if reproducible else None,
                                                    total_lightcurves=nsims if reproducible else None,
                                                    # (no timeout: a partner that fails aborts the barrier, below)
-                                                   before_sampling=meet.wait if meet is not None else None)
+                                                   before_sampling=meet_then_pair if meet is not None else None)
                 except BaseException:
                     if meet is not None:
                         meet.abort()        # the partner thread must not wait at the barrier for a refit that has failed
@@ -622,17 +637,11 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
                     # 250 light curves at 8 GPUs) the two chains interleave and gain 16 %: "auto" (docstring).
                     from concurrent.futures import ThreadPoolExecutor
                     from .gp import get_side_engine
-                    # ... and, the two contexts paired, the two models' pipelined half-steps go out in ONE launch
-                    # (mtg_pair_contexts: eight waves per compute unit on one table set, two per SIMD -- a pipelined
-                    # sweep alone takes the whole compute unit, so unpaired launches alternate rather than share SIMDs)
-                    paired = side_by_side is True and os.environ.get("MTG_PPP_PAIR", "1") != "0"
-                    if paired:
-                        get_side_engine(device, 0).pair_with(get_side_engine(device, 1))
                     try:
                         with ThreadPoolExecutor(max_workers=2) as pool:
                             futures = [pool.submit(refit, k) for k in (0, 1)]
                     finally:
-                        if paired:
+                        if paired:     # (both threads have returned: nobody is inside a paired call)
                             pair_stats = get_side_engine(device, 0).pair_stats()
                             get_side_engine(device, 0).unpair()
                     errors = [f.exception() for f in futures if f.exception() is not None]
