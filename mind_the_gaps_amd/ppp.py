@@ -590,7 +590,16 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     if hi > lo:
         try:
             sim.random_state = np.random.RandomState(sim_seed)
-            out = sim.simulate(samples[lo:hi, :null_kernel.vector_size], index_base=lo if reproducible else None)
+            if reproducible:
+                # Every series with the partner it has in the whole set (the simulator's transform packs series 2p and
+                # 2p + 1 together): a block that starts or ends inside a pair simulates the partner too -- its parameters
+                # are at hand, every rank holds all the posterior samples -- and drops it.  At most two extra series.
+                lo_e, hi_e = lo - (lo & 1), min(nsims, hi + (hi & 1))
+                out = sim.simulate(samples[lo_e:hi_e, :null_kernel.vector_size], index_base=lo_e, pair_series=True)
+                keep = slice(lo - lo_e, lo - lo_e + (hi - lo))
+                out = {k: (v[keep] if v is not None else None) for k, v in out.items()}
+            else:
+                out = sim.simulate(samples[lo:hi, :null_kernel.vector_size])
             clock.append(time.perf_counter())
             meet = threading.Barrier(2) if side_by_side else None
             # side by side AND paired: from the chains on, the two contexts' pipelined half-steps go out in ONE launch

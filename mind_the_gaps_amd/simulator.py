@@ -210,14 +210,19 @@ class Simulator:
 
     # -- simulation --------------------------------------------------------------------
     def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None, nsims=None,
-                 index_base=None):
+                 index_base=None, pair_series=None):
         """Light curves for S kernel parameter vectors ``thetas`` [S][P] (default: the kernel's
         current one; with a callable PSD: ``nsims`` realisations of it) in one device call ->
         dict(rates[S][N], dy[S][N], means[S], clean[S][N] | None).  ``index_base``: global index of the first of
         these series (mtg_set_stream_base) -- with the same ``seed``, series [index_base, index_base + S) of a set
         simulated in blocks are the ones a single call for the whole set would make.  That holds for what is drawn on the
         host as well (Kraft noise, a non-Gaussian flux PDF): given an ``index_base``, every series draws from a generator
-        of its own, keyed by (seed, global index), instead of this simulator's one ``random_state``."""
+        of its own, keyed by (seed, global index), instead of this simulator's one ``random_state``.
+        ``pair_series``: the device's hand-made transform (grid lengths with large prime factors) packs series 2p and
+        2p + 1 of a call into one complex transform, which ties a series' last bits to its neighbour's.  Default: on
+        without an ``index_base``, off with one (a block's series must not depend on where the block was cut).  A caller
+        that cuts at EVEN global indices -- so that every series keeps the partner it has in the whole set -- may turn it
+        on and keep both the speed and the invariance (``ppp.protassov_test`` does)."""
         eng, model = self._engine()
         if seed is None:
             seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
@@ -226,7 +231,10 @@ class Simulator:
                   exposures=self._exposures, want_clean=want_clean and not host_side,
                   make_resident=make_resident and not host_side, want_segments=self.pdf.lower() != "gaussian")
         eng.set_stream_base(index_base or 0)
-        eng.set_simulate_pairs(index_base is None)   # blocks of a larger set: no series shares a transform with a neighbour
+        if pair_series and index_base is not None and int(index_base) % 2:
+            raise ValueError("pair_series with an index_base needs an even index_base (series 2p and 2p + 1 share a transform)")
+        # blocks of a larger set: no series shares a transform with a neighbour, unless the caller cut at even indices
+        eng.set_simulate_pairs(index_base is None if pair_series is None else bool(pair_series))
         try:
             if model is None:
                 out = eng.simulate_tk95(int(nsims or 1), seed, self.fftndatapoints, self.sim_dt, self.mean, self.seg_len,

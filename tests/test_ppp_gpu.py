@@ -251,6 +251,16 @@ def test_simulated_series_in_blocks_are_the_series_of_one_call():
     # same series to rounding, not to the last bit -- which is why blocks of a larger set are asked for with one
     plain = sim.simulate(thetas, seed=12345)
     assert np.max(np.abs(plain["rates"] - whole["rates"])) <= 1e-10 * np.std(whole["rates"])
+    # ... or cut at EVEN global indices with the pairs kept: every series then has the partner it has in the whole set
+    # (what protassov_test does, simulating up to two extra series per block), bit for bit again and at the paired speed
+    paired = sim.simulate(thetas, seed=12345, index_base=0, pair_series=True)
+    for lo, hi in ((0, 4), (4, 9), (2, 6), (8, 9)):
+        part = sim.simulate(thetas[lo:hi], seed=12345, index_base=lo, pair_series=True)
+        for key in ("rates", "dy", "means"):
+            assert np.array_equal(part[key], paired[key][lo:hi]), (lo, hi, key)
+    assert np.array_equal(paired["rates"], plain["rates"])          # (the same pairs as an ordinary call from index 0)
+    with pytest.raises(ValueError):
+        sim.simulate(thetas[3:6], seed=12345, index_base=3, pair_series=True)
 
 
 @pytest.mark.parametrize("pdf", ["Gaussian", "Lognormal"])
