@@ -60,18 +60,18 @@ void launch_pair(const MtgSolveArgs &a, int64_t na, const MtgSolveArgs &b, int64
 struct Entry { MtgPipeShapeId a, b; mtg_pipe_pair_launcher fn; };
 #define PAIR(a0, a1, a2, a3, b0, b1, b2, b3) { {a0, a1, a2, a3}, {b0, b1, b2, b3}, launch_pair<Shape<a0, a1, a2, a3>, Shape<b0, b1, b2, b3>> }
 // A null model and the alternative that adds one term to it -- the pairs the posterior-predictive test is made of -- for
-// the nulls that have a pipelined sweep at all (at least one complex term; a DRW alone hands nothing over):
+// nulls that have a pipelined sweep at all (rank 3 to 6 with a complex term; a DRW, an SHO or a Lorentzian alone hands
+// nothing over or is below rank 3):
 //   shape = <real terms, complex terms with every SHO under-damped, structures = SHO terms + 1, last complex term has b = 0>
 const Entry pairs[] = {
     PAIR(1, 1, 2, 0, 1, 2, 2, 1),   // DRW + SHO            | + Lorentzian        (BASELINE configs[3])
     PAIR(1, 1, 2, 0, 1, 2, 3, 0),   // DRW + SHO            | + SHO
+    PAIR(1, 1, 2, 0, 2, 1, 2, 0),   // DRW + SHO            | + real term
     PAIR(1, 1, 1, 1, 1, 2, 1, 1),   // DRW + Lorentzian     | + Lorentzian
     PAIR(1, 1, 1, 1, 1, 2, 2, 0),   // DRW + Lorentzian     | + SHO
-    PAIR(0, 1, 2, 0, 0, 2, 2, 1),   // SHO                  | + Lorentzian
-    PAIR(0, 1, 2, 0, 0, 2, 3, 0),   // SHO                  | + SHO
-    PAIR(0, 1, 2, 0, 1, 1, 2, 0),   // SHO                  | DRW + SHO
-    PAIR(0, 1, 1, 1, 0, 2, 1, 1),   // Lorentzian           | + Lorentzian
-    PAIR(0, 1, 1, 1, 1, 1, 1, 1),   // Lorentzian           | DRW + Lorentzian
+    PAIR(0, 2, 2, 1, 1, 2, 2, 1),   // SHO + Lorentzian     | + DRW
+    PAIR(0, 2, 3, 0, 1, 2, 3, 0),   // SHO + SHO            | + DRW
+    PAIR(2, 1, 2, 0, 2, 2, 2, 1),   // DRW + real + SHO     | + Lorentzian
 };
 
 bool same(const MtgPipeShapeId &x, const MtgPipeShapeId &y)

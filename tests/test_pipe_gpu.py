@@ -251,11 +251,12 @@ def test_shipped_shape_against_the_oracle(pipe, name):
     assert np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])) <= 1e-8
 
 
-def _two_models(N=1000, L=9, W=40, seed=3):
-    """Two contexts on the same light curves: DRW + SHO (null) and DRW + SHO + Lorentzian (alternative)."""
+def _two_models(N=1000, L=9, W=40, seed=3, kinds_of=None):
+    """Two contexts on the same light curves: DRW + SHO (null) and DRW + SHO + Lorentzian (alternative) by default."""
     from mind_the_gaps_amd.engine import Engine
     t, y, dy = synth.make_lightcurves(N, L, seed=seed)
-    engines, thetas, kinds_of = [], [], (MODELS["null_drw_sho"], MODELS["alt_drw_sho_lorentzian"])
+    engines, thetas = [], []
+    kinds_of = kinds_of or (MODELS["null_drw_sho"], MODELS["alt_drw_sho_lorentzian"])
     lc = np.repeat(np.arange(L, dtype=np.int32), W)
     for i, kinds in enumerate(kinds_of):
         eng = Engine(0)
@@ -345,4 +346,60 @@ def test_a_partner_that_does_not_come_breaks_the_pair_not_the_run(monkeypatch):
         assert np.array_equal(both[0][0], alone[0]) and np.array_equal(both[1][0], alone[0])
     finally:
         for eng in engines:
+            eng.close()
+
+
+# the pairs csrc/mtg_kernels_pipe_pair.hip is compiled for: a null model and the alternative that adds one term to it
+PAIRS = {
+    "drw_sho | + lorentzian": ([K.K_DRW, K.K_SHO], [K.K_DRW, K.K_SHO, K.K_LORENTZIAN]),
+    "drw_sho | + sho": ([K.K_DRW, K.K_SHO], [K.K_DRW, K.K_SHO, K.K_SHO]),
+    "drw_sho | + real": ([K.K_DRW, K.K_SHO], [K.K_DRW, K.K_REAL, K.K_SHO]),
+    "drw_lorentzian | + lorentzian": ([K.K_DRW, K.K_LORENTZIAN], [K.K_DRW, K.K_LORENTZIAN, K.K_LORENTZIAN]),
+    "drw_lorentzian | + sho": ([K.K_DRW, K.K_LORENTZIAN], [K.K_DRW, K.K_LORENTZIAN, K.K_SHO]),
+    "sho_lorentzian | + drw": ([K.K_SHO, K.K_LORENTZIAN], [K.K_DRW, K.K_SHO, K.K_LORENTZIAN]),
+    "sho_sho | + drw": ([K.K_SHO, K.K_SHO], [K.K_DRW, K.K_SHO, K.K_SHO]),
+    "drw_real_sho | + lorentzian": ([K.K_DRW, K.K_REAL, K.K_SHO], [K.K_DRW, K.K_REAL, K.K_SHO, K.K_LORENTZIAN]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PAIRS))
+def test_every_compiled_pair_of_models(name):
+    """Each of the eight null / alternative pairs with a paired kernel: dispatched in one launch, in either order of the
+    two contexts, every row the same to the last bit as from the model's own pipelined kernel."""
+    engines, thetas, lc = _two_models(N=333, L=7, W=50, seed=21, kinds_of=PAIRS[name])
+    try:
+        alone = [engines[i].loglike(thetas[i], lc, add_prior=True) + (engines[i].last_solver,) for i in (0, 1)]
+        assert all("mtg_pipe_kernel" in a[2] for a in alone), [a[2] for a in alone]
+        for first, second in ((0, 1), (1, 0)):
+            engines[first].pair_with(engines[second])
+            got = _both_at_once(engines, thetas, lc, rounds=2)
+            stats = engines[0].pair_stats()
+            engines[0].unpair()
+            assert stats == {"paired": 2, "solo": 0, "broken": False}, (name, stats)
+            for i in (0, 1):
+                assert "mtg_pipe_pair_kernel" in got[i][2]
+                assert np.array_equal(got[i][1], alone[i][1]) and np.array_equal(got[i][0], alone[i][0])
+                assert (alone[i][1] == 0).sum() > 300
+    finally:
+        for eng in engines:
+            eng.close()
+
+
+def test_light_curves_of_different_lengths_do_not_pair():
+    """Two contexts whose light curves differ in length walk different numbers of hand-overs: no shared launch (the pair
+    breaks, both go alone, same results)."""
+    a, ta, lc = _two_models(N=300)
+    b, tb, _ = _two_models(N=310)
+    engines = [a[0], b[1]]
+    try:
+        alone = [engines[0].loglike(ta[0], lc, add_prior=True), engines[1].loglike(tb[1], lc, add_prior=True)]
+        engines[0].pair_with(engines[1])
+        got = _both_at_once(engines, [ta[0], tb[1]], lc)
+        stats = engines[0].pair_stats()
+        engines[0].unpair()
+        assert stats["paired"] == 0 and stats["broken"]
+        for i in (0, 1):
+            assert np.array_equal(got[i][0], alone[i][0]) and "mtg_pipe_kernel" in got[i][2]
+    finally:
+        for eng in a + b:
             eng.close()
