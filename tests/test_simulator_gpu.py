@@ -217,3 +217,21 @@ def test_chirp_z_transform_is_the_library_transform(monkeypatch, nsims):
     assert scale > 0
     assert np.max(np.abs(a["clean"] - b["clean"])) <= 1e-11 * scale
     assert np.max(np.abs(a["rates"] - b["rates"])) <= 1e-11 * scale
+
+
+def test_chirp_z_transform_even_and_odd_lengths(monkeypatch):
+    """The hand-made transform on grids of both parities (an even length has a real Nyquist entry, taken as real like the
+    k = 0 entry) against the library's, three series each (a full pair and a lone series)."""
+    kernel = DampedRandomWalk(np.log(100.0), np.log(2 * np.pi / 10), bounds=[(-10, 50), (-10, 10)])
+    seen = set()
+    for seed in (100, 101, 104, 105):         # sampling patterns whose grids come out at 56 989, 57 051, 56 414, 55 246 points
+        times = synth.make_times(150, np.random.default_rng(seed))
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MTG_SIM_CZT", mode)
+            sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=2, random_state=4)
+            thetas = np.tile(sim._engine()[1].full[sim._engine()[1].free_index][None, :], (3, 1))
+            got[mode] = sim.simulate(thetas, seed=97531, want_clean=True)["clean"]
+        seen.add(sim.fftndatapoints % 2)
+        assert np.max(np.abs(got["1"] - got["0"])) <= 1e-11 * np.std(got["0"]), (seed, sim.fftndatapoints)
+    assert seen == {0, 1}
