@@ -2262,6 +2262,14 @@ MTG_API int mtg_pair_contexts(mtg_ctx *a, mtg_ctx *b)
     p->members[0] = a; p->members[1] = b;
     a->pair = p; a->pair_index = 0;
     b->pair = p; b->pair_index = 1;
+    // Two models that are known now and have no kernel in common -- one of them without a pipelined sweep (a DRW alone),
+    // or a pair of shapes that is not compiled -- never meet: broken from the start, nobody waits for a partner that has
+    // nothing to bring.  (Models set later are looked at when their half-steps meet.)
+    if (a->has_model && b->has_model) {
+        auto shape = [](const mtg_ctx *c) { return MtgPipeShapeId{c->model.nr0, c->model.nc0, c->model.nsho + 1, c->model.last_b0 ? 1 : 0}; };
+        const MtgPipeShapeId sa = shape(a), sb = shape(b);
+        if (!mtg_find_pipe_pair_solver(sa, sb) && !mtg_find_pipe_pair_solver(sb, sa)) p->broken = true;
+    }
     if (!ok) {
         mtg_unpair_contexts(a);
         return fail(a, MTG_E_HIP, "mtg_pair_contexts: event creation failed");

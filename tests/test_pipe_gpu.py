@@ -333,13 +333,16 @@ def test_a_partner_that_does_not_come_breaks_the_pair_not_the_run(monkeypatch):
         assert "mtg_pipe_kernel" in engines[1].last_solver
         assert np.array_equal(got[0], alone[0]) and np.array_equal(again[0], alone[0])
         assert stats == {"paired": 0, "solo": 2, "broken": True} and 0.03 < waited < 2.0
-        # the same model twice is not a pair the library has a kernel for: both go alone, at once
+        # the same model twice is not a pair the library has a kernel for: known at pairing time, both go alone at once
         full_kinds = MODELS["alt_drw_sho_lorentzian"]
         t, y, dy = synth.make_lightcurves(300, 9, seed=3)
         full, free, bounds = synth.model_spec(full_kinds, y, per_lc_mean=True)
         engines[0].set_model(full_kinds, full, free, bounds)
         engines[0].pair_with(engines[1])
+        assert engines[0].pair_stats()["broken"]                       # (no waiting: the models are known already)
+        t0 = time.perf_counter()
         both = _both_at_once(engines, [thetas[1], thetas[1]], lc)
+        assert time.perf_counter() - t0 < 0.03 + 1.0                   # nobody sat out the patience
         stats = engines[0].pair_stats()
         engines[0].unpair()
         assert stats["paired"] == 0 and stats["broken"] and stats["solo"] == 2
