@@ -96,8 +96,8 @@ def rows():
          "`mtg_sort.hip`, `mtg_timeparallel*`, `mtg_tp_scan.*`, `mtg_tp_big*`, `mtg_capi.hip`; `gp.py`, `gpmodelling.py`",
          "`test_hip_parity`, `test_golden_gpu` (180 dense/mpmath vectors × 3 dispatch modes), `test_box_golden`, `test_fuzz_gpu`, "
          "`test_edge_cases_gpu`, `test_timeparallel_gpu`, `test_tp_big_gpu`, `test_window_gpu`, `test_sort_gpu`, `test_device_math_gpu`, "
-         "`test_highfreq_golden_gpu`, `test_pipe_gpu` (bit-identical to the one-lane sweep; the 32 000-row shape vs the oracle); CPU: "
-         "`test_oracle`, `test_modeling_terms`, `test_capi_cpu`", head),
+         "`test_highfreq_golden_gpu`, `test_pipe_gpu` (pipeline and paired launch bit-identical to the one-lane sweep; 32 000 rows vs "
+         "the oracle); CPU: `test_oracle`, `test_modeling_terms`, `test_capi_cpu`", head),
         ("a9 `fit`", "`GPModelling.fit`, `ppp.batched_minimize`",
          "`test_gpmodelling_gpu::test_fit_improves_and_matches_oracle_at_optimum`, `test_ppp_cpu`",
          "one launch of P + 1 rows per L-BFGS-B iteration; line search in 3 launches"),
@@ -121,8 +121,8 @@ def rows():
             d.get("clock_under_load", {}).get("sclk_mhz", "?"), d.get("clock_under_load", {}).get("socket_power_w", "?"))),
         ("e multi-GPU", "`distributed.py`, `ppp.protassov_test(sharded=True)`, `derive_posteriors(shard_walkers=True)` "
          "(`mtg_ensemble_shard_rccl` / `_host`), `bench.py --gpus N`",
-         "`test_distributed` (gloo world 2 and 3: row, light-curve and walker sharding bit-equal to one process, both splits of the "
-         "Protassov test, failure propagation; RCCL with a one-rank communicator; two-GPU RCCL chain, skipped on one GPU)",
+         "`test_distributed` (gloo world 2 and 3: every sharding bit-equal to one process, both splits of the Protassov test, failure "
+         "propagation; RCCL with one rank; two-GPU RCCL chain, skipped on one GPU)",
          "**N > 1 on hardware: not run here.**  One-GPU projections: sweep `strong_shard_8.per_gpu_factor` %.3f (× 8 = %.1f×); workflow "
          "share of 8: %.2f s of %.2f s ⇒ %.2f×; configs[4] walker shard 256 → 32 rows: %.2f → %.2f ms = %.2f×.  Rehearsals: %s"
          % (d["strong_shard_8"]["per_gpu_factor"], 8 * d["strong_shard_8"]["per_gpu_factor"], share_s, wf["whole_test_s"],
@@ -132,8 +132,8 @@ def rows():
          "as a10; `test_chain_autocorr_on_the_device_matches_the_host`",
          "one solve + one sampler launch per iteration (speculative) or per half-step, no host round trip"),
         ("f2 simulator", "`csrc/mtg_simulate.hip`, `simulator.py`, `models/psd_models.py`",
-         "`test_simulator_gpu` (exact host replay, moments, PSD shape, noise), `test_simulator_reference_cases` (the reference's known "
-         "answers), `test_psd_models`, `test_ppp_gpu` (block invariance incl. host-drawn Kraft noise)",
+         "`test_simulator_gpu` (exact host replay, chirp-z vs library transform, moments, noise), `test_simulator_reference_cases` (the "
+         "reference's known answers), `test_psd_models`, `test_ppp_gpu` (block invariance)",
          "%d × %s-point simulations in %.2f s inside the workflow" % (wf["nsims"], sci(wf["fft_points_per_simulation"]), wf["seconds"]["simulate"])),
         ("f3 predict", "`mtg_predict_kernel`, `mtg_apply_inverse_kernel`, `GP.predict`, `standarized_residuals`",
          "`test_gpmodelling_gpu` (dense algebra)", "O(N·J²) instead of celerite's dense N × N"),
