@@ -113,6 +113,7 @@ struct mtg_ctx {
     int32_t *shard_h_st = nullptr;
     int64_t shard_h_rows = 0;
     int64_t live_rows = 0;              // rows the next solve really evaluates (0: all) -- kernel choice only
+    bool no_prior_batch = false;        // the batch being solved was expanded WITHOUT the prior (run_model_batch): kernel choice only
 
     // mtg_chain_autocorr: the convergence check is repeated on a growing chain, so plans (remade when the padded
     // length or the shape changes) and buffers stay
@@ -393,7 +394,9 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     if (prof) HIP_TRY(ctx, hipEventRecord(pe[1], s));
     {
         mtg_trace::Range range("mtg:solve (factorisation + forward solve)");
+        ctx->no_prior_batch = !add_prior;
         rc = solve_prepared(ctx, B, d_lc, d_out, d_status, s, true);
+        ctx->no_prior_batch = false;
     }
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
@@ -517,7 +520,16 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // in ms: J = 3: 0.82 / 1.37 at 8192 rows, 1.20 / 1.39 at 12 288, 1.51 / 1.40 at 16 000; J = 5: 1.85 / 2.40 at 8192, 2.73 / 2.46 at 12 288)
     if (Jmodel <= 6) pays = ctx->N >= 256 && Bw <= (ctx->N >= 4096 ? (Jmodel <= 3 ? 12288 : 8192) : 4096);
     else pays = ctx->N >= 1024 && Bw <= 8192;
-    const bool small = ctx->tp_mode == 1 || ctx->tp_mode == 3 || (ctx->tp_mode == 2 && pays);
+    // A term with a free b (ComplexTerm with four parameters, BendingPowerlaw) has a power spectrum that goes negative
+    // where b d > a c -- which is exactly what those terms' own log_prior forbids, so a batch expanded WITH the prior never
+    // solves such a row.  Without it (the optimiser's -lnL, gpmodelling.py:155-169) it may, and there the state-space form
+    // the time-parallel kernels work in has an indefinite stationary covariance: their filter pass was found 1e-7 off on
+    // such a row (tests/test_fuzz_gpu.py at MTG_FUZZ_OFFSET=112000, case 70; scripts/fuzz_case.py) where celerite's own
+    // recursion -- the sweep -- is exact to rounding.  Those batches keep the sweep.
+    bool free_b = false;
+    for (int i = 0; i < m.nterms; ++i) free_b = free_b || m.kinds[i] == MTG_TERM_COMPLEX4 || m.kinds[i] == MTG_TERM_BPL;
+    const bool tp_allowed = !(free_b && ctx->no_prior_batch);
+    const bool small = tp_allowed && (ctx->tp_mode == 1 || ctx->tp_mode == 3 || (ctx->tp_mode == 2 && pays));
     sa.tp_ws = nullptr;
     sa.tp_chunks = 0;
     sa.tp_gsize = 0;

@@ -31,7 +31,19 @@ def random_model(rng, jmax, ncmax):
 
 @pytest.mark.parametrize("case", range(120))
 def test_random_model_vs_oracle(engine, case):
-    case = case + OFFSET
+    _random_model_vs_oracle(engine, case + OFFSET)
+
+
+# cases a soak (MTG_FUZZ_OFFSET) once failed on, kept for good:
+#   112070  ComplexTerm (4 parameters) + over-damped SHO, no prior, time-parallel kernels asked for: a row with b d > a c --
+#           outside that term's own prior, its power spectrum negative in places -- came out 1e-7 off through the time-parallel
+#           filter pass (round 5).  Batches expanded without the prior now keep the sweep for models with such terms.
+@pytest.mark.parametrize("case", [112070])
+def test_cases_a_soak_found(engine, case):
+    _random_model_vs_oracle(engine, case)
+
+
+def _random_model_vs_oracle(engine, case):
     rng = np.random.default_rng(9000 + case)
     tp_mode = int(rng.integers(0, 2))
     kinds = random_model(rng, *((6, 3) if tp_mode else (10, 5)))
