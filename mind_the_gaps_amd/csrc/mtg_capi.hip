@@ -540,6 +540,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     // mode 3 promises bits that do not depend on the batch; the rank-10 path sizes its chunks and scan groups by the
     // batch (mtg_tp_big_chunks), so under mode 3 such a model keeps the serial sweep
     if (ctx->tp_mode == 3 && Jmodel > 6) small_ok = false;
+    if (Jmodel == 0) small_ok = false;  // a white kernel: nothing to parallelise over time (mtg_white_kernel)
     if (small_ok && Jmodel > 6) {
         for (int k = 0; k < nsig; ++k)
             if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
@@ -680,6 +681,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             }
             if (k == 0) {
                 if (tp) snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_tp_kernel<%d,%d,%d>", nr, nc, tp == mtg_find_tp_solver(nr, nc) ? 64 : 256);
+                else if (nr + nc == 0) snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_white_kernel");
                 else snprintf(ctx->last_solver, sizeof ctx->last_solver, "mtg_solve_kernel<%d,%d,%d>", nr, nc, mtg_solver_uses_b0(nr, nc, m.last_b0));
             }
             hipStream_t sk = fan_out && k > 0 ? ctx->side[k - 1] : s;
@@ -982,8 +984,6 @@ MTG_API int mtg_set_model(mtg_ctx *ctx, int nterms, const int32_t *kinds, const 
     }
     m.nr_max = m.nr0 + 2 * m.nsho;
     m.nc_max = m.nc0;
-    if (m.nr0 + m.nc0 == 0)
-        return fail(ctx, MTG_E_UNSUPPORTED, "mtg_set_model: the kernel has no real or complex term");
     for (int k = 0; k <= m.nsho; ++k) {
         const int nr = m.nr0 + 2 * k, nc = m.nc0 - k;
         if (!mtg_find_solver(nr, nc))

@@ -158,6 +158,58 @@ struct MtgSel<NR, NC, false> { static constexpr mtg_solve_launcher fn = nullptr;
     { MtgSel<(nr), 0>::fn, MtgSel<(nr), 1>::fn, MtgSel<(nr), 2>::fn, MtgSel<(nr), 3>::fn, \
       MtgSel<(nr), 4>::fn, MtgSel<(nr), 5>::fn }
 
+// A white kernel -- JitterTerm alone, which celerite accepts and reference docs/notebooks/celerite_variance.ipynb cell 26
+// fits: K = diag(sigma_n^2 + jitter), so the sweep has no state: D_n = sigma_n^2 + jitter, z_n = r_n.  The rows, lists and
+// verdicts of mtg_solve_kernel; plain loads (nothing here is worth a buffer descriptor).
+__global__ void __launch_bounds__(MTG_BLOCK) mtg_white_kernel(MtgSolveArgs a)
+{
+    const int64_t count = a.count_ptr ? (int64_t)*a.count_ptr : a.B;
+    const int per_block = a.solo ? MTG_BLOCK / 64 : MTG_BLOCK;
+    if (a.solo && (threadIdx.x & 63) != 0) return;
+    const int64_t gid = (int64_t)blockIdx.x * per_block + (a.solo ? threadIdx.x >> 6 : threadIdx.x);
+    if (gid >= count) return;
+    int64_t first = 0;
+    if (a.seg_counts)
+        for (int i = 0; i < a.seg_k; ++i) first += a.seg_counts[i];
+    const int64_t e = a.list ? (int64_t)a.list[first + gid] : gid;
+    if (a.status[e] != MTG_ST_OK) return;
+    const double *cf = a.coef + e;
+    const double jit = cf[a.lay.jit() * a.cstride], slope = cf[a.lay.mean(0) * a.cstride], icpt = cf[a.lay.mean(1) * a.cstride];
+    const uint64_t lc = a.lc_index ? (uint64_t)(uint32_t)a.lc_index[e] : 0u;
+    if ((lc + 1u) * (uint64_t)a.N * 16u > a.yv_bytes) {  // a device-side lc_index outside the resident set
+        a.out[e] = -INFINITY;
+        a.status[e] = MTG_ST_NONFINITE;
+        return;
+    }
+    const double2 *yv = a.yv + lc * (uint64_t)a.N;
+    const double2 *dxt = a.dxt + (a.t_stride ? lc * (uint64_t)a.N : 0u);
+    double dot = 0.0, dprod = 1.0;
+    int dexp = 0, dmin_hi = 0x7fffffff;
+    for (int64_t n = 0; n < a.N; ++n) {
+        const double2 s = yv[n];
+        const double D = s.y + jit, z = s.x - fma(slope, dxt[n].y, icpt);
+        dmin_hi = min(dmin_hi, __double2hiint(D));
+        dot = fma(z, z / D, dot);
+        dprod *= D;
+        dexp += __builtin_amdgcn_frexp_exp(dprod);
+        dprod = __builtin_amdgcn_frexp_mant(dprod);
+    }
+    const double logdet = fma((double)dexp, 0.69314718055994530942, log(dprod));
+    double ll = -0.5 * fma((double)a.N, MTG_LN_2PI, dot + logdet);
+    int st = MTG_ST_OK;
+    if (dmin_hi <= 0) { st = MTG_ST_NOTPD; ll = -INFINITY; }
+    else if (!isfinite(ll)) { st = MTG_ST_NONFINITE; ll = -INFINITY; }
+    a.out[e] = ll;
+    a.status[e] = st;
+}
+
+static void mtg_launch_white(const MtgSolveArgs &a, int64_t nlanes, hipStream_t stream)
+{
+    const int64_t blocks = (nlanes + MTG_BLOCK - 1) / MTG_BLOCK;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(mtg_white_kernel, dim3((unsigned)blocks), dim3(MTG_BLOCK), 0, stream, a);
+}
+
 static const mtg_solve_launcher mtg_solver_table[MTG_MAX_NR + 1][MTG_MAX_NC + 1] = {
     MTG_ROW(0), MTG_ROW(1), MTG_ROW(2), MTG_ROW(3), MTG_ROW(4), MTG_ROW(5),
     MTG_ROW(6), MTG_ROW(7), MTG_ROW(8), MTG_ROW(9), MTG_ROW(10)};
@@ -182,5 +234,6 @@ mtg_solve_launcher mtg_find_solver(int nr, int nc, int last_b0)
 {
     if (nr < 0 || nc < 0 || nr > MTG_MAX_NR || nc > MTG_MAX_NC) return nullptr;
     if (last_b0 && nr < 5 && nc < 4 && mtg_solver_table_b0[nr][nc]) return mtg_solver_table_b0[nr][nc];
+    if (nr + nc == 0) return mtg_launch_white;
     return mtg_solver_table[nr][nc];
 }

@@ -8,7 +8,9 @@ celerite>=0.4.2 solver it calls):
 * ``oracle.celerite`` -- ctypes view of oracle/celerite_ref.c (the celerite
   semiseparable recurrences in plain C)
 
-PARITY STATUS: "parity unpinned" at the lnL boundary (see the file headers).
+PARITY STATUS: "parity unpinned" at the lnL boundary (see the file headers); the one
+celerite-produced lnL the reference's notebooks print (a white kernel) is reproduced:
+tests/test_notebook_known_answer.py.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this package; nothing under mind_the_gaps_amd/ does.
 """

@@ -1,0 +1,119 @@
+"""The one log-likelihood NUMBER the reference's own material holds (SURVEY §8c said there was none: it is in a notebook
+output, not in a test): docs/notebooks/celerite_variance.ipynb, cells 24-27.  A white-noise light curve of 1000 points is
+given to `celerite.GP(JitterTerm(log_sigma=log 3), mean=np.mean(y))`, `gp.compute(time)` (celerite's default yerr,
+1.123e-12), and `scipy.optimize.minimize(neg_log_like, method="L-BFGS-B")` prints
+
+      fun: 3433.545361920608        x: [2.01460783]          (cell 26 / cell 27 output)
+
+next to "Sample Variance: 56.21669" of the same series (cell 24 output).  The series itself is not reproducible here
+(unseeded pyfftw simulation), but with a white kernel and the mean fixed at the sample mean the likelihood depends on
+the data only through N and the sample variance, both printed: -lnL(x) = N/2 [ var / s2 + ln s2 + ln 2 pi ],
+s2 = exp(2 x) + yerr^2.  The printed variance has 5 decimals (+-5e-6), which bounds the printed minimum to
+[3433.545332, 3433.545422]: the reference's celerite value pins the normalisation of this build's lnL (the 1/2, the
+N ln 2 pi, jitter = exp(2 log_sigma), the default yerr) to 1.3e-8 relative -- celerite run by the reference's author,
+not by this build.  Any series with that N, mean and variance must give that number through the oracle (CPU) and
+through the HIP path (GPU)."""
+import numpy as np
+import pytest
+
+N, SAMPLE_VARIANCE, PRINTED_FUN, PRINTED_X = 1000, 56.21669, 3433.545361920608, 2.01460783
+ROUNDING = 0.5 * N * 5e-6 / SAMPLE_VARIANCE * 1.02          # of `fun`, from the 5 printed decimals of the variance
+
+
+def series(seed=0):
+    """a series of the notebook's length, sampling and sample variance (np.var, ddof 0), any mean"""
+    z = np.random.default_rng(seed).standard_normal(N)
+    z = (z - z.mean()) * np.sqrt(SAMPLE_VARIANCE / np.var(z))
+    times = np.linspace(0, 1000, N) * 3600 * 24                # cell 24: seconds
+    return times, z + 0.3
+
+
+def test_the_printed_value_is_inside_the_interval_its_printed_variance_allows():
+    s2 = np.exp(2 * PRINTED_X) + 1.123e-12 ** 2
+    lo, hi = (0.5 * N * (v / s2 + np.log(s2) + np.log(2 * np.pi)) for v in (SAMPLE_VARIANCE - 5e-6, SAMPLE_VARIANCE + 5e-6))
+    assert lo < PRINTED_FUN < hi and hi - lo < 1e-4
+    # the printed optimum against the maximum-likelihood sigma: L-BFGS-B stopped with jac = 2.6e-3 (cell 26), curvature 2 N
+    assert abs(0.5 * np.log(SAMPLE_VARIANCE) - PRINTED_X) < 2.0 * 2.592e-3 / (2 * N)
+
+
+def test_oracle_gives_the_notebooks_number():
+    from oracle import dense
+    from oracle import celerite as oc
+    t, y = series()
+    dy = np.full(N, 1.123e-12 - 1e-12)        # the oracle adds the facade's 1e-12 (gpmodelling.py:54); celerite's default is 1.123e-12
+    co = dense.build_coeffs([dense.K_JITTER], [PRINTED_X])
+    want = -dense.dense_loglike(t, y, dy, co, 0, [np.mean(y)])
+    assert abs(want - PRINTED_FUN) < ROUNDING
+    got, st = oc.logprob_batch(t, y, dy, [dense.K_JITTER], np.array([PRINTED_X, np.mean(y)]))
+    assert st[0] == 0 and abs(-got[0] - PRINTED_FUN) < ROUNDING
+
+
+@pytest.mark.gpu
+def test_hip_path_gives_the_notebooks_number_as_the_notebook_drives_it():
+    """cells 26-27 with this build's GP / JitterTerm in place of celerite's"""
+    from scipy.optimize import minimize
+    from mind_the_gaps_amd import terms
+    from mind_the_gaps_amd.gp import GP
+    for seed in (0, 1):
+        time, y = series(seed)
+        kernel = terms.JitterTerm(log_sigma=np.log(3))
+        gp = GP(kernel, mean=np.mean(y))
+        gp.compute(time)
+        assert gp.get_parameter_names() == ("kernel:log_sigma",) and gp.parameter_names == ("kernel:log_sigma", "mean:value")
+
+        def neg_log_like(params, y, gp):
+            gp.set_parameter_vector(params)
+            return -gp.log_likelihood(y)
+        assert abs(neg_log_like(np.array([PRINTED_X]), y, gp) - PRINTED_FUN) < ROUNDING
+        solution = minimize(neg_log_like, gp.get_parameter_vector(), method="L-BFGS-B", bounds=gp.get_parameter_bounds(), args=(y, gp))
+        assert solution.success and abs(solution.fun - PRINTED_FUN) < ROUNDING
+        assert abs(solution.x[0] - PRINTED_X) < 2e-4          # the notebook's own jac is 2.6e-3 at its stopping point
+
+
+# ---- the white kernel beyond the notebook's case: celerite takes a JitterTerm alone, so must the HIP path ------------------
+@pytest.mark.gpu
+def test_white_kernel_against_the_dense_algebra(engine):
+    """unequal errors, several light curves, a batch larger than a workgroup, the prior's verdicts"""
+    from oracle import dense
+    rng = np.random.default_rng(4)
+    Nn, L, B = 333, 3, 700
+    t = np.cumsum(0.05 + rng.exponential(1.0, Nn))
+    y = 5.0 + rng.standard_normal((L, Nn)) * 2.0
+    dy = rng.uniform(0.3, 1.5, (L, Nn))
+    thetas = rng.uniform(-1.0, 1.5, (B, 1))
+    lc = rng.integers(0, L, B).astype(np.int32)
+    mean = 4.9
+    engine.set_lightcurves(t, y, dy + 1e-12)
+    bounds = np.array([[-0.8, 1.4], [-np.inf, np.inf]])
+    engine.set_model([dense.K_JITTER], np.array([0.0, mean]), np.array([0], np.int32), bounds)
+    out, st = engine.loglike(thetas, lc_index=lc, add_prior=True)
+    inside = (thetas[:, 0] >= -0.8) & (thetas[:, 0] <= 1.4)
+    assert np.array_equal(st == 0, inside) and np.array_equal(st == 1, ~inside) and np.all(np.isneginf(out[~inside]))
+    assert "white" in engine.last_solver
+    for b in np.flatnonzero(inside)[:60]:
+        want = dense.dense_loglike(t, y[lc[b]], dy[lc[b]], dense.build_coeffs([dense.K_JITTER], thetas[b]), 0, [mean])
+        assert abs(out[b] - want) <= 1e-12 * abs(want)
+    closed = [-0.5 * np.sum((y[l] - mean) ** 2 / ((dy[l] + 1e-12) ** 2 + np.exp(2 * th)) + np.log((dy[l] + 1e-12) ** 2 + np.exp(2 * th))
+                            + np.log(2 * np.pi)) for th, l in zip(thetas[inside, 0], lc[inside])]
+    np.testing.assert_allclose(out[inside], closed, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_white_kernel_through_the_facade():
+    """GPModelling on a JitterTerm alone: fit, chains, prediction (mean = the constant, variance = the jitter)"""
+    import warnings
+    from mind_the_gaps_amd import terms
+    from mind_the_gaps_amd.gpmodelling import GPModelling
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    time, y = series(2)
+    lc = GappyLightcurve(time, y, np.full(N, 1e-3))
+    gpm = GPModelling(lc, terms.JitterTerm(log_sigma=np.log(3.0), bounds=[(-5.0, 8.0)]))
+    assert abs(gpm._neg_log_like(np.array([PRINTED_X])) - PRINTED_FUN) < 1e-3       # dy = 1e-3 instead of 1.123e-12
+    sol = gpm.fit()
+    assert sol.success and abs(sol.x[0] - 0.5 * np.log(SAMPLE_VARIANCE)) < 1e-4
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gpm.derive_posteriors(fit=True, converge=False, max_steps=300, walkers=12, progress=False)
+    assert abs(gpm.max_parameters[0] - 0.5 * np.log(SAMPLE_VARIANCE)) < 0.01
+    assert abs(-gpm.max_loglikelihood - PRINTED_FUN) < 0.01
+    assert abs(np.std(gpm.mcmc_samples[:, 0]) - 1.0 / np.sqrt(2 * N)) < 0.01       # the posterior width of a variance: 1 / sqrt(2 N)
