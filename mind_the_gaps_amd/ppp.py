@@ -433,7 +433,8 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     3. both kernels refitted to every simulated light curve in lock-step;
     4. p-value of ``T_obs`` in the simulated distribution.
 
-    Returns dict(T_obs, T_sim[nsims], p_value, null, alt, sim_null, sim_alt, lightcurves, seconds, split, reproducible) --
+    Returns dict(T_obs, T_sim[nsims], p_value ((1 + #{T_sim >= T_obs}) / (1 + nsims)), p_value_percentile (the tutorial's own
+    ``1 - percentileofscore(T_sim, T_obs) / 100``), null, alt, sim_null, sim_alt, lightcurves, seconds, split, reproducible) --
     ``seconds``:
     wall time of the observed chains, the simulation and the two refits on this process.
 
@@ -481,7 +482,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     """
     from .gpmodelling import GPModelling
     from .simulator import Simulator
-    from .stats import lrt_pvalue, lrt_statistic
+    from .stats import lrt_pvalue, lrt_pvalue_percentile, lrt_statistic
     rng = np.random.default_rng(seed)
 
     seeds = [int(rng.integers(0, 2 ** 31 - 1)) for _ in range(2)]
@@ -698,7 +699,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     clock.append(time.perf_counter())
     seconds = dict(zip(("observed_chains", "simulate", "refit_null", "refit_alt", "gather"), np.diff(clock))) \
         if len(clock) == 6 else {"observed_chains": clock[1] - clock[0]}
-    return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), null=null, alt=alt,
+    return dict(T_obs=t_obs, T_sim=t_sim, p_value=lrt_pvalue(t_obs, t_sim), p_value_percentile=lrt_pvalue_percentile(t_obs, t_sim), null=null, alt=alt,
                 sim_null=fits[0], sim_alt=fits[1], lightcurves=out, seconds=seconds, reproducible=reproducible,
                 paired_launches=pair_stats,
                 split=None if not sharded else ("models" if len(models) < 2 else "lightcurves"))

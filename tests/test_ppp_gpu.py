@@ -136,6 +136,7 @@ def test_protassov_test_end_to_end():
     assert res["T_sim"].shape == (24,) and np.all(np.isfinite(res["T_sim"])) and np.isfinite(res["T_obs"])
     assert np.all(res["T_sim"] > -5.0)                             # nested models: alt never much worse
     assert 1 / 25 <= res["p_value"] <= 1.0 and res["p_value"] > 0.04
+    assert abs(res["p_value_percentile"] - res["p_value"]) <= 1 / 24 and 0.0 <= res["p_value_percentile"] <= 1.0     # the tutorial's expression
     assert res["lightcurves"]["rates"].shape == (24, 250)
     # the two models' refits side by side on two contexts of their own: the same numbers as one after the other
     both = protassov_test(lc, drw(), alt, nsims=24, walkers=16, max_steps=120, sim_steps=60, sigma_noise=2.0, seed=5,

@@ -44,3 +44,43 @@ def test_lightcurve_csv_round_trip(tmp_path):
     back = GappyLightcurve.from_csv(str(f))
     assert np.allclose(back.times, lc.times, rtol=1e-8) and np.allclose(back.y, lc.y, atol=1e-5)
     assert np.allclose(back.dy, lc.dy, atol=1e-5) and np.allclose(back.exposures, 0.5)
+
+
+def test_distributions_match_the_reference_module():
+    """kraft_pdf, lognormal, create_log_normal, create_uniform_distribution (reference stats.py:10-29, 116-146) against the
+    reference module's own outputs (tests/golden/make_stats_golden.py)."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stats_golden.json")) as f:
+        dists = json.load(f)["distributions"]
+    assert len(dists) == 20
+    for d in dists:
+        x = np.array(d["x"])
+        ln, un = stats.create_log_normal(d["mean"], d["std"]), stats.create_uniform_distribution(d["mean"], d["std"])
+        np.testing.assert_allclose(ln.pdf(x), d["lognormal_pdf"], rtol=1e-13)
+        np.testing.assert_allclose(ln.ppf([0.1, 0.5, 0.9]), d["lognormal_ppf"], rtol=1e-13)
+        np.testing.assert_allclose([ln.mean(), ln.std()], d["lognormal_moments"], rtol=1e-13)
+        np.testing.assert_allclose([ln.mean(), ln.std()], [d["mean"], d["std"]], rtol=1e-10)       # what the function is for
+        np.testing.assert_allclose(un.pdf(x), d["uniform_pdf"], rtol=1e-13)
+        np.testing.assert_allclose([un.ppf(0.0), un.ppf(1.0)], d["uniform_support"], rtol=1e-13)
+        np.testing.assert_allclose([un.mean(), un.std()], [d["mean"], d["std"]], rtol=1e-10)
+        got = [float(stats.kraft_pdf(a=0)._pdf(v, d["N"], d["B"])) for v in d["s"]]
+        np.testing.assert_allclose(got, d["kraft_pdf"], rtol=1e-12)
+        np.testing.assert_allclose(stats.lognormal(a=0)._pdf(x, d["center"], d["sigma"]), d["lognormal_class_pdf"], rtol=1e-13)
+    # the Kraft posterior integrates to one and its median is the simulator's (simulator.py kraft helpers)
+    k = stats.kraft_pdf(a=0)
+    from scipy.integrate import quad
+    assert abs(quad(lambda s: k._pdf(s, 7, 2.5), 0, 80)[0] - 1.0) < 1e-9
+
+
+def test_tutorial_pvalue_expression_and_neg_log_like():
+    from scipy.stats import percentileofscore
+    sims = np.random.default_rng(1).chisquare(3, 500)
+    for t in (0.5, 3.0, 11.0, 1e3, -1.0):
+        assert stats.lrt_pvalue_percentile(t, sims) == 1 - percentileofscore(sims, t) / 100
+        assert abs(stats.lrt_pvalue_percentile(t, sims) - stats.lrt_pvalue(t, sims)) <= 1.0 / 500 + 1e-12
+
+    class FakeGP:
+        def set_parameter_vector(self, p): self.p = np.asarray(p)
+        def log_likelihood(self, y): return -float(np.sum((y - self.p[0]) ** 2))
+    g = FakeGP()
+    assert stats.neg_log_like([2.0], np.array([1.0, 4.0]), g) == 5.0 and g.p[0] == 2.0
