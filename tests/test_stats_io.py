@@ -84,3 +84,57 @@ def test_tutorial_pvalue_expression_and_neg_log_like():
         def log_likelihood(self, y): return -float(np.sum((y - self.p[0]) ** 2))
     g = FakeGP()
     assert stats.neg_log_like([2.0], np.array([1.0, 4.0]), g) == 5.0 and g.p[0] == 2.0
+
+
+def test_simple_lightcurve_reads_what_to_csv_writes_and_plain_tables(tmp_path):
+    """lightcurves/simplelightcurve.py:16-59: columns by position, a header line of names, days -> seconds by the
+    time column's name, missing exposure / background columns -> zeros (with the reference's warning)."""
+    import pytest
+    from mind_the_gaps_amd.lightcurves import SimpleLightcurve
+    rng = np.random.default_rng(3)
+    t = np.cumsum(rng.uniform(100, 200, 15))
+    lc = GappyLightcurve(t, rng.normal(10, 1, 15), rng.uniform(0.1, 0.2, 15), exposures=50.0, bkg_rate=rng.uniform(0, 1, 15),
+                         bkg_rate_err=rng.uniform(0, 0.1, 15))
+    f = tmp_path / "lc.csv"
+    lc.to_csv(str(f))
+    back = SimpleLightcurve(str(f))
+    assert back.n == 15 and np.allclose(back.times, t, rtol=1e-8) and np.allclose(back.y, lc.y, atol=1e-5)
+    assert np.allclose(back.exposures, 50.0) and np.allclose(back.bkg_rate, lc.bkg_rate, atol=1e-5) and np.allclose(back.bkg_rate_err, lc.bkg_rate_err, atol=1e-5)
+    g = tmp_path / "three.txt"
+    g.write_text("mjd,flux,err\n1.0,5.0,0.5\n2.5,6.0,0.4\n4.0,5.5,0.6\n")
+    with pytest.warns(UserWarning, match="no exposures"):
+        three = SimpleLightcurve(str(g), delimiter=",")
+    assert np.array_equal(three.times, np.array([1.0, 2.5, 4.0]) * 86400.0) and np.array_equal(three.y, [5.0, 6.0, 5.5])
+    assert np.array_equal(three.exposures, np.zeros(3)) and np.array_equal(three.bkg_rate, np.zeros(3)) and three.duration == 3.0 * 86400
+    h = tmp_path / "four.txt"
+    h.write_text("junk line\ntime rate error exposure\n0 1 0.1 2\n10 2 0.1 2\n20 3 0.1 2\n")
+    four = SimpleLightcurve(str(h), skip_header=1)
+    assert np.array_equal(four.times, [0, 10, 20]) and np.array_equal(four.exposures, [2, 2, 2]) and np.array_equal(four.bkg_rate_err, np.zeros(3))
+
+
+def test_truncate_split_rand_remove_get_simulator():
+    """gappylightcurve.py:174-293"""
+    import pytest
+    t = np.concatenate([np.arange(0.0, 50.0, 5.0), np.arange(200.0, 240.0, 5.0), np.arange(1000.0, 1030.0, 5.0)])
+    n = len(t)
+    lc = GappyLightcurve(t, np.arange(n) + 100.0, np.full(n, 0.5), exposures=2.0, bkg_rate=np.full(n, 0.1), bkg_rate_err=np.full(n, 0.01))
+    cut = lc.truncate(20.0, 205.0)
+    assert np.array_equal(cut.times, [20, 25, 30, 35, 40, 45, 200, 205]) and np.array_equal(cut.y, lc.y[4:12]) and np.array_equal(cut.exposures, np.full(8, 2.0))
+    assert lc.truncate().n == n and lc.truncate(tmin=1000.0).n == 6
+    with pytest.raises(ValueError, match="greater than or equal"):
+        lc.truncate(10.0, 10.0)
+    with pytest.raises(ValueError, match="lower than initial"):
+        lc.truncate(-20.0, -10.0)
+    pieces = lc.split(100.0)
+    assert [p.n for p in pieces] == [10, 8, 6] and np.array_equal(np.concatenate([p.times for p in pieces]), t)
+    assert [p.n for p in lc.split(1e6)] == [n]
+    import random
+    random.seed(4)
+    fewer = lc.rand_remove(7)
+    assert fewer.n == n - 7 and np.all(np.isin(fewer.times, t)) and np.all(np.diff(fewer.times) > 0)
+    assert np.array_equal(fewer.y, lc.y[np.isin(t, fewer.times)])
+    with pytest.raises(ValueError, match="greater than number"):
+        lc.rand_remove(n + 1)
+    from mind_the_gaps_amd.models.psd_models import BendingPowerlaw
+    sim = lc.get_simulator(BendingPowerlaw(S0=1.0, omega0=0.1), "Lognormal", sigma_noise=2.0, extension_factor=3)
+    assert sim.pdf == "Lognormal" and np.array_equal(sim._times, t) and sim.mean == lc.mean and sim.noise_name == "Gaussian"
