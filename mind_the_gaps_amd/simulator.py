@@ -33,7 +33,7 @@ from .modeling import ConstantModel
 from .models.psd_models import PSDModel
 from .terms import Term
 
-__all__ = ["Simulator", "kraft_median", "kraft_interval"]
+__all__ = ["Simulator", "RegularLightcurve", "kraft_median", "kraft_interval"]
 
 
 # -- Kraft, Burrows & Nousek (1991): posterior of the source counts s given N total and B background --
@@ -76,6 +76,18 @@ def kraft_interval(N, B, confidence_level=0.68):
         lo_max *= 0.999
     lo = brentq(lambda s: logpdf(s) - logpdf(upper_for(s)), 0.0, lo_max, xtol=1e-10)
     return lo, upper_for(lo)
+
+
+class RegularLightcurve:
+    """What ``Simulator.simulate_regularly_sampled`` returns: the attributes of stingray's Lightcurve the reference's
+    own code reads (``time``, ``countrate``, ``dt``, ``n``, ``tseg``, ``meanrate``; simulator.py:340-420, 503-539)."""
+
+    def __init__(self, time, countrate, dt):
+        self.time, self.countrate, self.dt = np.asarray(time), np.asarray(countrate), float(dt)
+
+    n = property(lambda self: len(self.time))
+    tseg = property(lambda self: self.n * self.dt)
+    meanrate = property(lambda self: float(np.mean(self.countrate)))
 
 
 class Simulator:
@@ -163,12 +175,14 @@ class Simulator:
     # -- PSD model ---------------------------------------------------------------------
     @property
     def psd_model(self):
-        return self._kernel.get_psd if self._kernel is not None else self._psd_callable
+        """the object the caller gave (simulator.py:267-270); a celerite term, which is not callable: its ``get_psd``"""
+        return self._psd_given if callable(self._psd_given) else self._psd_given.get_psd
 
     @psd_model.setter
     def psd_model(self, new_psd_model):
         if not callable(new_psd_model) and not isinstance(new_psd_model, Term):
             raise ValueError("PSD model must be callable (e.g., a function or Astropy model).")
+        self._psd_given = new_psd_model
         kernel = getattr(new_psd_model, "__self__", new_psd_model)
         if isinstance(kernel, PSDModel):
             try:
@@ -315,6 +329,31 @@ class Simulator:
         warnings.warn("Lightcurve did not converge after %d iterations, PDF might be inaccurate. Try increase the "
                       "maximum number of iterations" % self.max_iter)
         return current
+
+    def __str__(self):
+        return "Simulator(\n  PSD Model: %s\n  PDF: %s\n) Noise: %s" % (self.psd_model, self.pdf, self.noise_name)
+
+    def set_psd_params(self, psd_params):
+        """Set attributes of the PSD model by name before the next ``generate_lightcurve`` (simulator.py:282-298)."""
+        for name, value in psd_params.items():
+            setattr(self._psd_given, name, value)
+        self.psd_model = self._psd_given     # a closed-form spectrum is simulated through its celerite term: derive it again
+
+    def simulate_regularly_sampled(self):
+        """One TK95 realisation on the whole fine grid -- ``sim_timestamps``, longer and finer than the observed light
+        curve -- with the mean set to the simulator's (simulator.py:369-394).  The reference returns stingray's Lightcurve;
+        here an object with its ``time``, ``countrate``, ``dt``, ``n``, ``tseg`` and ``meanrate``."""
+        eng, model = self._engine()
+        seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
+        lo, hi = self._windows(self.sim_timestamps)
+        kw = dict(noise_kind=0, want_segments=True)
+        if model is None:
+            out = eng.simulate_tk95(1, seed, self.fftndatapoints, self.sim_dt, self.mean, self.fftndatapoints, lo, hi,
+                                    psd_table=self._psd_table(), **kw)
+        else:
+            out = eng.simulate_tk95(model.full[model.free_index][None, :], seed, self.fftndatapoints, self.sim_dt, self.mean,
+                                    self.fftndatapoints, lo, hi, **kw)
+        return RegularLightcurve(self.sim_timestamps, out["segments"][0], self.sim_dt)
 
     def generate_lightcurve(self):
         """One noise-free realisation on the observing pattern (simulator.py:397-420)."""

@@ -235,3 +235,29 @@ def test_chirp_z_transform_even_and_odd_lengths(monkeypatch):
         seen.add(sim.fftndatapoints % 2)
         assert np.max(np.abs(got["1"] - got["0"])) <= 1e-11 * np.std(got["0"]), (seed, sim.fftndatapoints)
     assert seen == {0, 1}
+
+
+def test_regularly_sampled_series_str_and_set_psd_params():
+    """simulator.py:260-298, 369-394: the whole fine-grid realisation (mean = the simulator's, variance = the PSD's integral),
+    down-sampled by the reference's rule it gives a light curve on the observing pattern; __str__; set_psd_params."""
+    from mind_the_gaps_amd.models.psd_models import BendingPowerlaw
+    times = np.arange(0.0, 600.0, 1.0)
+    psd = BendingPowerlaw(S0=4.0, omega0=2 * np.pi / 30)
+    sim = Simulator(psd, times, 1.0, 50.0, pdf="Gaussian", sigma_noise=1.0, extension_factor=20, random_state=3)
+    lc = sim.simulate_regularly_sampled()
+    assert lc.n == sim.fftndatapoints == len(lc.countrate) and lc.dt == sim.sim_dt and np.array_equal(lc.time, sim.sim_timestamps)
+    assert abs(lc.meanrate - 50.0) < 1e-9 and abs(lc.tseg - lc.n * lc.dt) < 1e-9
+    assert 0.5 * 4.0 < np.var(lc.countrate) < 1.6 * 4.0             # S0 is the variance of this model (one realisation, 20 x 600 / 30 bends)
+    down = sim.downsample(lc)
+    assert len(down) == len(times) and np.all(np.isfinite(down)) and abs(np.mean(down) - 50.0) < 2.0
+    other = sim.simulate_regularly_sampled()
+    assert not np.array_equal(other.countrate, lc.countrate)        # the simulator's generator moved on
+    text = str(sim)
+    assert text.startswith("Simulator(") and "PDF: Gaussian" in text and "Noise: Gaussian" in text
+    sim.set_psd_params({"S0": 400.0})
+    assert psd.S0 == 400.0 and np.var(sim.simulate_regularly_sampled().countrate) > 20 * 4.0
+    # a celerite kernel as the PSD: the same entry
+    from mind_the_gaps_amd.models import DampedRandomWalk
+    sim2 = Simulator(DampedRandomWalk(np.log(4.0), np.log(2 * np.pi / 30)), times, 1.0, 50.0, sigma_noise=1.0, extension_factor=20, random_state=3)
+    lc2 = sim2.simulate_regularly_sampled()
+    assert lc2.n == sim2.fftndatapoints and abs(lc2.meanrate - 50.0) < 1e-9 and 0.5 * 4.0 < np.var(lc2.countrate) < 1.6 * 4.0
