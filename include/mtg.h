@@ -226,6 +226,17 @@ MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index);
  * blocks over several GPUs needs to be the set of one call, bit for bit (with mtg_set_stream_base); default 1.
  */
 MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on);
+/*
+ * The reference's simulator draws from numpy's GLOBAL generator -- get_fft (simulator.py:468-501): real, im =
+ * np.random.normal(0, size=(2, N // 2 + 1)); cut_random_segment (simulator.py:536-539): np.random.uniform -- so a user who
+ * calls np.random.seed() gets the same light curve every time.  For that user the host draws those numbers in the
+ * reference's order and hands them to the NEXT mtg_simulate_tk95 of this context in place of its own Philox streams:
+ * normals [S][2][nk] (per series the row of real parts, then the row of imaginary parts, nk = nfft / 2 + 1; entry 0 of
+ * either is unused as in the reference) and starts [S], the index of the first fine-grid sample of each series' cut.
+ * The spectrum scaling, the inverse transform, the cut, the window averages stay on the device.  Consumed by one call
+ * (which must have the same S and nfft; every start + seg_len <= nfft); S = 0 clears.  `Simulator(..., stream="numpy")`.
+ */
+MTG_API int mtg_set_simulate_draws(mtg_ctx *ctx, int64_t S, int64_t nk, const double *normals, const int64_t *starts);
 MTG_API int mtg_set_sort(mtg_ctx *ctx, int mode);
 /*
  * The serial sweep as a two-wave pipeline (csrc/mtg_kernels_pipe.hip): 0 = never, 1 = whenever the model has the

@@ -141,6 +141,9 @@ struct mtg_ctx {
         DevBuf chirp, bhat, work;
         struct { hipfftHandle h = 0; bool have = false; int64_t m = 0; int pairs = 0; } plans[2];
     } czt;
+    // draws handed in by the caller for the NEXT mtg_simulate_tk95 (mtg_set_simulate_draws): standard normals
+    // [S][2][nfft / 2 + 1] and segment starts [S]
+    struct { DevBuf normals, starts; std::vector<int64_t> starts_host; int64_t S = 0, nk = 0; } given;
 
     // side streams: the structures (signatures) of a small batch run next to each other
     hipStream_t side[MTG_MAX_J / 2] = {};
@@ -1861,6 +1864,18 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
                         (long long)n, win_lo[n], win_hi[n], (long long)seg_len);
     if (make_resident && ctx->t_per_lc)
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: make_resident needs a shared sampling");
+    // draws handed in for this call (consumed whatever happens next)
+    const int64_t given_S = ctx->given.S, given_nk = ctx->given.nk;
+    ctx->given.S = 0;
+    if (given_S && (given_S != S || given_nk != nfft / 2 + 1))
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: the draws of mtg_set_simulate_draws are for %lld series of %lld frequencies, "
+                    "this call simulates %lld of %lld", (long long)given_S, (long long)given_nk, (long long)S, (long long)(nfft / 2 + 1));
+    for (int64_t i = 0; i < given_S; ++i)  // a start is an index into the series: the kernels do not check it
+        if (ctx->given.starts_host[i] + seg_len > nfft)
+            return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: given start %lld + segment %lld beyond the series of %lld samples",
+                        (long long)ctx->given.starts_host[i], (long long)seg_len, (long long)nfft);
+    const double *given_normals = given_S ? ctx->given.normals.as<double>() : nullptr;
+    const int64_t *given_starts = given_S ? ctx->given.starts.as<int64_t>() : nullptr;
     rc = use_device(ctx);
     if (rc) return rc;
     mtg_trace::Range range("mtg:simulate_tk95");
@@ -1936,7 +1951,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         const int64_t sc = s0 + chunk <= S ? chunk : S - s0;
         what = "simulation kernels";
         mtg_launch_tk95_spectrum(sc, s0, ctx->stream_base, nfft, sim_dt, ctx->coef.as<double>(), ctx->cstride, lay, m.nr0, m.nc0,
-                                 d_sig.as<int32_t>(), psd_table ? d_psd.as<double>() : nullptr, psd_rows, seed,
+                                 d_sig.as<int32_t>(), psd_table ? d_psd.as<double>() : nullptr, psd_rows, seed, given_normals,
                                  spec.as<double2>(), s);
         if (czt) {
             // pairs of series through two power-of-two complex transforms (a short last group packs zeros into the
@@ -1965,10 +1980,10 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         }
         mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
                                 d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
-                                -1, seed, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+                                -1, seed, given_starts, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
         if (segments)
             mtg_launch_tk95_segment(sc, s0, ctx->stream_base, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
-                                    d_seg.as<double>(), s);
+                                    given_starts, d_seg.as<double>(), s);
         e = hipGetLastError();
     }
     DevBuf yv_tmp;
@@ -2028,7 +2043,7 @@ MTG_API int mtg_tk95_observe_series(mtg_ctx *ctx, int64_t S, int64_t nfft, int64
     if (e == hipSuccess) {
         // scale = dt = 1, mean 0, no noise: the plain window average of the series
         mtg_launch_tk95_observe(S, 0, 0, N, nfft, seg_len, 1.0, 1.0, 0.0, d_series.as<double>(), d_lo.as<int32_t>(),
-                                d_hi.as<int32_t>(), 0, 0.0, nullptr, start, 0, nullptr, d_rates.as<double>(),
+                                d_hi.as<int32_t>(), 0, 0.0, nullptr, start, 0, nullptr, nullptr, d_rates.as<double>(),
                                 d_dy.as<double>(), s);
         e = hipGetLastError();
     }
@@ -2189,6 +2204,29 @@ MTG_API int mtg_set_time_parallel(mtg_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 3) return MTG_E_ARG;
     ctx->tp_mode = mode;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_simulate_draws(mtg_ctx *ctx, int64_t S, int64_t nk, const double *normals, const int64_t *starts)
+{
+    if (!ctx) return MTG_E_ARG;
+    ctx->given.S = 0;
+    ctx->given.nk = 0;
+    if (S == 0) return MTG_OK;  // cleared
+    if (S < 0 || nk < 3 || !normals || !starts) return fail(ctx, MTG_E_ARG, "mtg_set_simulate_draws: bad arguments");
+    for (int64_t i = 0; i < S; ++i)
+        if (starts[i] < 0) return fail(ctx, MTG_E_ARG, "mtg_set_simulate_draws: starts[%lld] = %lld is negative", (long long)i, (long long)starts[i]);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    CTX_STREAM(ctx, s);
+    HIP_TRY(ctx, ctx->given.normals.reserve((size_t)S * 2 * nk * 8));
+    HIP_TRY(ctx, ctx->given.starts.reserve((size_t)S * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->given.normals.p, normals, (size_t)S * 2 * nk * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->given.starts.p, starts, (size_t)S * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));  // the caller's arrays are free again
+    ctx->given.starts_host.assign(starts, starts + S);
+    ctx->given.S = S;
+    ctx->given.nk = nk;
     return MTG_OK;
 }
 

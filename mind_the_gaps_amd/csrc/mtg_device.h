@@ -197,13 +197,14 @@ void mtg_launch_initial_best(int E, int W, int P, const double *coords, const do
 // TK95 light-curve simulation (mtg_simulate.hip)
 void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, double dt, const double *coef, int64_t cstride,
                               MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
-                              int64_t psd_rows, uint64_t seed, double2 *X, hipStream_t);
+                              int64_t psd_rows, uint64_t seed, const double *given, double2 *X, hipStream_t);
 void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
-                             double mean_rate, const double *series, uint64_t seed, double *out, hipStream_t);
+                             double mean_rate, const double *series, uint64_t seed, const int64_t *given_start, double *out,
+                             hipStream_t);
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
-                             uint64_t seed, double *clean, double *rates, double *dy, hipStream_t);
+                             uint64_t seed, const int64_t *given_start, double *clean, double *rates, double *dy, hipStream_t);
 void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const double *dy, double2 *yv, double *means,
                               hipStream_t);
 // inverse real transform of a length with large prime factors on power-of-two transforms (chirp-z; mtg_simulate.hip)

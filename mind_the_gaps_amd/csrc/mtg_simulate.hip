@@ -80,7 +80,7 @@ __device__ inline double mtg_psd(const double *cf, int64_t cs, const MtgCoefLayo
 __global__ void __launch_bounds__(256)
 mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, double dt, const double *coef, int64_t cstride,
                          MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
-                         int64_t psd_rows, uint32_t seed_lo, uint32_t seed_hi, double2 *X)
+                         int64_t psd_rows, uint32_t seed_lo, uint32_t seed_hi, const double *given, double2 *X)
 {
     const int64_t nk = nfft / 2 + 1;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,8 +98,13 @@ mtg_tk95_spectrum_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, dou
             power = mtg_psd(coef + sg, cstride, lay, nr, nc, w);
         }
         const double amp = sqrt(0.5 * power);
-        const Philox r = philox4x32_10((uint32_t)k, PURPOSE_SPECTRUM, (uint32_t)(sg + sbase), (uint32_t)(k >> 32), seed_lo, seed_hi);
-        normal2(r, &re, &im);
+        if (given) {  // the caller's own standard normals (mtg_set_simulate_draws): [series][re | im][k]
+            re = given[(2 * sg) * nk + k];
+            im = given[(2 * sg + 1) * nk + k];
+        } else {
+            const Philox r = philox4x32_10((uint32_t)k, PURPOSE_SPECTRUM, (uint32_t)(sg + sbase), (uint32_t)(k >> 32), seed_lo, seed_hi);
+            normal2(r, &re, &im);
+        }
         re *= amp; im *= amp;
         if (2 * k == nfft) im = 0.0;  // Nyquist term of an even-length series is real
     }
@@ -124,12 +129,12 @@ __device__ inline int64_t tk95_segment_start(int64_t sg, int64_t nfft, int64_t s
 // amplitude adjustment before down-sampling): out[sg][j] = series[s][j0 + j] scale / dt + mean.
 __global__ void __launch_bounds__(256)
 mtg_tk95_segment_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale, double mean_rate,
-                        const double *series, uint32_t seed_lo, uint32_t seed_hi, double *out)
+                        const double *series, uint32_t seed_lo, uint32_t seed_hi, const int64_t *given_start, double *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * seg_len) return;
     const int64_t s = i / seg_len, j = i % seg_len, sg = s0 + s;
-    const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, -1, seed_lo, seed_hi);
+    const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, given_start ? given_start[sg] : -1, seed_lo, seed_hi);
     out[sg * seg_len + j] = series[s * nfft + j0 + j] * scale / dt + mean_rate;
 }
 
@@ -138,12 +143,12 @@ __global__ void __launch_bounds__(256)
 mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                         double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                         int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
-                        uint32_t seed_lo, uint32_t seed_hi, double *clean, double *rates, double *dy)
+                        uint32_t seed_lo, uint32_t seed_hi, const int64_t *given_start, double *clean, double *rates, double *dy)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * N) return;
     const int64_t s = i / N, n = i % N, sg = s0 + s;
-    const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, fixed_start, seed_lo, seed_hi);
+    const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, given_start ? given_start[sg] : fixed_start, seed_lo, seed_hi);
     const double *x = series + s * nfft + j0;
     const int lo = win_lo[n], hi = win_hi[n];
     double acc = 0.0;
@@ -333,30 +338,31 @@ void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const d
 
 void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, double dt, const double *coef, int64_t cstride,
                               MtgCoefLayout lay, int nr0, int nc0, const int32_t *sig, const double *psd_table,
-                              int64_t psd_rows, uint64_t seed, double2 *X, hipStream_t st)
+                              int64_t psd_rows, uint64_t seed, const double *given, double2 *X, hipStream_t st)
 {
     const int64_t n = S * (nfft / 2 + 1);
     hipLaunchKernelGGL(mtg_tk95_spectrum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, nfft, dt,
-                       coef, cstride, lay, nr0, nc0, sig, psd_table, psd_rows, (uint32_t)seed, (uint32_t)(seed >> 32), X);
+                       coef, cstride, lay, nr0, nc0, sig, psd_table, psd_rows, (uint32_t)seed, (uint32_t)(seed >> 32), given, X);
 }
 
 void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
-                             double mean_rate, const double *series, uint64_t seed, double *out, hipStream_t st)
+                             double mean_rate, const double *series, uint64_t seed, const int64_t *given_start, double *out,
+                             hipStream_t st)
 {
     const int64_t n = S * seg_len;
     hipLaunchKernelGGL(mtg_tk95_segment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, nfft, seg_len,
-                       dt, scale, mean_rate, series, (uint32_t)seed, (uint32_t)(seed >> 32), out);
+                       dt, scale, mean_rate, series, (uint32_t)seed, (uint32_t)(seed >> 32), given_start, out);
 }
 
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
-                             uint64_t seed, double *clean, double *rates, double *dy, hipStream_t st)
+                             uint64_t seed, const int64_t *given_start, double *clean, double *rates, double *dy, hipStream_t st)
 {
     const int64_t n = S * N;
     hipLaunchKernelGGL(mtg_tk95_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, N, nfft,
                        seg_len, dt, scale, mean_rate, series, win_lo, win_hi, noise_kind, sigma_noise, exposures,
-                       fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), clean, rates, dy);
+                       fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), given_start, clean, rates, dy);
 }
 
 

@@ -33,6 +33,7 @@ EXPORTS = (
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
     "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs",
+    "mtg_set_simulate_draws",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
 
@@ -249,6 +250,8 @@ def load_library():
     lib.mtg_simulate_plan.argtypes = [c_vp, c_i64]
     lib.mtg_set_simulate_pairs.restype = c_int
     lib.mtg_set_simulate_pairs.argtypes = [c_vp, c_int]
+    lib.mtg_set_simulate_draws.restype = c_int
+    lib.mtg_set_simulate_draws.argtypes = [c_vp, c_i64, c_i64, _dp, ctypes.POINTER(c_i64)]
     lib.mtg_pair_contexts.restype = c_int
     lib.mtg_pair_contexts.argtypes = [c_vp, c_vp]
     lib.mtg_unpair_contexts.restype = c_int
@@ -759,6 +762,19 @@ class Engine:
         """False: one series per transform in simulate_tk95's chirp-z path -- a series' values then do not depend on the
         other series of the call (include/mtg.h: mtg_set_simulate_pairs)."""
         self._check(self._lib.mtg_set_simulate_pairs(self._ctx, 1 if on else 0))
+
+    def set_simulate_draws(self, normals, starts):
+        """Hand the next simulate_tk95 its random numbers (include/mtg.h: mtg_set_simulate_draws): ``normals`` [S][2][nk]
+        standard normals, ``starts`` [S] first fine-grid index of every cut.  ``None``: clear."""
+        if normals is None:
+            self._check(self._lib.mtg_set_simulate_draws(self._ctx, 0, 0, None, None))
+            return
+        normals = _f64(normals)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        if normals.ndim != 3 or normals.shape[1] != 2 or starts.shape != (normals.shape[0],):
+            raise ValueError("normals must be [S][2][nk] and starts [S]")
+        self._check(self._lib.mtg_set_simulate_draws(self._ctx, normals.shape[0], normals.shape[2], _ptr(normals),
+                                                     starts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
 
     def set_pipeline(self, mode):
         """0: never the two-wave pipeline of the serial sweep, 1: whenever compiled, 2 (default): for batches of ~8e3 to

@@ -23,6 +23,14 @@ Protassov hot path): the Emmanoulopoulos et al. (2013) amplitude adjustment for
 ``pdf="lognormal" | "uniform"`` (simulator.py:65-131), applied to the fine-grid segments the device
 returns, and the Kraft et al. (1991) treatment of low-count epochs with background
 (noise_models.py:81-150).
+
+Random numbers.  Default (``stream="philox"``): counter-based streams on the device, keyed by (seed, series index) -- what
+the batched Protassov loop needs.  ``stream="numpy"``: the reference draws everything from numpy's GLOBAL generator
+(get_fft, simulator.py:468-501; cut_random_segment, :536-539; the noise classes, noise_models.py:71,182), so
+``np.random.seed(s)`` fixes its light curves; in this mode the host makes those draws in the reference's order and the
+device does the arithmetic with them (``mtg_set_simulate_draws``): ``generate_lightcurve`` / ``add_noise`` then return the
+REFERENCE'S light curve for a seed, to the rounding of the transform (tests/test_simulator_gpu.py: the two light curves of
+docs/notebooks/celerite_variance.ipynb, whose variances the notebook prints).  Gaussian flux PDF only.
 """
 import warnings
 
@@ -95,7 +103,12 @@ class Simulator:
 
     def __init__(self, psd_model, times, exposures, mean, pdf="gaussian", bkg_rate=None, bkg_rate_err=None,
                  sigma_noise=None, aliasing_factor=2, extension_factor=10, epsilon=1.001, max_iter=400,
-                 random_state=None, device=0, kraft_counts=15):
+                 random_state=None, device=0, kraft_counts=15, stream="philox"):
+        if stream not in ("philox", "numpy"):
+            raise ValueError("stream must be 'philox' or 'numpy'")
+        if stream == "numpy" and pdf.lower() != "gaussian":
+            raise NotImplementedError("stream='numpy' reproduces the reference's Gaussian (TK95) light curves only")
+        self.stream = stream
         if extension_factor < 1:
             raise ValueError("Extension factor must be greater than 1")
         if epsilon < 1:
@@ -237,6 +250,9 @@ class Simulator:
         without an ``index_base``, off with one (a block's series must not depend on where the block was cut).  A caller
         that cuts at EVEN global indices -- so that every series keeps the partner it has in the whole set -- may turn it
         on and keep both the speed and the invariance (``ppp.protassov_test`` does)."""
+        if self.stream == "numpy":
+            raise NotImplementedError("stream='numpy' serves generate_lightcurve / simulate_regularly_sampled / add_noise (one light "
+                                      "curve per call, as the reference); the batched simulate() draws on the device")
         eng, model = self._engine()
         if seed is None:
             seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
@@ -343,6 +359,8 @@ class Simulator:
         """One TK95 realisation on the whole fine grid -- ``sim_timestamps``, longer and finer than the observed light
         curve -- with the mean set to the simulator's (simulator.py:369-394).  The reference returns stingray's Lightcurve;
         here an object with its ``time``, ``countrate``, ``dt``, ``n``, ``tseg`` and ``meanrate``."""
+        if self.stream == "numpy":
+            return RegularLightcurve(self.sim_timestamps, self._generate_with_reference_draws(whole_grid=True)["segments"][0], self.sim_dt)
         eng, model = self._engine()
         seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
         lo, hi = self._windows(self.sim_timestamps)
@@ -355,8 +373,38 @@ class Simulator:
                                     self.fftndatapoints, lo, hi, **kw)
         return RegularLightcurve(self.sim_timestamps, out["segments"][0], self.sim_dt)
 
+    def _reference_draws(self):
+        """The reference's draws for one light curve, from numpy's global generator in its order: the spectrum's standard
+        normals (simulator.py:486) and the cut (:538, then stingray's truncate: first sample at or after the drawn start,
+        last sample at or before start + sim_duration -- both kept, which the variances printed in
+        docs/notebooks/celerite_variance.ipynb decide).  -> normals [1][2][nk], first index, samples in the cut"""
+        grid = self.sim_timestamps
+        normals = np.random.normal(0, size=(2, self.fftndatapoints // 2 + 1))
+        shift = np.random.uniform(grid[0], grid[-1] - self.sim_duration)
+        first = int(np.flatnonzero(grid >= shift)[0])
+        last = int(np.flatnonzero(grid <= shift + self.sim_duration)[-1])
+        return normals[None, :, :], first, last - first + 1
+
+    def _generate_with_reference_draws(self, whole_grid=False):
+        eng, model = self._engine()
+        normals, first, count = self._reference_draws() if not whole_grid else \
+            (np.random.normal(0, size=(2, self.fftndatapoints // 2 + 1))[None, :, :], 0, self.fftndatapoints)
+        cut_times = self.strategy[0][0] + self.sim_dt / 2 + np.arange(count) * self.sim_dt
+        lo, hi = self._windows(self.sim_timestamps if whole_grid else cut_times)
+        eng.set_simulate_draws(normals, [first])
+        try:
+            if model is None:
+                return eng.simulate_tk95(1, 0, self.fftndatapoints, self.sim_dt, self.mean, count, lo, hi,
+                                         psd_table=self._psd_table(), noise_kind=0, want_segments=whole_grid)
+            return eng.simulate_tk95(model.full[model.free_index][None, :], 0, self.fftndatapoints, self.sim_dt, self.mean, count,
+                                     lo, hi, noise_kind=0, want_segments=whole_grid)
+        finally:
+            eng.set_simulate_draws(None, None)
+
     def generate_lightcurve(self):
         """One noise-free realisation on the observing pattern (simulator.py:397-420)."""
+        if self.stream == "numpy":
+            return self._generate_with_reference_draws()["rates"][0]
         return self.simulate(noise=False)["rates"][0]
 
     def add_noise(self, rates):
@@ -364,11 +412,12 @@ class Simulator:
         on the host with this simulator's RandomState; the batched path adds Gaussian and Poisson noise on
         the device."""
         rates = np.asarray(rates, dtype=np.float64)
+        rng = np.random if self.stream == "numpy" else self.random_state      # the reference's noise classes: the global generator
         if self._noise_kind == 1:
-            return rates + self.random_state.normal(scale=self.sigma_noise, size=len(rates)), \
+            return rates + rng.normal(scale=self.sigma_noise, size=len(rates)), \
                 self.sigma_noise * np.ones(len(rates))
         expo, bkg = self._exposures, self._bkg_counts
-        total = self.random_state.poisson(rates * expo + bkg).astype(np.float64)
+        total = rng.poisson(rates * expo + bkg).astype(np.float64)
         net_rates = (total - bkg) / expo
         dy = np.sqrt((np.sqrt(total) / expo) ** 2 + self._bkg_rate_err ** 2)
         if self._noise_kind == 3:

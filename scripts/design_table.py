@@ -132,7 +132,7 @@ def rows():
          "as a10; `test_chain_autocorr_on_the_device_matches_the_host`",
          "one solve + one sampler launch per iteration (speculative) or per half-step, no host round trip"),
         ("f2 simulator", "`csrc/mtg_simulate.hip`, `simulator.py`, `models/psd_models.py`",
-         "`test_simulator_gpu` (exact host replay, chirp-z vs library transform, moments, noise), `test_simulator_reference_cases` (the "
+         "`test_simulator_gpu` (exact host replay, chirp-z vs library transform, moments, noise; `stream=numpy`: the reference notebook's own light curves for its seeds), `test_simulator_reference_cases` (the "
          "reference's known answers), `test_psd_models`, `test_ppp_gpu` (block invariance)",
          "%d × %s-point simulations in %.2f s inside the workflow" % (wf["nsims"], sci(wf["fft_points_per_simulation"]), wf["seconds"]["simulate"])),
         ("f3 predict", "`mtg_predict_kernel`, `mtg_apply_inverse_kernel`, `GP.predict`, `standarized_residuals`",

@@ -261,3 +261,75 @@ def test_regularly_sampled_series_str_and_set_psd_params():
     sim2 = Simulator(DampedRandomWalk(np.log(4.0), np.log(2 * np.pi / 30)), times, 1.0, 50.0, sigma_noise=1.0, extension_factor=20, random_state=3)
     lc2 = sim2.simulate_regularly_sampled()
     assert lc2.n == sim2.fftndatapoints and abs(lc2.meanrate - 50.0) < 1e-9 and 0.5 * 4.0 < np.var(lc2.countrate) < 1.6 * 4.0
+
+
+def _golden_module():
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_notebook_data.py")
+    spec = importlib.util.spec_from_file_location("make_notebook_data", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_numpy_stream_gives_the_reference_notebooks_light_curves():
+    """stream="numpy": np.random.seed(45) / (4) and the calls of docs/notebooks/celerite_variance.ipynb cells 6 / 14 return
+    the light curves the NOTEBOOK had -- tests/golden/notebook_variance_data.npz, whose variances match the digits the
+    notebook printed (tests/test_notebook_known_answer.py) -- to the rounding of the transform (the reference carries a
+    10^6 zero-frequency term through its own: ~1e-11 of noise)."""
+    import os
+    from mind_the_gaps_amd.models.psd_models import BendingPowerlaw as BPL, Lorentzian as Lor
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "notebook_variance_data.npz"))
+    times = np.linspace(0, 5000, 5000)
+    exposures = 0.5 * np.ones(5000)
+    w0 = 2 * np.pi / 100
+    for seed, psd_model, key, printed in ((45, BPL(S0=1.0, omega0=w0), "cell6_rates", "0.97372"), (4, Lor(S0=1.0, omega0=w0, Q=5), "cell14_rates", "0.96105")):
+        np.random.seed(seed)
+        simulator = Simulator(psd_model, times, exposures, mean=0, pdf="Gaussian", extension_factor=1.0, stream="numpy")
+        rates = simulator.generate_lightcurve()
+        assert np.max(np.abs(rates - data[key])) < 1e-9 and "%.5f" % np.var(rates) == printed      # "Sample Variance: ..."
+        # the generator was left where the reference leaves it: the next draw is the same
+        state_next = np.random.uniform()
+        np.random.seed(seed)
+        np.random.normal(0, size=(2, simulator.fftndatapoints // 2 + 1)); np.random.uniform()
+        assert np.random.uniform() == state_next
+
+
+def test_numpy_stream_against_the_restated_reference_pipeline():
+    """an ordinary case (gaps, unequal exposures, the series 3x longer than the light curve, a celerite kernel's get_psd as
+    the spectrum, a mean), against tests/golden/make_notebook_data.reference_lightcurve; then noise from the global
+    generator as noise_models.py:71,182 draws it"""
+    from mind_the_gaps_amd import terms
+    from mind_the_gaps_amd.models.celerite_models import Lorentzian
+    ref = _golden_module().reference_lightcurve
+    rng = np.random.default_rng(8)
+    times = np.cumsum(rng.uniform(2.0, 5.0, 300))
+    times[150:] += 400.0
+    exposures = rng.uniform(0.8, 1.6, 300)
+    kernel = Lorentzian(np.log(40.0), np.log(30.0), np.log(2 * np.pi / 25)) + terms.RealTerm(np.log(60.0), np.log(2 * np.pi / 90))
+    for trial in range(3):
+        np.random.seed(100 + trial)
+        want = ref(kernel.get_psd, times, exposures, 50.0, 3)
+        want_noisy = want + np.random.normal(scale=2.0, size=len(want))
+        np.random.seed(100 + trial)
+        simulator = Simulator(kernel.get_psd, times, exposures, 50.0, pdf="Gaussian", sigma_noise=2.0, extension_factor=3, stream="numpy")
+        rates = simulator.generate_lightcurve()
+        noisy, dy = simulator.add_noise(rates)
+        assert np.max(np.abs(rates - want)) < 1e-8 and np.max(np.abs(noisy - want_noisy)) < 1e-8 and np.all(dy == 2.0)
+    # Poisson noise: np.random.poisson of the same expected counts
+    np.random.seed(7)
+    simulator = Simulator(kernel.get_psd, times, exposures, 50.0, extension_factor=3, stream="numpy")
+    rates = simulator.generate_lightcurve()
+    state = np.random.get_state()
+    noisy, dy = simulator.add_noise(rates)
+    np.random.set_state(state)
+    counts = np.random.poisson(rates * exposures)
+    assert np.array_equal(noisy, counts / exposures) and np.allclose(dy, np.sqrt(counts) / exposures)
+    # the whole fine-grid series of simulate_regularly_sampled: same normals, no cut
+    np.random.seed(11)
+    lc = simulator.simulate_regularly_sampled()
+    assert lc.n == simulator.fftndatapoints and abs(lc.meanrate - 50.0) < 1e-9
+    with pytest.raises(NotImplementedError):
+        simulator.simulate(nsims=2)
+    with pytest.raises(NotImplementedError):
+        Simulator(kernel.get_psd, times, exposures, 50.0, pdf="Lognormal", stream="numpy")
