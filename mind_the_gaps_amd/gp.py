@@ -208,9 +208,13 @@ class LogProbEvaluator:
 class GP(ModelSet):
     """celerite.GP look-alike; parameters are ``kernel:*`` then ``mean:*``."""
 
-    def __init__(self, kernel, mean=0.0, fit_mean=False, device=0, own_engine=False):
+    def __init__(self, kernel, mean=0.0, fit_mean=False, log_white_noise=None, fit_white_noise=False, device=0, own_engine=False):
         if not isinstance(kernel, Term):
             raise TypeError("kernel must be a mind_the_gaps_amd Term")
+        if log_white_noise is not None:
+            # celerite's extra diagonal model; the reference never passes one (its notebooks give fit_white_noise=False
+            # with the default None, docs/notebooks/poisson_level.ipynb cell 5): white noise goes in as a JitterTerm
+            raise NotImplementedError("log_white_noise: add a JitterTerm to the kernel instead")
         try:
             mean = ConstantModel(float(mean))
         except TypeError:

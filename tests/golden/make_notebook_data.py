@@ -56,6 +56,35 @@ def reference_lightcurve(psd_model, times, exposures, mean, extension_factor, al
     return np.array([np.mean(cut_r[(cut_t >= a) & (cut_t < b)]) for a, b in windows])
 
 
+def reference_regular_series(psd_model, times, exposures, mean, extension_factor, aliasing_factor=2):
+    """Simulator(...).simulate_regularly_sampled() (simulator.py:369-394): the whole fine-grid series -> (grid, rates)"""
+    sim_dt = np.min(exposures) / aliasing_factor
+    dt = np.diff(times)
+    start_time = times[0] - dt[0] / 1.99
+    grid = np.arange(start_time - sim_dt, start_time + (times[-1] - times[0]) * extension_factor + sim_dt, sim_dt)
+    n = len(grid)
+    omega = np.fft.rfftfreq(n, sim_dt) * 2 * np.pi
+    re, im = np.random.normal(0, size=(2, n // 2 + 1))
+    spectrum = np.empty(len(omega), dtype=complex)
+    spectrum[1:] = (re + 1j * im)[1:] * np.sqrt(0.5 * psd_model(omega[1:]))
+    spectrum[0] = 1e6
+    if n % 2 == 0:
+        spectrum[-1] = spectrum[-1].real
+    rate = np.fft.irfft(spectrum, n=n) * np.sqrt(n * sim_dt * np.sqrt(2 * np.pi)) / sim_dt
+    return grid, rate - np.mean(rate) + mean
+
+
+def poisson_level_series():
+    """docs/notebooks/poisson_level.ipynb cells 2 and 4 (executed one after the other, np.random.seed(42) in the first):
+    1 728 002 points.  Cell 4 prints the kernel it builds from the series' variance, `DampedRandomWalk(0.017072777961537826,
+    ...)`: log(np.var(lc.countrate)) with all its digits -- this restatement gives exactly that number.
+    -> (time, noiseless rates, rates + the cell's Gaussian noise)"""
+    np.random.seed(42)
+    times = np.linspace(0, 1000, 1000) * 3600 * 24
+    grid, rate = reference_regular_series(BendingPowerlaw(S0=1.0, omega0=np.exp(-13)), times, 1000 * np.ones(1000), 0, 10)
+    return grid, rate, rate + np.random.normal(0, 0.5, size=len(rate))
+
+
 def main():
     times = np.linspace(0, 5000, 5000)
     exposures = 0.5 * np.ones(5000)
@@ -70,6 +99,9 @@ def main():
         print("%s: variance %.12f, the notebook's %.5f and %.12f (difference %.1e)" % (name, var, printed5, target, var - target))
         assert "%.5f" % var == "%.5f" % printed5 and abs(var - target) < 6e-9
     np.savez(os.path.join(HERE, "notebook_variance_data.npz"), times=times, cell6_rates=drw, cell14_rates=lor)
+    grid, rate, _ = poisson_level_series()
+    print("poisson_level: %d points, log variance %r, the notebook's 0.017072777961537826" % (len(grid), float(np.log(np.var(rate)))))
+    assert abs(np.log(np.var(rate)) - 0.017072777961537826) < 1e-14
 
 
 if __name__ == "__main__":
