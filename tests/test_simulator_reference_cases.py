@@ -197,3 +197,30 @@ def test_kraft_noise_through_generate_from_posteriors(engine):
     out = simu.simulate(np.tile(kernel.get_parameter_vector(), (6, 1)), make_resident=True)
     assert out["rates"].shape == (6, len(times)) and np.all(np.isfinite(out["rates"])) and np.all(out["dy"] > 0)
     assert abs(out["rates"].mean() - 20.0) < 2.0
+
+
+def test_noise_model_classes_are_the_simulators_noise():
+    """mind_the_gaps/noise_models.py:14-184 by name: same numbers as Simulator(stream="numpy").add_noise for the same state of
+    numpy's global generator (both draw from it, as the reference does), names and error shapes as there"""
+    from mind_the_gaps_amd import noise_models as nm
+    rng = np.random.default_rng(2)
+    n = 40
+    times = np.arange(n) * 10.0
+    exposures = rng.uniform(1.0, 3.0, n)
+    rates = rng.uniform(0.5, 30.0, n)
+    rates[:8] = rng.uniform(0.0, 2.0, 8)                      # faint epochs: the Kraft branch
+    bkg_rate, bkg_err = rng.uniform(0.1, 0.5, n), rng.uniform(0.01, 0.05, n)
+    flat = lambda w: np.ones_like(w)
+    cases = [(nm.GaussianNoise(exposures, 1.5), dict(sigma_noise=1.5), "Gaussian"),
+             (nm.PoissonNoise(exposures), dict(), "Poisson"),
+             (nm.KraftNoise(exposures, bkg_rate * exposures, bkg_err), dict(bkg_rate=bkg_rate, bkg_rate_err=bkg_err), "Kraft")]
+    for model, kwargs, name in cases:
+        sim = Simulator(flat, times, exposures, 10.0, stream="numpy", **kwargs)
+        assert model.name == name == sim.noise_name
+        np.random.seed(3)
+        got, got_dy = model.add_noise(rates.copy())
+        np.random.seed(3)
+        want, want_dy = sim.add_noise(rates.copy())
+        assert np.array_equal(got, want) and np.array_equal(got_dy, want_dy) and got.shape == got_dy.shape == (n,)
+    with pytest.raises(NotImplementedError):
+        nm.BaseNoise("x").add_noise(rates)
