@@ -28,7 +28,8 @@ region.  "weak" gives every rank its own 2000 light curves instead.
 The JSON line also carries
   roofline        : algorithmic bytes (24 N + 8 P + 12 per evaluation) / mean
                     duration of the dominant kernel (named by the library: mtg_last_solver), HIP events
-                    on the launch stream; the binding resource is FP64 vector issue ("fp64_valu");
+                    on the launch stream; "bound": "hbm" (the contract's nominal roofline), "binds": "fp64_valu" (FP64
+                    vector issue, what really limits it; the sub-object of that name prices it against the FP64 peak);
   walker_sharded  : (N > 1) configs[2] and configs[4] -- ONE light curve, 256 / 512 walkers -- through
                     GPModelling.derive_posteriors(device_sampler=True, shard_walkers=True): every
                     half-step's proposals split over the ranks, ncclAllGather pair on the launch stream
@@ -652,7 +653,8 @@ def main():
                 # nominal roofline of SURVEY.md 8(d): algorithmic bytes over HBM peak (achieved / peak / frac);
                 # what binds the kernel is FP64 vector issue (fp64_valu below, profiles/): 256 walkers share a
                 # light curve through L2 / MALL and the real HBM traffic is ~1 % of the algorithmic bytes
-                "bound": "fp64_valu",
+                "bound": "hbm",              # the contract's vocabulary: achieved / peak / frac below are the HBM figures
+                "binds": "fp64_valu",        # what actually limits the kernel (the sub-object of that name)
                 "kernel": kernel_name,   # as dispatched by the library (mtg_last_solver)
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
