@@ -115,12 +115,12 @@ struct mtg_ctx {
     int64_t live_rows = 0;              // rows the next solve really evaluates (0: all) -- kernel choice only
     bool no_prior_batch = false;        // the batch being solved was expanded WITHOUT the prior (run_model_batch): kernel choice only
 
-    // mtg_chain_autocorr: the convergence check is repeated on a growing chain, so plans (remade when the padded
-    // length or the shape changes) and buffers stay
-    hipfftHandle acf_fwd = 0, acf_inv = 0;
-    bool acf_plans = false;
-    int64_t acf_n2 = 0, acf_S = 0;
-    int64_t acf_P = 0;
+    // mtg_chain_autocorr: the convergence check is repeated on a growing chain, so plans and buffers stay.  Four plan
+    // pairs, the least recently used one making room: the tutorial's loop checks the null and the alternative model's
+    // chains in turn (two shapes), and a single slot was rebuilt at every check -- 9 ms each, a third of that loop
+    // (scripts/tutorial_loop_probe.py)
+    struct AcfPlans { hipfftHandle fwd = 0, inv = 0; bool have = false; int64_t n2 = 0, S = 0, P = 0; uint64_t used = 0; } acf_slots[4];
+    uint64_t acf_clock = 0;
     DevBuf acf_chain, acf_x, acf_f, acf_g, acf_r, acf_ss, acf_tmp;
 
     // mtg_simulate_tk95: the inverse transform's plan (made once per length: a Bluestein plan for the 1 087 853 points
@@ -806,7 +806,8 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     shard_release(ctx);
     {
         std::lock_guard<std::mutex> plans(g_fft_plan_mu);
-        if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); }
+        for (auto &sl : ctx->acf_slots)
+            if (sl.have) { (void)hipfftDestroy(sl.fwd); (void)hipfftDestroy(sl.inv); }
         for (auto &sp : ctx->sim_plans)
             if (sp.have) (void)hipfftDestroy(sp.h);
         for (auto &sp : ctx->czt.plans)
@@ -1698,24 +1699,31 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
     mtg_launch_acf_center(n_t, n2, S, d_chain.as<double>(), d_x.as<double>(), d_ss.as<double>(), ctx->acf_tmp.as<double>(), s);
     mtg_launch_acf_transpose(n2, S, d_x.as<double>(), d_chain.as<double>(), s);
     // contiguous batched transforms (stock kernels: no run-time compilation inside rocFFT)
-    if (!ctx->acf_plans || ctx->acf_n2 != n2 || ctx->acf_S != S || ctx->acf_P != EP) {
+    mtg_ctx::AcfPlans *slot = nullptr;
+    for (auto &sl : ctx->acf_slots)
+        if (sl.have && sl.n2 == n2 && sl.S == S && sl.P == EP) slot = &sl;
+    if (!slot) {
         std::lock_guard<std::mutex> plans(g_fft_plan_mu);
-        if (ctx->acf_plans) { (void)hipfftDestroy(ctx->acf_fwd); (void)hipfftDestroy(ctx->acf_inv); ctx->acf_plans = false; }
+        slot = &ctx->acf_slots[0];
+        for (auto &sl : ctx->acf_slots)  // an empty slot, else the least recently used
+            if (!sl.have || (slot->have && sl.used < slot->used)) slot = &sl;
+        if (slot->have) { (void)hipfftDestroy(slot->fwd); (void)hipfftDestroy(slot->inv); slot->have = false; }
         int len = (int)n2;
-        if (hipfftPlanMany(&ctx->acf_fwd, 1, &len, nullptr, 1, (int)n2, nullptr, 1, (int)nk, HIPFFT_D2Z, (int)S) != HIPFFT_SUCCESS)
+        if (hipfftPlanMany(&slot->fwd, 1, &len, nullptr, 1, (int)n2, nullptr, 1, (int)nk, HIPFFT_D2Z, (int)S) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (forward) failed");
-        if (hipfftPlanMany(&ctx->acf_inv, 1, &len, nullptr, 1, (int)nk, nullptr, 1, (int)n2, HIPFFT_Z2D, (int)EP) != HIPFFT_SUCCESS) {
-            (void)hipfftDestroy(ctx->acf_fwd);
+        if (hipfftPlanMany(&slot->inv, 1, &len, nullptr, 1, (int)nk, nullptr, 1, (int)n2, HIPFFT_Z2D, (int)EP) != HIPFFT_SUCCESS) {
+            (void)hipfftDestroy(slot->fwd);
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (inverse) failed");
         }
-        ctx->acf_plans = true; ctx->acf_n2 = n2; ctx->acf_S = S; ctx->acf_P = EP;
-        if (hipfftSetStream(ctx->acf_fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(ctx->acf_inv, s) != HIPFFT_SUCCESS)
+        slot->have = true; slot->n2 = n2; slot->S = S; slot->P = EP;
+        if (hipfftSetStream(slot->fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(slot->inv, s) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftSetStream failed");
     }
-    if (hipfftExecD2Z(ctx->acf_fwd, d_chain.as<double>(), (hipfftDoubleComplex *)d_f.p) != HIPFFT_SUCCESS)
+    slot->used = ++ctx->acf_clock;
+    if (hipfftExecD2Z(slot->fwd, d_chain.as<double>(), (hipfftDoubleComplex *)d_f.p) != HIPFFT_SUCCESS)
         return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftExecD2Z failed");
     mtg_launch_acf_power(nk, E, W, P, d_f.as<double2>(), d_ss.as<double>(), d_g.as<double2>(), s);
-    if (hipfftExecZ2D(ctx->acf_inv, (hipfftDoubleComplex *)d_g.p, d_r.as<double>()) != HIPFFT_SUCCESS)
+    if (hipfftExecZ2D(slot->inv, (hipfftDoubleComplex *)d_g.p, d_r.as<double>()) != HIPFFT_SUCCESS)
         return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftExecZ2D failed");
     double *d_rho = d_r.as<double>() + n2 * EP;
     mtg_launch_acf_out(n_t, n2, EP, 1.0 / (double)n2, d_r.as<double>(), d_rho, s);   // hipFFT does not normalise

@@ -24,6 +24,7 @@ __all__ = ["DeviceEnsembleSampler"]
 # chain point -- not a measured time) has reached what the plan would cost, or a single check would -- at most
 # twice the cost of always choosing right.  The choice is a pure function of the sequence of chain shapes checked
 # so far: the same run takes the same path (and gets the same tau, to the last bit) every time, on every rank.
+ACF_PLAN_SLOTS = 4                   # plan pairs mtg_chain_autocorr keeps (csrc/mtg_capi.hip: acf_slots)
 HOST_SECONDS_PER_POINT = 1.1e-8      # measured: 7 ms for 6.4e5 points, 30 ms for 2e6, 220 ms for 2e7
 
 
@@ -44,18 +45,20 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
                          for e in range(chain.shape[1])])
 
     key = (1 << max(n_t - 1, 1).bit_length(),) + chain.shape[1:]
-    state = engine.__dict__.setdefault("_acf_state", {"planned": None, "rented": {}})
+    # "planned": the shapes the library holds plans for, least recently used first (it keeps four: the tutorial's loop
+    # checks the null and the alternative model's chains in turn)
+    state = engine.__dict__.setdefault("_acf_state", {"planned": [], "rented": {}})
     estimate = HOST_SECONDS_PER_POINT * chain.size
     rented = state["rented"].get(key, 0.0)
     plan = _plan_seconds()
-    on_device = n_t >= 2 and (key == state["planned"] or estimate > plan or rented > plan)
+    on_device = n_t >= 2 and (key in state["planned"] or estimate > plan or rented > plan)
     if on_device:
         try:
             rho = engine.chain_autocorr(chain)   # (waits for the hipFFT warm-up thread if it is still at it)
         except Exception:        # (too large for the device's workspace, hipFFT refusing a plan ...): the host can always
             rho = None
         else:
-            state["planned"] = key
+            state["planned"] = [k for k in state["planned"] if k != key][-(ACF_PLAN_SLOTS - 1):] + [key]
             return taus(rho)
     state["rented"][key] = rented + estimate
     return taus(None)

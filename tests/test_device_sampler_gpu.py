@@ -105,7 +105,24 @@ def test_chain_autocorr_on_the_device_matches_the_host(engine):
     tau_host = _autocorr_time_where_it_is_cheapest(engine, many, dict(tol=0, quiet=True))        # rented: the host
     engine._acf_state["rented"][(512, 7, 10, 3)] = 10.0                                          # ... long enough
     tau = _autocorr_time_where_it_is_cheapest(engine, many, dict(tol=0, quiet=True))             # bought: the device
-    assert engine._acf_state["planned"] == (512, 7, 10, 3) and np.allclose(tau, tau_host, rtol=1e-9)
+    assert engine._acf_state["planned"] == [(512, 7, 10, 3)] and np.allclose(tau, tau_host, rtol=1e-9)
+    # the tutorial's loop checks two models' chains in turn: both shapes keep their plans (four slots, least recently used out)
+    import time as _time
+    shapes = [(500, 30, 2), (500, 30, 5)]
+    chains = [rng.standard_normal(sh).cumsum(axis=0) for sh in shapes]
+    for c in chains:
+        engine.chain_autocorr(c)                       # plans made
+    t0 = _time.perf_counter()
+    for _ in range(10):
+        for c in chains:
+            got = engine.chain_autocorr(c)
+    per_call = (_time.perf_counter() - t0) / 20
+    assert per_call < 3e-3, per_call                   # (9 ms each while one slot was rebuilt at every call)
+    assert np.max(np.abs(got - _mean_autocorr_function(chains[1]))) < 1e-11
+    for i, c in enumerate(chains + [rng.standard_normal((500, 30, k)).cumsum(axis=0) for k in (3, 4, 6)]):   # a fifth shape evicts the oldest
+        engine._acf_state["rented"][(512,) + c.shape[1:]] = 10.0
+        _autocorr_time_where_it_is_cheapest(engine, c, dict(tol=0, quiet=True))
+    assert len(engine._acf_state["planned"]) == 4 and engine._acf_state["planned"][-1] == (512, 30, 6) and (512, 30, 2) not in engine._acf_state["planned"]
     assert tau.shape == (7, 3) and np.allclose(tau, [integrated_time(many[:, e], tol=0) for e in range(7)], rtol=1e-9)
     still = rng.standard_normal((64, 4, 2))
     still[:, 1, 0] = 1.25                              # a walker that never moved: NaN in its dimension, as emcee
