@@ -128,7 +128,8 @@ class TermSum(ModelSet, Term):
         return ModelSet.log_prior(self)
 
     def __repr__(self):
-        return " + ".join(repr(t) for t in self.terms)
+        # celerite's form, as the notebooks print it: "(Lorentzian(...) + RealTerm(...) + Matern32Term(..., eps=1e-08))"
+        return "(" + " + ".join(repr(t) for t in self.terms) + ")"
 
 
 class TermProduct(ModelSet, Term):

@@ -181,3 +181,14 @@ def test_term_product_is_the_product_of_the_kernels():
     np.testing.assert_allclose(total.get_value(tau), real.get_value(tau) + comp.get_value(tau) * sho.get_value(tau), rtol=1e-12)
     with pytest.raises(ValueError):
         real * terms.JitterTerm(0.0)
+
+
+def test_kernels_print_as_the_notebooks_print_them():
+    """celerite's repr of a sum of terms, copied from the stored output of docs/notebooks/tutorial_model_selection.ipynb cell 8"""
+    from mind_the_gaps_amd.models.celerite_models import Lorentzian
+    k = Lorentzian(4.792317694191546, 4.88245622156523, -1.381704165724039) + terms.RealTerm(5.3258366603280365, -0.9582493463338226) \
+        + terms.Matern32Term(2.9179435023277605, 0.9755365010911353, eps=1e-08)
+    assert repr(k) == ("(Lorentzian(4.792317694191546, 4.88245622156523, -1.381704165724039) + RealTerm(5.3258366603280365, "
+                       "-0.9582493463338226) + Matern32Term(2.9179435023277605, 0.9755365010911353, eps=1e-08))")
+    assert repr(terms.RealTerm(6.125107037258277, -2.0741459390188006)) == "RealTerm(6.125107037258277, -2.0741459390188006)"
+    assert repr(terms.Matern32Term(3.0625535186291386, 2.3025850929940455, eps=1e-08)) == "Matern32Term(3.0625535186291386, 2.3025850929940455, eps=1e-08)"
