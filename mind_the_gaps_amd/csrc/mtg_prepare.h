@@ -15,11 +15,11 @@
 // arithmetic of ~8 exp, a sqrt and three divisions per row on the six waves that hold the rows)
 // (Not kept: the model's description read from a copy in LDS instead of the kernel arguments -- the expansion took as
 // long, and copying the description out of the argument segment with per-thread indices cost 27 us.)
-__device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e, bool live, const double *th_row = nullptr)
+// th: the row's free parameters (valid for a dead thread too)
+__device__ __forceinline__ void mtg_prepare_from(const MtgPrepArgs &a, int64_t e, bool live, const double *th)
 {
     const MtgModel &m = a.model;
-    const double *th = th_row ? th_row : a.theta + (live ? e : 0) * m.P;
-    auto par = [&](int k) -> double {
+    auto par = [th, &m](int k) -> double {   // (th by value: a reference would take the address of a local, which the back end mishandles when it survives inlining)
         const int s = m.src[k];
         return s >= 0 ? th[s] : m.defaults[k];
     };
@@ -169,4 +169,10 @@ __device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e,
                     (int)e;
         }
     }
+}
+
+// row e of the batch a.theta, or the copy of it the caller holds (th_row)
+__device__ __forceinline__ void mtg_prepare_one(const MtgPrepArgs &a, int64_t e, bool live, const double *th_row = nullptr)
+{
+    mtg_prepare_from(a, e, live, th_row ? th_row : a.theta + (live ? e : 0) * a.model.P);
 }

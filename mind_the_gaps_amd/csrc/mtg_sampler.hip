@@ -280,6 +280,15 @@ __device__ __forceinline__ void mtg_propose_both(const MtgEnsembleArgs &g, uint3
     }
     __syncthreads();  // every row is expanded by the thread with its number, not by the one that wrote it
     MTG_STAMP(9);
+}
+
+// theta -> prior + coefficients of the 3 H rows just proposed, read from their copy in LDS (the one place of the kernel
+// that holds the expansion: two inlined copies of its list-appending atomics trip the compiler's back end)
+__device__ __forceinline__ void mtg_expand_proposals(const MtgEnsembleArgs &g, const MtgPrepArgs &pa, const double *s_q)
+{
+    const int H = g.W / 2, P = g.P;
+    const int e = blockIdx.x;
+    const int64_t EH = (int64_t)g.E * H;
     for (int t0 = 0; t0 < 3 * H; t0 += blockDim.x) {  // uniform trip count: mtg_prepare_one votes per wave
         const int t = t0 + (int)threadIdx.x;
         const bool live = t < 3 * H;
@@ -350,10 +359,203 @@ __device__ __forceinline__ void mtg_accept_both(const MtgEnsembleArgs &g, uint32
         for (int w = threadIdx.x; w < W; w += 256) lnp_chain_row[(int64_t)e * W + w] = g.lnp[(int64_t)e * W + w];
 }
 
+// The accept step of one speculative iteration and the proposals of the next with the ensemble's state in LDS (small
+// ensembles: W P <= MTG_SPEC_LDS_DOUBLES, H <= 256, the splits made beforehand).  mtg_accept_both + mtg_propose_both are a
+// chain of about ten dependent global-memory round trips of ONE workgroup (profiles/r05_sampler_stamps.txt: seven phases
+// of 1-2.6 us around 3-5 us of expansion); here everything the iteration reads -- coordinates, log-probabilities, both
+// splits, the evaluated proposals with their results -- is fetched at once, the phases then run out of LDS and registers
+// and only write to memory.  Same counters, same arithmetic, same stores: the chain of the other form to the last bit.
+#define MTG_SPEC_LDS_DOUBLES 2048
+__device__ __forceinline__ void mtg_spec_both_lds(const MtgEnsembleArgs &g, uint32_t iteration, uint32_t next_iteration,
+                                                  const MtgPrepArgs &pa, const double *new_lnp, const int32_t *status,
+                                                  int *clear_counts, double *chain_row, double *lnp_chain_row, double *s_best,
+                                                  int *s_idx, int *s_acc, double *s_q, double *s_c, double *s_l, int *s_p, double *s_r)
+{
+    const int W = g.W, P = g.P, H = W / 2, nt = (int)blockDim.x, tid = (int)threadIdx.x;
+    const int e = blockIdx.x;
+    const int64_t EH = (int64_t)g.E * H, i = (int64_t)e * H + tid;
+    const bool mine = tid < H;  // thread k holds walker slot k of either half
+    double *q = const_cast<double *>(pa.theta);
+    if (e == 0 && tid < 64 && clear_counts) clear_counts[tid] = 0;
+    // ---- everything this iteration reads, in one go: every load is issued before the first of them is waited for (fixed trip
+    // counts over registers: a loop that loads and stores to LDS waits for memory once per trip) ---------------------------
+    constexpr int CPT = MTG_SPEC_LDS_DOUBLES / 256;  // coordinates per thread at most (blocks of 256 threads or more)
+    double rc[CPT], rq[3][CPT / 2], rl[2];
+    int rp_next[2];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int j = tid + u * nt;
+        rc[u] = j < W * P ? g.coords[(int64_t)e * W * P + j] : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b)  // the proposals being decided (block b of the batch), where the new ones will go afterwards
+#pragma unroll
+        for (int u = 0; u < CPT / 2; ++u) {
+            const int j = tid + u * nt;
+            rq[b][u] = j < H * P ? q[((int64_t)b * EH + (int64_t)e * H) * P + j] : 0.0;
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int w = tid + u * nt;
+        rl[u] = w < W ? g.lnp[(int64_t)e * W + w] : 0.0;
+        rp_next[u] = w < W ? g.perm_next[(int64_t)e * W + w] : 0;
+    }
+    int w0 = 0, w1 = 0, j1 = 0, st0 = 0, st1a = 0, st1b = 0;
+    double lu0 = 0.0, lu1 = 0.0, cand0 = 0.0, cand1a = 0.0, cand1b = 0.0, f0 = 0.0, f1 = 0.0;
+    if (mine) {
+        w0 = g.perm[(int64_t)e * W + tid];
+        w1 = g.perm[(int64_t)e * W + H + tid];
+        cand0 = new_lnp[i]; st0 = status[i]; f0 = g.factor[i];
+        cand1a = new_lnp[EH + i]; st1a = status[EH + i];
+        cand1b = new_lnp[2 * EH + i]; st1b = status[2 * EH + i];
+        f1 = g.factor[EH + i];
+    }
+    // The expansion that follows this function walks through the model's description -- ~1.4 KB of the argument segment, read
+    // with scalar loads whose addresses depend on what the previous one returned; the segment was written by the host
+    // moments ago, so every 64-byte line of it is a trip to memory the first time (the expansion: 4.0 / 4.8 / 6.4 us at the
+    // three sizes of profiles/r05_sampler_stamps.txt, 2.6 / 3.6 / 4.7 with the lines touched beforehand).  Touch every line
+    // now, behind the vector loads above: the trips run under this function's phases.
+    {
+        int touched = 0;
+        const int *words = (const int *)&pa.model;
+#pragma unroll
+        for (int off = 0; off < (int)(sizeof(MtgModel) / sizeof(int)); off += 16) touched ^= words[off];
+        if (touched == 0x5eed5eed && clear_counts) clear_counts[63] = 0;  // (keeps the loads; what it writes is what is there)
+    }
+    // The iteration's random numbers depend on nothing but counters: every quarter of the workgroup makes one kind of them
+    // for all H slots (a lone wave walks through a Philox block and a logarithm in ~0.5 us -- five blocks and four
+    // logarithms one after the other were most of this kernel's time outside the expansion).
+    //   s_r[0..H)  ln u of the first half's accept        s_r[H..2H)   ln u of the second half's accept
+    //   s_r[2H..)  z, (P - 1) ln z of the first half's proposal, then of the second half's;   s_ri: partner slots
+    double *s_lu0 = s_r, *s_lu1 = s_r + H, *s_z1 = s_r + 2 * H, *s_f1 = s_r + 3 * H, *s_z2 = s_r + 4 * H, *s_f2 = s_r + 5 * H;
+    int *s_j1 = (int *)(s_r + 6 * H), *s_pj = s_j1 + H, *s_j2 = s_pj + H;
+    {
+        const int quarter = nt / 4, role = tid / quarter;
+        for (int k = tid - role * quarter; k < H; k += quarter) {
+            if (role == 0) {
+                const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
+                s_lu0[k] = log(u01(r.c[0], r.c[1]));
+            } else if (role == 1) {
+                const Philox r = philox4x32_10(iteration, PURPOSE_ACCEPT + 16, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
+                s_lu1[k] = log(u01(r.c[0], r.c[1]));
+                const Philox rp = philox4x32_10(iteration, PURPOSE_PROPOSE + 16, (uint32_t)e + g.e_base, (uint32_t)k, g.seed_lo, g.seed_hi);
+                s_j1[k] = (int)(u01(rp.c[2], rp.c[3]) * (double)H);
+            } else {
+                const Philox r = philox4x32_10(next_iteration, role == 2 ? PURPOSE_PROPOSE : PURPOSE_PROPOSE + 16, (uint32_t)e + g.e_base,
+                                               (uint32_t)k, g.seed_lo, g.seed_hi);
+                const double u = u01(r.c[0], r.c[1]);
+                const double zr = (g.a - 1.0) * u + 1.0;
+                const double z = zr * zr / g.a;
+                (role == 2 ? s_z1 : s_z2)[k] = z;
+                (role == 2 ? s_f1 : s_f2)[k] = (double)(P - 1) * log(z);
+                (role == 2 ? s_pj : s_j2)[k] = (int)(u01(r.c[2], r.c[3]) * (double)H);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int j = tid + u * nt;
+        if (j < W * P) s_c[j] = rc[u];
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int u = 0; u < CPT / 2; ++u) {
+            const int j = tid + u * nt;
+            if (j < H * P) s_q[(int64_t)b * H * P + j] = rq[b][u];
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int w = tid + u * nt;
+        if (w < W) { s_l[w] = rl[u]; s_p[w] = rp_next[u]; }
+    }
+    __syncthreads();
+    MTG_STAMP(1);
+    if (mine) { lu0 = s_lu0[tid]; lu1 = s_lu1[tid]; j1 = s_j1[tid]; }
+    // ---- accept / reject, first half then second -----------------------------------------------------------------------
+    double my_best = -INFINITY;
+    int64_t my_idx = -1;
+    if (mine) {
+        if (st0 == MTG_ST_NOTPD) atomicAdd(g.n_notpd, 1);
+        const int64_t wi = (int64_t)e * W + w0;
+        const bool accept = f0 + cand0 - s_l[w0] > lu0;  // false for NaN and for cand = -inf
+        s_acc[tid] = accept ? 1 : 0;
+        if (accept) {
+            for (int d = 0; d < P; ++d) { const double v = s_q[(int64_t)tid * P + d]; g.coords[wi * P + d] = v; s_c[w0 * P + d] = v; }
+            g.lnp[wi] = cand0; s_l[w0] = cand0;
+            g.naccept[wi] += 1;
+            my_best = cand0; my_idx = i;
+        }
+    }
+    __syncthreads();  // the accept flags
+    MTG_STAMP(2);
+    if (mine) {
+        const int which = s_acc[j1] ? 2 : 1;
+        const double cand = which == 2 ? cand1b : cand1a;
+        if ((which == 2 ? st1b : st1a) == MTG_ST_NOTPD) atomicAdd(g.n_notpd, 1);
+        const int64_t wi = (int64_t)e * W + w1;
+        if (f1 + cand - s_l[w1] > lu1) {
+            for (int d = 0; d < P; ++d) { const double v = s_q[((int64_t)which * H + tid) * P + d]; g.coords[wi * P + d] = v; s_c[w1 * P + d] = v; }
+            g.lnp[wi] = cand; s_l[w1] = cand;
+            g.naccept[wi] += 1;
+            if (cand > my_best) { my_best = cand; my_idx = (int64_t)which * EH + i; }
+        }
+    }
+    // best accepted proposal of the ensemble (as mtg_accept_both: the four worker waves by shuffles, then thread 0)
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(my_best, off);
+        const int64_t oi = __shfl_down(my_idx, off);
+        if (ob > my_best) { my_best = ob; my_idx = oi; }
+    }
+    if (tid < 256 && (tid & 63) == 0) { s_best[tid >> 6] = my_best; s_idx[tid >> 6] = (int)my_idx; }
+    __syncthreads();  // the state after both halves; the waves' bests
+    MTG_STAMP(5);
+    if (tid == 0) {
+        for (int wv = 1; wv < 4; ++wv)
+            if (s_best[wv] > s_best[0]) { s_best[0] = s_best[wv]; s_idx[0] = s_idx[wv]; }
+        if (s_idx[0] >= 0 && s_best[0] > g.best_lnp[e]) {
+            g.best_lnp[e] = s_best[0];
+            // row b EH + e H + k of the batch is slot (b H + k) of this ensemble's copy
+            const int64_t row = s_idx[0], b = row / EH, k = row - b * EH - (int64_t)e * H;
+            for (int d = 0; d < P; ++d) g.best_coords[(int64_t)e * P + d] = s_q[(b * H + k) * P + d];
+        }
+    }
+    if (chain_row)
+        for (int j = tid; j < W * P; j += nt) chain_row[(int64_t)e * W * P + j] = s_c[j];
+    if (lnp_chain_row)
+        for (int w = tid; w < W; w += nt) lnp_chain_row[(int64_t)e * W + w] = s_l[w];
+    __syncthreads();  // thread 0 is done with the decided proposals: their place takes the new ones
+    MTG_STAMP(7);
+    // ---- the coming iteration's proposals (as mtg_propose_both, the state read from LDS) --------------------------------
+    if (mine) {
+        const double z = s_z1[tid];
+        const double *sw = s_c + (int64_t)s_p[tid] * P;
+        const double *c = s_c + (int64_t)s_p[H + s_pj[tid]] * P;
+        double *qo = q + i * P, *ql = s_q + (int64_t)tid * P;
+        for (int d = 0; d < P; ++d) { const double v = c[d] - (c[d] - sw[d]) * z; qo[d] = v; ql[d] = v; }
+        g.factor[i] = s_f1[tid];
+    }
+    __syncthreads();  // ... which other threads read as the partner's would-be place
+    MTG_STAMP(8);
+    for (int t = tid; t < 2 * H; t += nt) {
+        const int k = t % H, which = t / H;
+        const int64_t ik = (int64_t)e * H + k;
+        const double z = s_z2[k];
+        const int j = s_j2[k];
+        const double *sw = s_c + (int64_t)s_p[H + k] * P;
+        const double *c = which ? s_q + (int64_t)j * P : s_c + (int64_t)s_p[j] * P;
+        double *qo = q + ((which ? 2 * EH : EH) + ik) * P, *ql = s_q + ((int64_t)(1 + which) * H + k) * P;
+        for (int d = 0; d < P; ++d) { const double v = c[d] - (c[d] - sw[d]) * z; qo[d] = v; ql[d] = v; }
+        if (!which) g.factor[EH + ik] = s_f2[k];
+    }
+    __syncthreads();
+    MTG_STAMP(9);
+}
+
 __global__ void __launch_bounds__(1024)
 mtg_sampler_spec_kernel(MtgEnsembleArgs g, int do_accept, uint32_t iteration, const double *new_lnp, const int32_t *status,
                         int *clear_counts, double *chain_row, double *lnp_chain_row, int do_propose, uint32_t next_iteration,
-                        MtgPrepArgs pa)
+                        MtgPrepArgs pa, int state_in_lds)
 {
     extern __shared__ uint64_t s_key[];   // W keys, W ranks (int), H accept flags (int)
     __shared__ double s_best[256];
@@ -362,19 +564,33 @@ mtg_sampler_spec_kernel(MtgEnsembleArgs g, int do_accept, uint32_t iteration, co
     // the 3 H proposals of the coming iteration, kept beside their global copy (mtg_prepare_one reads them from here)
     double *s_q = (double *)(s_key + g.W + (3 * g.W / 2 + 1) / 2 + 1);
     MTG_STAMP(0);
-    if (do_accept) {
-        mtg_accept_both(g, iteration, pa.theta, new_lnp, status, clear_counts, chain_row, lnp_chain_row, s_best, s_idx, s_acc);
-        __syncthreads();
+    const bool in_lds = state_in_lds && do_accept && do_propose;  // a small ensemble in the middle of a run
+    if (in_lds) {
+        double *s_c = s_q + (int64_t)3 * (g.W / 2) * g.P, *s_l = s_c + (int64_t)g.W * g.P;
+        mtg_spec_both_lds(g, iteration, next_iteration, pa, new_lnp, status, clear_counts, chain_row, lnp_chain_row, s_best, s_idx,
+                          s_acc, s_q, s_c, s_l, (int *)(s_l + g.W), s_l + g.W + (g.W + 1) / 2);
+    } else {
+        if (do_accept) {
+            mtg_accept_both(g, iteration, pa.theta, new_lnp, status, clear_counts, chain_row, lnp_chain_row, s_best, s_idx, s_acc);
+            __syncthreads();
+        }
+        MTG_STAMP(5);
+        if (do_propose) mtg_propose_both(g, next_iteration, pa, s_key, s_q);
     }
-    MTG_STAMP(5);
-    if (do_propose) mtg_propose_both(g, next_iteration, pa, s_key, s_q);
+    if (do_propose) mtg_expand_proposals(g, pa, s_q);
 #ifdef MTG_SAMPLER_STAMPS
     __syncthreads();
     MTG_STAMP(10);
-    if (threadIdx.x == 0 && blockIdx.x == 0 && iteration == 100)
-        printf("sampler stamps (10 ns ticks): accept0 %llu accept1 %llu best+chain %llu | split %llu propose1 %llu propose2 %llu expand %llu | total %llu\n",
-               mtg_stamps[1] - mtg_stamps[0], mtg_stamps[2] - mtg_stamps[1], mtg_stamps[5] - mtg_stamps[2], mtg_stamps[7] - mtg_stamps[6],
-               mtg_stamps[8] - mtg_stamps[7], mtg_stamps[9] - mtg_stamps[8], mtg_stamps[10] - mtg_stamps[9], mtg_stamps[10] - mtg_stamps[0]);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && iteration == 100) {
+        if (in_lds)
+            printf("sampler stamps, state in LDS (10 ns ticks): fetch %llu accept0 %llu accept1+best %llu chain %llu | propose1 %llu propose2 %llu expand %llu | total %llu\n",
+                   mtg_stamps[1] - mtg_stamps[0], mtg_stamps[2] - mtg_stamps[1], mtg_stamps[5] - mtg_stamps[2], mtg_stamps[7] - mtg_stamps[5],
+                   mtg_stamps[8] - mtg_stamps[7], mtg_stamps[9] - mtg_stamps[8], mtg_stamps[10] - mtg_stamps[9], mtg_stamps[10] - mtg_stamps[0]);
+        else
+            printf("sampler stamps (10 ns ticks): accept0 %llu accept1 %llu best+chain %llu | split %llu propose1 %llu propose2 %llu expand %llu | total %llu\n",
+                   mtg_stamps[1] - mtg_stamps[0], mtg_stamps[2] - mtg_stamps[1], mtg_stamps[5] - mtg_stamps[2], mtg_stamps[7] - mtg_stamps[6],
+                   mtg_stamps[8] - mtg_stamps[7], mtg_stamps[9] - mtg_stamps[8], mtg_stamps[10] - mtg_stamps[9], mtg_stamps[10] - mtg_stamps[0]);
+    }
 #endif
 }
 
@@ -458,11 +674,18 @@ void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t i
     // the barriers of four waves than of sixteen)
     // (measured, iterations/s with 256 / 1024 threads: W = 32 44.1e3 / 43.0e3, W = 128 18.2e3 / 19.0e3, W = 256 6.8e3 / 7.7e3)
     const int threads = do_propose && g.E <= 64 && g.W > 64 ? 1024 : 256;
-    hipLaunchKernelGGL(mtg_sampler_spec_kernel, dim3((unsigned)g.E), dim3(threads),
-                       // keys (8 W), ranks (4 W), accept flags (4 W/2), padding to 8 bytes, then 3 W/2 proposals of P doubles
-                       (size_t)(g.W + (3 * g.W / 2 + 1) / 2 + 1) * sizeof(uint64_t) + (size_t)(3 * (g.W / 2)) * g.P * sizeof(double), s,
-                       g, do_accept, iteration,
-                       new_lnp, status, clear_counts, chain_row, lnp_chain_row, do_propose, next_iteration, pa);
+    // the ensemble's state in LDS for the length of the kernel (mtg_spec_both_lds): small ensembles whose splits were made
+    // beforehand, between two solves of a run (MTG_SAMPLER_LDS=0: never, for measurements)
+    static const bool lds_wanted = !(getenv("MTG_SAMPLER_LDS") && atoi(getenv("MTG_SAMPLER_LDS")) == 0);
+    const int state_in_lds = lds_wanted && do_accept && do_propose && g.perm_next && g.W / 2 <= 256 && g.W / 2 <= threads &&
+                             (int64_t)g.W * g.P <= MTG_SPEC_LDS_DOUBLES ? 1 : 0;
+    // keys (8 W), ranks (4 W), accept flags (4 W/2), padding to 8 bytes, then 3 W/2 proposals of P doubles; with the state
+    // in LDS also W P coordinates, W log-probabilities, W ints of the next split
+    size_t lds = (size_t)(g.W + (3 * g.W / 2 + 1) / 2 + 1) * sizeof(uint64_t) + (size_t)(3 * (g.W / 2)) * g.P * sizeof(double);
+    // ... W ints of the next split (padded to doubles), and the iteration's random numbers: 6 H doubles + 3 H ints
+    if (state_in_lds) lds += ((size_t)g.W * g.P + g.W + (g.W + 1) / 2 + 6 * (g.W / 2) + (3 * (g.W / 2) + 1) / 2) * sizeof(double);
+    hipLaunchKernelGGL(mtg_sampler_spec_kernel, dim3((unsigned)g.E), dim3(threads), lds, s, g, do_accept, iteration,
+                       new_lnp, status, clear_counts, chain_row, lnp_chain_row, do_propose, next_iteration, pa, state_in_lds);
 }
 
 void mtg_launch_initial_best(int E, int W, int P, const double *coords, const double *lnp, double *best_lnp,
