@@ -32,6 +32,8 @@
 #pragma once
 #include "mtg_device.h"
 
+#include <stdlib.h>
+
 #define MTG_TPB_ELEM(J) (3 * (J) * (J) + 2 * (J))
 #define MTG_TPB_STATE(J) ((J) * (J) + (J))
 #define MTG_TPB_LANES 16    /* lanes per lane group */
@@ -83,8 +85,16 @@ static inline MtgTpBigPlan mtg_tp_big_plan(int J, int64_t B, int C, int g)
 // workgroups with chunks half as long take the composition exactly as long, and leave the scan twice the elements.)
 static inline int mtg_tp_big_chunks(int64_t N, int64_t B)
 {
+    // chunks over the whole batch: two waves per SIMD in the composition (32 768), one for the smallest batches, whose up-sweep
+    // is then half as long (scripts/c5_chunk_target.sh, N = 2e5, ms per half-step at 32 768 / 16 384: 8 rows 0.311 / 0.265,
+    // 16 rows 0.385 / 0.349, 32 rows 0.540 / 0.534, 64 rows 0.843 / 0.876, 256 rows 2.66 / 2.87)
+    int64_t target = B <= 16 ? 16384 : 32768;
+    if (const char *env = getenv("MTG_TP_CHUNK_TARGET")) {  // measurements only
+        const long v = atol(env);
+        if (v >= 64) target = v;
+    }
     int C = 64;
-    while (C < 4096 && (int64_t)C * B < 32768 && (int64_t)C * 2 * 24 <= N) C *= 2;
+    while (C < 4096 && (int64_t)C * B < target && (int64_t)C * 2 * 24 <= N) C *= 2;
     return C;
 }
 
