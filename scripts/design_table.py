@@ -6,8 +6,8 @@
 
 Sources, newest round first: profiles/rNN_bench_line.json (the full JSON line of `python bench.py` on one MI355X, copied
 from gpurun_out/ by hand when a round's numbers are final) and profiles/rNN_bench_line_{2,6}ranks_one_gpu.json (the
-multi-rank rehearsals).  The driver's BENCH_rNN.json keeps the contract fields only; where one exists for the same
-round its `value` is quoted beside the line's.  Everything else in a row (where it is built, what tests it) is static
+multi-rank rehearsals).  Only tracked files under profiles/ are read: the driver's BENCH_rNN.json lands after the last
+commit of a round and must not be able to change what --check expects.  Everything else in a row (where it is built, what tests it) is static
 text below: a row is edited HERE, never in DESIGN.md, which is why the table cannot go stale behind a bench line.
 """
 import glob
@@ -56,11 +56,6 @@ def rows():
     wf, share = d["workflow_config3"], d["workflow_config3_share_of_8"]
     mid = d["mid_batch_half_step"]
     c4 = chain["configs[4]"]
-    driver = newest("BENCH_r*.json")
-    driver_note = ""
-    if driver and driver[0] == rnd:
-        dv = json.load(open(driver[1]))["parsed"]
-        driver_note = "; the driver's own run (`%s`): %s" % (os.path.basename(driver[1]), sci(dv["value"]))
     multi = []
     for n in (2, 6):
         got = newest("profiles/r*_bench_line_%dranks_one_gpu.json" % n)
@@ -71,12 +66,12 @@ def rows():
                          % (n, os.path.relpath(got[1], ROOT), m["_rehearsal"]["wall_clock_of_the_whole_command_s"],
                             m["workflow_config3_sharded"]["p_value"],
                             "identical" if inv.get("identical_to_one_rank_alone") else "NOT RUN"))
-    head = ("`%s`: **%s evals/s** at N = 10⁴, J = 6 (%.2f ms per 512 000 rows; kernel `%s` %.2f ms)%s; roofline %.3f of "
+    head = ("`%s`: **%s evals/s** at N = 10⁴, J = 6 (%.2f ms per 512 000 rows; kernel `%s` %.2f ms); roofline %.3f of "
             "algorithmic HBM bytes, %.3f of the FP64 vector peak; HBM traffic %s; worst difference to the CPU port %.1e over %d "
             "rows of the timed batch; CPU port %s evals/s on %d cores, %s on one; null model (J = 3) %s; three SHO terms (six "
             "ranks of arithmetic) %s, FP64 fraction %.2f; 32 000 rows: %.2f / %.2f ms on the pipeline against %.2f / %.2f "
             "one-lane; PCIe-inclusive %s"
-            % (src, sci(d["value"]), d["ms_per_step"], roof["kernel"], roof["kernel_ms"], driver_note, roof["frac"],
+            % (src, sci(d["value"]), d["ms_per_step"], roof["kernel"], roof["kernel_ms"], roof["frac"],
                roof["fp64_valu"]["frac"],
                "%.2f GB per launch = %.1f %% of algorithmic" % (roof["traffic"] / 1e9, 100 * roof["traffic"] / (roof["evals_per_launch"] * roof["bytes_per_eval"]))
                if roof.get("traffic") else "see `profiles/r04_pmc_traffic.json`",
