@@ -110,15 +110,9 @@ def free_port():
 
 
 def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher: N children, one rank each, started before this process has
-    made any GPU call (counting devices does not initialise one)."""
-    import torch
-    ndev = torch.cuda.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
-    if args.gpus > ndev * MAX_RANKS_PER_GPU:
-        raise SystemExit("--gpus %d on %d GPU(s): at most %d ranks may share a card (rehearsal only)"
-                         % (args.gpus, ndev, MAX_RANKS_PER_GPU))
+    """`python bench.py --gpus N` without a launcher: N children, one rank each.  The parent imports no torch and makes no
+    HIP / HSA call at all -- `--gpus` is taken as given, the children are fresh processes (never a re-exec of one that
+    touched a GPU) and each of them checks the devices it sees and refuses loudly before the process group exists."""
     env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     children = []
@@ -452,6 +446,9 @@ def main():
     # Rehearsal only: more ranks than GPUs (e.g. two ranks on a one-GPU box) share the cards and agree on
     # the timing over gloo -- RCCL refuses two ranks on one device.  The line then says "oversubscribed".
     ndev = torch.cuda.device_count()
+    if world > ndev * MAX_RANKS_PER_GPU:     # every rank sees the same and leaves before the process group exists
+        raise SystemExit("--gpus %d on %d GPU(s): at most %d ranks may share a card (rehearsal only)"
+                         % (world, ndev, MAX_RANKS_PER_GPU))
     oversubscribed = world > ndev
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
