@@ -45,8 +45,8 @@ The JSON line also carries
                     of the 2000 light curves, one all-gather of the maxima per model; time = max over ranks;
                     (both N > 1 extras run after the timed region under --extras-timeout: if one of them fails or
                     hangs on some rank, rank 0 still prints the line -- the scaling number stands -- with
-                    `multi_rank_extras_error` saying what happened, and every rank then exits with code 3;
-                    MTG_BENCH_FAIL_EXTRAS=<rank> rehearses that)
+                    `multi_rank_extras_error` saying what happened (exit code 3 with --strict-extras, else 0: the
+                    first multi-GPU bring-up costs a field, not the record); MTG_BENCH_FAIL_EXTRAS=<rank> rehearses that)
   cpu_baseline    : oracle/celerite_ref.c (a plain-C port of celerite's algorithm, fused one-sweep
                     variant, built -O3 -march=native on this host) single thread and on all usable
                     cores, bounded sample (rank 0; at N > 1 on rank 0's block while the other ranks wait at a barrier
@@ -100,6 +100,10 @@ def parse():
     ap.add_argument("--extras-timeout", type=int, default=300,
                     help="N > 1: seconds the walker-sharded configs and the sharded workflow may take after the timed "
                          "region before the line is printed without them")
+    ap.add_argument("--strict-extras", action="store_true",
+                    help="N > 1: exit with code 3 when the extras after the timed region fail (default: the failure is a "
+                         "field of the line, `multi_rank_extras_error`, and a message on stderr; the exit code stays 0 so "
+                         "that a measured scaling number is never discarded for a side measurement)")
     return ap.parse_args()
 
 
@@ -422,7 +426,9 @@ def walker_sharded_configs(rank, world, local_dev, oversubscribed):
             raise SystemExit("bench: the ranks of the walker-sharded chain (%s) hold different chains" % name)
         out[name] = {"iterations_per_s": steps / el, "evals_per_s": steps * walkers / el, "half_step_ms": el / steps / 2 * 1e3,
                      "iterations_timed": steps, "rows_per_rank": -(-(walkers // 2) // world), "kernel": eng.last_solver,
-                     "transport": info["kind"], "rccl_ranks": info["comm_ranks"],
+                     # ("host (rccl failed: ...)" when the library's communicator could not be brought up on some rank:
+                     # distributed.shard_device_ensemble then takes the host-staged exchange on every rank)
+                     "transport": getattr(sampler, "transport", None) or info["kind"], "rccl_ranks": info["comm_ranks"],
                      "exchange_us_median": float(np.median(exchange_ms) * 1e3) if len(exchange_ms) else None,
                      "exchange_us_min": float(np.min(exchange_ms) * 1e3) if len(exchange_ms) else None,
                      "chains_identical_on_all_ranks": True}
@@ -699,11 +705,12 @@ def main():
             # the timer below, rank 0 printing the line with what it has.
             import threading
             import traceback
-            EXTRAS_FAILED = 3      # exit code of a run whose timed region is fine and printed, but whose extras are not
+            # exit code of a run whose timed region is fine and printed, but whose extras are not
+            EXTRAS_FAILED = 3 if args.strict_extras else 0
 
             def give_up(why):
-                """The line, with what there is, then a non-zero exit: the scaling number is on stdout, the failure in the
-                line ("multi_rank_extras_error") AND in the exit code."""
+                """The line, with what there is: the scaling number is on stdout, the failure in the line
+                ("multi_rank_extras_error"), on stderr, and with --strict-extras in the exit code."""
                 sys.stderr.write("bench: rank %d: multi-rank extras: %s\n" % (rank, why))
                 if rank == 0:
                     extras["multi_rank_extras_error"] = why

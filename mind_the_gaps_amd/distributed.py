@@ -233,13 +233,65 @@ def shard_device_ensemble(engine, group=None, transport=None):
     if transport is None:
         transport = "rccl" if dist.get_backend(group) == "nccl" else "host"
     if transport == "rccl":
-        objs = [engine.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
-                                   device=_object_device(group))
-        engine.ensemble_shard_rccl(objs[0], rank, world)
-        return transport
+        # Bringing the library's own communicator up is the one step no one-GPU box can rehearse with more than one
+        # rank.  A rank on which it fails (or does not come back within MTG_RCCL_INIT_TIMEOUT_S, default 120 s) says so
+        # over ``group``; if ANY rank failed, EVERY rank drops the communicator and takes the host-staged exchange over
+        # ``group`` instead -- same chains (the exchange moves the same bytes), and the returned string says why.
+        why = _try_rccl(engine, group, rank, world)
+        flags = [None] * world
+        dist.all_gather_object(flags, why, group=group)
+        failed = [(r, w) for r, w in enumerate(flags) if w]
+        if not failed:
+            return "rccl"
+        if why is None:
+            engine.ensemble_unshard()
+        import warnings
+        reason = "rank %d: %s" % failed[0]
+        warnings.warn("walker sharding: RCCL communicator not available (%s); host-staged exchange instead" % reason)
+        _host_transport(engine, group, rank, world)
+        return "host (rccl failed: %s)" % reason
     if transport != "host":
         raise ValueError("transport must be 'rccl' or 'host'")
+
+    _host_transport(engine, group, rank, world)
+    return transport
+
+
+def _try_rccl(engine, group, rank, world):
+    """None when this rank's communicator is up, else the reason it is not (never raises: the verdict is agreed on by
+    all ranks afterwards)."""
+    import os
+    import threading
+    import torch.distributed as dist
+    try:
+        objs = [engine.rccl_unique_id() if rank == 0 else None]
+    except Exception as exc:        # (rank 0 could not even load librccl: the others must not wait for an id)
+        objs = [exc]
+    dist.broadcast_object_list(objs, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                               device=_object_device(group))
+    if isinstance(objs[0], Exception) or objs[0] is None:
+        return "no ncclUniqueId from rank 0 (%r)" % (objs[0],)
+    verdict = []
+
+    def init():
+        try:
+            engine.ensemble_shard_rccl(objs[0], rank, world)
+            verdict.append(None)
+        except Exception as exc:
+            verdict.append("%s: %s" % (type(exc).__name__, exc))
+
+    limit = float(os.environ.get("MTG_RCCL_INIT_TIMEOUT_S", "120"))
+    worker = threading.Thread(target=init, daemon=True)
+    worker.start()
+    worker.join(limit)
+    if worker.is_alive():
+        return "ncclCommInitRank did not return within %.0f s" % limit
+    return verdict[0]
+
+
+def _host_transport(engine, group, rank, world):
+    import torch
+    import torch.distributed as dist
 
     def exchange(lnp, status, lo, hi):
         # the library's layout: rank r owns rows [r * chunk, (r + 1) * chunk), chunk = ceil(count / world)
@@ -248,12 +300,15 @@ def shard_device_ensemble(engine, group=None, transport=None):
         mine = torch.zeros(2 * chunk, dtype=torch.float64)
         mine[:hi - lo] = torch.from_numpy(lnp[lo:hi])
         mine[chunk:chunk + hi - lo] = torch.from_numpy(status[lo:hi].astype(np.float64))
+        dev = _object_device(group)      # RCCL moves device buffers only: stage through the card when the group is nccl
+        if dev is not None:
+            mine = mine.to(dev)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         for r, part in enumerate(parts):
+            part = part.cpu()
             a, b = min(r * chunk, count), min((r + 1) * chunk, count)
             lnp[a:b] = part[:b - a].numpy()
             status[a:b] = part[chunk:chunk + b - a].numpy().astype(np.int32)
 
     engine.ensemble_shard_host(rank, world, exchange)
-    return transport

@@ -446,8 +446,26 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
 class _FakeShardEngine:
     """Stands in for Engine in the CPU test of the host exchange: keeps the callback the way the library would."""
 
+    unsharded = 0
+
     def ensemble_shard_host(self, rank, world, exchange):
         self.rank, self.world, self.exchange = rank, world, exchange
+
+    # the RCCL bring-up as the library exposes it; `fail_on` = the ranks whose ncclCommInitRank "fails"
+    fail_on = ()
+
+    def rccl_unique_id(self):
+        return bytes(range(128))
+
+    def ensemble_shard_rccl(self, unique_id, rank, world):
+        assert unique_id == bytes(range(128))
+        if rank in self.fail_on:
+            raise RuntimeError("ncclCommInitRank failed: unhandled system error")
+        self.comm = (rank, world)
+
+    def ensemble_unshard(self):
+        self.unsharded += 1
+        self.comm = None
 
 
 def _host_exchange_worker(rank, world, port, out_dir):
@@ -474,6 +492,21 @@ def _host_exchange_worker(rank, world, port, out_dir):
     from mind_the_gaps_amd.distributed import broadcast_array
     tau = broadcast_array(np.array([[1.5 + rank, 2.0], [np.nan, 7.0 - rank]]))     # rank 0's autocorrelation times win
     ok = ok and tau.shape == (2, 2) and tau[0, 0] == 1.5 and tau[1, 1] == 7.0 and np.isnan(tau[1, 0])
+    # a communicator that comes up on rank 0 only: EVERY rank ends on the host-staged exchange, rank 0 having dropped its
+    # half-made communicator, and the returned transport says why (bench.py prints it as walker_sharded.*.transport)
+    eng = _FakeShardEngine()
+    eng.fail_on = (1,)
+    with pytest.warns(UserWarning, match="RCCL communicator not available"):
+        got = shard_device_ensemble(eng, transport="rccl")
+    ok = ok and got.startswith("host (rccl failed: rank 1: RuntimeError: ncclCommInitRank failed") and eng.unsharded == (1 if rank == 0 else 0)
+    lnp, st = np.full(5, np.nan), np.full(5, -1, dtype=np.int32)
+    lo, hi = min(rank * 3, 5), min(rank * 3 + 3, 5)
+    lnp[lo:hi], st[lo:hi] = -np.arange(5.0)[lo:hi], np.arange(5, dtype=np.int32)[lo:hi]
+    eng.exchange(lnp, st, lo, hi)
+    ok = ok and np.array_equal(lnp, -np.arange(5.0)) and np.array_equal(st, np.arange(5))
+    # ... and one that comes up everywhere stays on RCCL
+    eng = _FakeShardEngine()
+    ok = ok and shard_device_ensemble(eng, transport="rccl") == "rccl" and eng.comm == (rank, world) and eng.unsharded == 0
     open(os.path.join(out_dir, "hx%d.txt" % rank), "w").write("ok" if ok else "bad")
     dist.barrier()
     dist.destroy_process_group()
