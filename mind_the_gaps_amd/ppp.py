@@ -458,8 +458,10 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     (``observed_split``, two ranks or more): rank 0 runs the null model's chain on the observed light curve, rank 1 the
     alternative's, nobody else any; rank 1's maximum and rank 0's maximum, posterior samples and seeds are broadcast,
     so that all ranks test the same thing -- the chains are the ones one process runs (each model has a generator of its
-    own), hence the same ``T_obs`` to the last bit.  The returned ``null`` is then rank 0's alone and ``alt`` rank 1's
-    (``None`` elsewhere); ``observed_split=False``: every rank runs both and keeps both, rank 0's are everybody's test.
+    own), hence the same ``T_obs`` to the last bit.  **The returned ``null`` is then rank 0's alone and ``alt`` rank 1's
+    (``None`` on every other rank** -- a caller that reads ``res["null"].sampler`` on all ranks passes
+    ``observed_split=False``); a chain that fails on rank 0 or 1 raises on every rank (a ``RuntimeError`` naming the rank
+    on the others); ``observed_split=False``: every rank runs both and keeps both, rank 0's are everybody's test.
     ``sim_null``, ``sim_alt`` and ``lightcurves`` hold the rank's own block.  ``split``: "lightcurves" as just described,
     "models" -- the first half of the ranks refits the null model, the second half the alternative, each over all the
     light curves (a rank then holds ``sim_null`` or ``sim_alt``, not both) --, "auto" picks by the rows a half-step
@@ -521,8 +523,20 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
         warnings.simplefilter("ignore")
         if by_model:
             # one model's chain per rank (0: null, 1: alternative), on the process's own context
-            null = observed(null_kernel, seeds[0]) if shard.rank == 0 else None
-            alt = observed(alt_kernel, seeds[1]) if shard.rank == 1 else None
+            null = alt = obs_failure = None
+            try:
+                if shard.rank == 0:
+                    null = observed(null_kernel, seeds[0])
+                elif shard.rank == 1:
+                    alt = observed(alt_kernel, seeds[1])
+            except Exception as exc:      # said to everybody below: nobody may wait in a broadcast for a chain that died
+                obs_failure = exc
+            obs_failed = all_gather_rows(np.array([0.0 if obs_failure is None else 1.0]), np.ones(shard.world, dtype=int), group)
+            if obs_failure is not None:
+                raise obs_failure
+            if obs_failed.any():
+                raise RuntimeError("protassov_test: the observed light curve's chain failed on rank(s) %s"
+                                   % np.flatnonzero(obs_failed).tolist())
         elif walkers % 2 == 0 and observed_side_by_side:
             # two single-light-curve chains leave the GPU nearly empty: the two models side by side, each on a context
             # and a generator of its own -- the same chains as one after the other

@@ -441,6 +441,56 @@ def test_protassov_test_sharded_two_ranks_one_gpu(tmp_path):
     assert all(np.array_equal(x["T_sim"], single["T_sim"]) and float(x["p"]) == float(single["p"]) for x in o)
 
 
+def _protassov_observed_failure_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    guard = _watchdog(out_dir, "pof%d" % rank)
+    import warnings
+    import torch.distributed as dist
+    from mind_the_gaps_amd import gpmodelling
+    from mind_the_gaps_amd.lightcurves import GappyLightcurve
+    from mind_the_gaps_amd.models import DampedRandomWalk, Lorentzian
+    from mind_the_gaps_amd.ppp import protassov_test
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    th = synth.truth(synth.ALT_MODEL)
+    t, y, dy = synth.make_lightcurves(400, 1, seed=43)
+    lc = GappyLightcurve(t, y[0] + 50.0, dy[0], exposures=0.5 * np.diff(t).min())
+    null = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)])
+    alt = DampedRandomWalk(th[0], th[1], bounds=[(-10, 50), (-10, 10)]) + Lorentzian(
+        th[5], th[6], th[7], bounds=[(-10, 50), (-10, 10), (-10, 10)])
+    if rank == 1:       # the alternative model's observed chain dies on the rank that runs it
+
+        def broken(self, *a, **k):
+            raise ArithmeticError("failed to factorize or solve matrix")
+        gpmodelling.GPModelling.derive_posteriors = broken
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            protassov_test(lc, null, alt, nsims=4, walkers=16, max_steps=40, sim_steps=20, seed=11, sharded=True, reproducible=True)
+        outcome = "returned"
+    except ArithmeticError:
+        outcome = "own error"
+    except RuntimeError as exc:
+        outcome = "peer error" if "rank(s) [1]" in str(exc) else "other: %s" % exc
+    open(os.path.join(out_dir, "pof%d.txt" % rank), "w").write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+    guard.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_protassov_observed_chain_failure_reaches_every_rank(tmp_path):
+    """Step 1 split by model (rank 0 the null chain, rank 1 the alternative's): a chain that raises on its rank raises on
+    every rank before the first broadcast -- nobody waits for a maximum that will never be sent."""
+    world = 3
+    _spawn(_protassov_observed_failure_worker, (world, _free_port(), str(tmp_path)), world, tmp_path)
+    assert [open(tmp_path / ("pof%d.txt" % r)).read() for r in range(world)] == ["peer error", "own error", "peer error"]
+
+
 # ---- the device-resident sampler, walker-sharded (mtg_ensemble_shard_*) -------------------------------------
 
 class _FakeShardEngine:
