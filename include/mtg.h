@@ -226,6 +226,9 @@ MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index);
  * blocks over several GPUs needs to be the set of one call, bit for bit (with mtg_set_stream_base); default 1.
  */
 MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on);
+/* Which transform mtg_simulate_tk95 takes: 0 (default) = by grid length (hipFFT's plan for lengths of radices 2-13, the
+ * hand-written chirp-z otherwise), 1 = always hipFFT's plan, 2 = always chirp-z (tests compare the two). */
+MTG_API int mtg_set_simulate_transform(mtg_ctx *ctx, int mode);
 /*
  * The reference's simulator draws from numpy's GLOBAL generator -- get_fft (simulator.py:468-501): real, im =
  * np.random.normal(0, size=(2, N // 2 + 1)); cut_random_segment (simulator.py:536-539): np.random.uniform -- so a user who
@@ -255,13 +258,17 @@ MTG_API int mtg_set_pipeline(mtg_ctx *ctx, int mode);
  * driven by a host thread of its own.  A pipelined sweep takes a whole compute unit (its tables and rings fill the LDS),
  * so two contexts' launches alternate on the compute units and leave every SIMD one wave that issues ~60 % of the time;
  * paired, a workgroup of eight waves runs 128 rows of each model on one table set, two waves per SIMD.  Each call that
- * would dispatch mtg_pipe_kernel meets its partner's (on the host, bounded wait: MTG_PAIR_PATIENCE_MS, default 250);
- * a partner that does not come, another sampling or a pair of model shapes without a compiled kernel break the pair for
- * good and both go on alone.  Results are those of the unpaired kernels to the last bit.  mtg_pair_stats: launches that
- * were shared / made alone since pairing, and whether the pair is broken.  mtg_destroy unpairs.
+ * would dispatch mtg_pipe_kernel meets its partner's (on the host, bounded wait: mtg_set_pair_patience, default 250 ms);
+ * a partner that does not come in time means "alone this time" (the next wait is half as long); four misses in a row,
+ * another sampling or a pair of model shapes without a compiled kernel break the pair for good and both go on alone.
+ * Results are those of the unpaired kernels to the last bit.  mtg_pair_stats: launches that were shared / made alone
+ * since pairing, and whether the pair is broken.  mtg_destroy unpairs; unpairing (or destroying) one context while the
+ * partner's thread is inside a call is safe: the rendezvous is reference-counted and the partner launches alone.
  */
 MTG_API int mtg_pair_contexts(mtg_ctx *a, mtg_ctx *b);
 MTG_API int mtg_unpair_contexts(mtg_ctx *ctx);
+/* Longest host-side wait (ms >= 1) of a paired context for its partner's half-step; the context must be paired. */
+MTG_API int mtg_set_pair_patience(mtg_ctx *ctx, int milliseconds);
 MTG_API int mtg_pair_stats(const mtg_ctx *ctx, int64_t *paired_launches, int64_t *solo_launches, int *broken);
 /*
  * Speculative iterations of mtg_ensemble_run (default 1 = where they pay, 0 = never).  The time-parallel solve of a

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <condition_variable>
+#include <memory>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -175,8 +176,13 @@ struct mtg_ctx {
     int shard_ev_cap = 0, shard_ev_n = 0;
 
     // mtg_pair_contexts: the partner whose pipelined half-steps share a launch with this context's (MtgPair below)
-    struct MtgPair *pair = nullptr;
-    int pair_index = 0;
+    // Shared ownership: a thread inside pair_launch holds a reference of its own, so that mtg_unpair_contexts /
+    // mtg_destroy on the partner's thread cannot free the rendezvous under it.  Read and written with
+    // std::atomic_load / std::atomic_store only.
+    std::shared_ptr<struct MtgPair> pair;
+
+    // mtg_set_simulate_transform: 0 = by grid length (default), 1 = hipFFT's own plan, 2 = chirp-z
+    int sim_transform = 0;
 };
 
 // Two contexts whose pipelined sweeps go out in ONE launch (mtg_kernels_pipe_pair.hip): the two models of the Protassov
@@ -184,9 +190,16 @@ struct mtg_ctx {
 // a pipelined half-step first leaves its arguments here, records `ready` on its stream and waits -- on the HOST, for as
 // long as the partner takes to get to its own half-step, microseconds in steady state --; the second one makes its
 // stream wait for `ready`, launches both models' rows in one grid, records `done`, and the first one's stream waits
-// for that.  Nothing waits without a bound: a partner that does not come within `patience_ms` (its run is over, its
-// batch took another kernel) breaks the pair for good and everybody launches alone from then on.
+// for that.  Nothing waits without a bound: a partner that does not come within `patience_ms` (stalled between two C
+// calls, its run over, its batch on another kernel) means "alone this time"; MTG_PAIR_MAX_MISSES consecutive misses
+// (each waited for half as long as the one before) break the pair for good and everybody launches alone from then on.
+enum { MTG_PAIR_MAX_MISSES = 4 };
 struct MtgPair {
+    ~MtgPair()
+    {
+        for (hipEvent_t e : {ready[0], ready[1], done})
+            if (e) (void)hipEventDestroy(e);
+    }
     std::mutex mu;
     std::condition_variable cv;
     mtg_ctx *members[2] = {nullptr, nullptr};
@@ -199,6 +212,7 @@ struct MtgPair {
     uint64_t launched = 0;    // pair launches so far (a waiter leaves when it moves)
     bool broken = false;
     int patience_ms = 250;
+    int misses = 0;           // consecutive half-steps whose partner did not come
     int64_t n_pair = 0, n_solo = 0;
 };
 
@@ -411,10 +425,10 @@ int run_model_batch(mtg_ctx *ctx, int64_t B, const double *d_theta, const int32_
     return MTG_OK;
 }
 
-// MTG_SWEEP_MULTI=0 (measurements): one launch per structure even where the one-launch kernel exists
+// MTG_SWEEP_MULTI=0 (MTG_MEASURE builds only): one launch per structure even where the one-launch kernel exists
 bool sweep_multi_enabled()
 {
-    static const bool on = !(getenv("MTG_SWEEP_MULTI") && atoi(getenv("MTG_SWEEP_MULTI")) == 0);
+    static const bool on = !(mtg_measure_env("MTG_SWEEP_MULTI") && atoi(mtg_measure_env("MTG_SWEEP_MULTI")) == 0);
     return on;
 }
 
@@ -422,23 +436,27 @@ bool sweep_multi_enabled()
 // before anything that follows on `s` -- in a launch shared with the partner's; 0: the caller launches alone.
 int pair_launch(mtg_ctx *ctx, const MtgSolveArgs &sa, int64_t B, const MtgPipeShapeId &shape, hipStream_t s, int *paired)
 {
-    MtgPair *p = ctx->pair;
-    const int me = ctx->pair_index;
     *paired = 0;
+    const std::shared_ptr<MtgPair> p = std::atomic_load(&ctx->pair);   // ours for the whole call, whatever the partner does
+    if (!p) return MTG_OK;
     std::unique_lock<std::mutex> lk(p->mu);
     if (p->broken) { p->n_solo += 1; return MTG_OK; }
+    const int me = p->members[0] == ctx ? 0 : 1;
     if (!p->waiting) {
         HIP_TRY(ctx, hipEventRecord(p->ready[me], s));
         p->sa = sa; p->rows = B; p->shape = shape; p->who = me; p->waiting = true;
         const uint64_t seen = p->launched;
-        p->cv.wait_for(lk, std::chrono::milliseconds(p->patience_ms), [&] { return p->launched != seen || p->broken; });
+        const int patience = std::max(1, p->patience_ms >> std::min(p->misses, 8));
+        p->cv.wait_for(lk, std::chrono::milliseconds(patience), [&] { return p->launched != seen || p->broken; });
         if (p->launched != seen) {   // the partner launched both
+            p->misses = 0;
             HIP_TRY(ctx, hipStreamWaitEvent(s, p->done, 0));
             *paired = 1;
             return MTG_OK;
         }
-        p->waiting = false;          // nobody came (or the pair has no kernel): alone, now and from now on
-        p->broken = true;
+        p->waiting = false;          // nobody came: alone this time; for good after a few misses in a row
+        p->misses += 1;
+        if (p->misses >= MTG_PAIR_MAX_MISSES) p->broken = true;
         p->n_solo += 1;
         return MTG_OK;
     }
@@ -463,16 +481,27 @@ int pair_launch(mtg_ctx *ctx, const MtgSolveArgs &sa, int64_t B, const MtgPipeSh
         p->cv.notify_all();
         return MTG_OK;
     }
-    HIP_TRY(ctx, hipStreamWaitEvent(s, p->ready[p->who], 0));
+    if (hipStreamWaitEvent(s, p->ready[p->who], 0) != hipSuccess) {   // nothing launched: the waiter goes alone
+        p->broken = true;
+        p->n_solo += 1;
+        lk.unlock();
+        p->cv.notify_all();
+        return fail(ctx, MTG_E_HIP, "pair_launch: hipStreamWaitEvent failed");
+    }
     if (mine_first) fn(sa, B, other, p->rows, s);
     else fn(other, p->rows, sa, B, s);
-    HIP_TRY(ctx, hipEventRecord(p->done, s));
+    // The partner's rows ARE in flight from here on: whatever happens next, its wait must end with "launched" (a waiter
+    // that timed out would launch them a second time), and `done` is what its stream orders itself behind.
+    const hipError_t recorded = hipEventRecord(p->done, s);
     p->waiting = false;
     p->launched += 1;
     p->n_pair += 1;
+    p->misses = 0;
     *paired = 1;
+    if (recorded != hipSuccess) p->broken = true;
     lk.unlock();
     p->cv.notify_all();
+    if (recorded != hipSuccess) return fail(ctx, MTG_E_HIP, "pair_launch: hipEventRecord(done) failed: %s", hipGetErrorString(recorded));
     return MTG_OK;
 }
 
@@ -549,7 +578,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
             if (!mtg_find_tp_solver(m.nr0 + 2 * k, m.nc0 - k)) small_ok = false;
         const int C = mtg_tp_big_chunks(ctx->N, Bw);
         int g = mtg_tp_big_gsize(Bw, C);
-        if (const char *env = getenv("MTG_TP_GSIZE")) {  // measurements only
+        if (const char *env = mtg_measure_env("MTG_TP_GSIZE")) {  // MTG_MEASURE builds only
             const int v = atoi(env);
             if (v == 4 || v == 8 || v == 16) g = v;
         }
@@ -624,7 +653,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         sa.seg_k = 0;
         const MtgPipeShapeId shape{m.nr0, m.nc0, nsig, m.last_b0 ? 1 : 0};
         int paired = 0;
-        if (ctx->pair) {
+        if (std::atomic_load(&ctx->pair)) {
             const int rc = pair_launch(ctx, sa, B, shape, s, &paired);
             if (rc) return rc;
         }
@@ -652,7 +681,7 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
         // rows -- and a sampler's half-step of 256 000 walkers with a handful of them over-damped paid 14.9 ms for
         // the first structure and 3.2-4.3 ms more for those few (profiles/r03_c3_halfstep_trace.txt).  On their own
         // stream they take wave slots as the big launch frees them and finish under it.
-        static const bool sweep_fan_out = !(getenv("MTG_SWEEP_FANOUT") && atoi(getenv("MTG_SWEEP_FANOUT")) == 0);
+        static const bool sweep_fan_out = !(mtg_measure_env("MTG_SWEEP_FANOUT") && atoi(mtg_measure_env("MTG_SWEEP_FANOUT")) == 0);
         const bool fan_out = (small_ok || sweep_fan_out) && nsig > 1 && nsig - 1 <= MTG_MAX_J / 2;
         if (fan_out) {
             if (!ctx->fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming));
@@ -761,7 +790,7 @@ static mtg_ctx *create_context(int device, int part, int parts)
         // leaves every XCD with its share of enabled compute units, which a dispatch split over all XCDs needs.)
         uint32_t mask[16] = {};
         int mine = 0;
-        const bool interleaved = getenv("MTG_CU_SLICE_INTERLEAVED") && atoi(getenv("MTG_CU_SLICE_INTERLEAVED")) == 1;
+        const bool interleaved = mtg_measure_env("MTG_CU_SLICE_INTERLEAVED") && atoi(mtg_measure_env("MTG_CU_SLICE_INTERLEAVED")) == 1;
         const int per = ctx->cus / parts;
         for (int i = 0; i < ctx->cus && i < 512; ++i)
             if (interleaved ? i % parts == part : (i / per == part || (part == parts - 1 && i / per >= parts))) {
@@ -1743,7 +1772,7 @@ static int sim_batch_for(int64_t nfft, int64_t S = INT64_MAX)
 {
     int64_t b = ((int64_t)1 << 24) / nfft;
     b = b < 16 ? 16 : b > 256 ? 256 : b;
-    if (const char *env = getenv("MTG_SIM_BATCH")) b = atoi(env) > 0 ? atoi(env) : b;
+    if (const char *env = mtg_measure_env("MTG_SIM_BATCH")) b = atoi(env) > 0 ? atoi(env) : b;   // MTG_MEASURE builds only
     const int64_t fit = ((int64_t)1 << 31) / (16 * (nfft / 2 + 1) + 8 * nfft);
     if (b > fit) b = fit;
     if (b > S) b = S;   // fewer series than a full batch: no transforms of empty slots
@@ -1777,10 +1806,12 @@ static int64_t czt_length(int64_t nfft)
     return m;
 }
 // lengths hipFFT transforms natively (radices 2 .. 13) keep its Z2D plan; anything with a larger prime factor goes through
-// power-of-two transforms -- while one pair's work area (16 m bytes) stays within 2 GiB.  MTG_SIM_CZT=0 / 1 forces.
-static bool sim_wants_czt(int64_t nfft)
+// power-of-two transforms -- while one pair's work area (16 m bytes) stays within 2 GiB.  mtg_set_simulate_transform
+// forces one or the other (mode 1: the library's plan, 2: chirp-z).
+static bool sim_wants_czt(const mtg_ctx *ctx, int64_t nfft)
 {
-    if (const char *env = getenv("MTG_SIM_CZT")) return atoi(env) != 0 && czt_length(nfft) * 16 <= ((int64_t)1 << 31);
+    if (ctx->sim_transform == 1) return false;
+    if (ctx->sim_transform == 2) return czt_length(nfft) * 16 <= ((int64_t)1 << 31);
     int64_t r = nfft;
     for (int64_t f : {2, 3, 5, 7, 11, 13})
         while (r % f == 0) r /= f;
@@ -1842,7 +1873,7 @@ MTG_API int mtg_simulate_plan(mtg_ctx *ctx, int64_t nfft)
 {
     if (!ctx || nfft < 4 || nfft > ((int64_t)1 << 30)) return MTG_E_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return MTG_E_HIP;   // (HIP's current device is per thread)
-    if (sim_wants_czt(nfft)) {   // the bulk plan of the power-of-two transforms (milliseconds); the tables at first use
+    if (sim_wants_czt(ctx, nfft)) {   // the bulk plan of the power-of-two transforms (milliseconds); the tables at first use
         const int64_t m = czt_length(nfft);
         return czt_plan_get(ctx, m, czt_pairs_for(m), nullptr);
     }
@@ -1898,7 +1929,7 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     const int64_t nk = nfft / 2 + 1;
     // the simulations go through the context's plan `chunk` at a time (the last group may be short: the transforms of
     // the unused slots run on whatever the buffer holds and are not looked at)
-    const bool czt = sim_wants_czt(nfft);
+    const bool czt = sim_wants_czt(ctx, nfft);
     const int64_t czt_m = czt ? czt_length(nfft) : 0;
     const int czt_per = ctx->czt.pairs_on ? 2 : 1;   // series per complex transform
     const int czt_pairs = czt ? czt_pairs_for(czt_m, S, czt_per) : 0;
@@ -2245,6 +2276,13 @@ MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on)
     return MTG_OK;
 }
 
+MTG_API int mtg_set_simulate_transform(mtg_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MTG_E_ARG;
+    ctx->sim_transform = mode;
+    return MTG_OK;
+}
+
 MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index)
 {
     if (!ctx) return MTG_E_ARG;
@@ -2289,18 +2327,21 @@ MTG_API const char *mtg_last_solver(const mtg_ctx *ctx) { return ctx ? ctx->last
 MTG_API int mtg_unpair_contexts(mtg_ctx *ctx)
 {
     if (!ctx) return MTG_E_ARG;
-    MtgPair *p = ctx->pair;
+    const std::shared_ptr<MtgPair> p = std::atomic_load(&ctx->pair);
     if (!p) return MTG_OK;
+    mtg_ctx *members[2];
     {
+        // A partner thread may be inside pair_launch right now (waiting for this context's half-step, or about to
+        // lock): it holds a reference of its own, sees `broken` and launches alone; the rendezvous is freed by
+        // whoever drops the last reference.
         std::lock_guard<std::mutex> lk(p->mu);
-        p->broken = true;      // (nobody may be inside a paired call now: the callers' threads have returned)
+        p->broken = true;
+        members[0] = p->members[0]; members[1] = p->members[1];
+        p->members[0] = p->members[1] = nullptr;
     }
     p->cv.notify_all();
-    for (mtg_ctx *m : p->members)
-        if (m) { m->pair = nullptr; m->pair_index = 0; }
-    for (hipEvent_t e : {p->ready[0], p->ready[1], p->done})
-        if (e) (void)hipEventDestroy(e);
-    delete p;
+    for (mtg_ctx *m : members)
+        if (m) std::atomic_store(&m->pair, std::shared_ptr<MtgPair>());
     return MTG_OK;
 }
 
@@ -2308,18 +2349,16 @@ MTG_API int mtg_pair_contexts(mtg_ctx *a, mtg_ctx *b)
 {
     if (!a || !b || a == b) return MTG_E_ARG;
     if (a->device != b->device) return fail(a, MTG_E_ARG, "mtg_pair_contexts: the two contexts are on different devices");
-    if (a->pair || b->pair) return fail(a, MTG_E_STATE, "mtg_pair_contexts: a context is paired already (mtg_unpair_contexts first)");
+    if (std::atomic_load(&a->pair) || std::atomic_load(&b->pair))
+        return fail(a, MTG_E_STATE, "mtg_pair_contexts: a context is paired already (mtg_unpair_contexts first)");
     int rc = use_device(a);
     if (rc) return rc;
-    MtgPair *p = new (std::nothrow) MtgPair();
+    std::shared_ptr<MtgPair> p(new (std::nothrow) MtgPair());
     if (!p) return fail(a, MTG_E_HIP, "mtg_pair_contexts: out of memory");
-    bool ok = true;
     for (hipEvent_t *e : {&p->ready[0], &p->ready[1], &p->done})
-        ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    if (const char *env = getenv("MTG_PAIR_PATIENCE_MS")) p->patience_ms = atoi(env) > 0 ? atoi(env) : p->patience_ms;
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
+            return fail(a, MTG_E_HIP, "mtg_pair_contexts: event creation failed");   // (~MtgPair destroys the ones made)
     p->members[0] = a; p->members[1] = b;
-    a->pair = p; a->pair_index = 0;
-    b->pair = p; b->pair_index = 1;
     // Two models that are known now and have no kernel in common -- one of them without a pipelined sweep (a DRW alone),
     // or a pair of shapes that is not compiled -- never meet: broken from the start, nobody waits for a partner that has
     // nothing to bring.  (Models set later are looked at when their half-steps meet.)
@@ -2328,17 +2367,25 @@ MTG_API int mtg_pair_contexts(mtg_ctx *a, mtg_ctx *b)
         const MtgPipeShapeId sa = shape(a), sb = shape(b);
         if (!mtg_find_pipe_pair_solver(sa, sb) && !mtg_find_pipe_pair_solver(sb, sa)) p->broken = true;
     }
-    if (!ok) {
-        mtg_unpair_contexts(a);
-        return fail(a, MTG_E_HIP, "mtg_pair_contexts: event creation failed");
-    }
+    std::atomic_store(&a->pair, p);
+    std::atomic_store(&b->pair, p);
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_pair_patience(mtg_ctx *ctx, int milliseconds)
+{
+    if (!ctx || milliseconds < 1) return MTG_E_ARG;
+    const std::shared_ptr<MtgPair> p = std::atomic_load(&ctx->pair);
+    if (!p) return fail(ctx, MTG_E_STATE, "mtg_set_pair_patience: the context is not paired");
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->patience_ms = milliseconds;
     return MTG_OK;
 }
 
 MTG_API int mtg_pair_stats(const mtg_ctx *ctx, int64_t *paired_launches, int64_t *solo_launches, int *broken)
 {
     if (!ctx) return MTG_E_ARG;
-    MtgPair *p = ctx->pair;
+    const std::shared_ptr<MtgPair> p = std::atomic_load(&const_cast<mtg_ctx *>(ctx)->pair);
     if (paired_launches) *paired_launches = 0;
     if (solo_launches) *solo_launches = 0;
     if (broken) *broken = 0;

@@ -6,6 +6,16 @@
 
 #include "../../include/mtg.h"
 
+// Measurement knobs (kernel A/B experiments: scripts/build_variant.sh compiles with -DMTG_MEASURE).  The shipped library
+// reads NO environment variable: every switch a user may touch is an mtg_set_* entry of include/mtg.h, and nothing that
+// can change the bits of a result (the rank-10 chunk count, ...) hangs on the environment of the process.
+#ifdef MTG_MEASURE
+#include <stdlib.h>
+static inline const char *mtg_measure_env(const char *name) { return getenv(name); }
+#else
+static inline const char *mtg_measure_env(const char *) { return nullptr; }
+#endif
+
 // What celerite.GP(kernel, mean, fit_mean) holds (reference gpmodelling.py:51),
 // flattened so that it travels as a kernel argument (scalar loads only).
 struct MtgModel {

@@ -675,8 +675,8 @@ void mtg_launch_sampler_spec(const MtgEnsembleArgs &g, int do_accept, uint32_t i
     // (measured, iterations/s with 256 / 1024 threads: W = 32 44.1e3 / 43.0e3, W = 128 18.2e3 / 19.0e3, W = 256 6.8e3 / 7.7e3)
     const int threads = do_propose && g.E <= 64 && g.W > 64 ? 1024 : 256;
     // the ensemble's state in LDS for the length of the kernel (mtg_spec_both_lds): small ensembles whose splits were made
-    // beforehand, between two solves of a run (MTG_SAMPLER_LDS=0: never, for measurements)
-    static const bool lds_wanted = !(getenv("MTG_SAMPLER_LDS") && atoi(getenv("MTG_SAMPLER_LDS")) == 0);
+    // beforehand, between two solves of a run (MTG_SAMPLER_LDS=0 in an MTG_MEASURE build: never)
+    static const bool lds_wanted = !(mtg_measure_env("MTG_SAMPLER_LDS") && atoi(mtg_measure_env("MTG_SAMPLER_LDS")) == 0);
     const int state_in_lds = lds_wanted && do_accept && do_propose && g.perm_next && g.W / 2 <= 256 && g.W / 2 <= threads &&
                              (int64_t)g.W * g.P <= MTG_SPEC_LDS_DOUBLES ? 1 : 0;
     // keys (8 W), ranks (4 W), accept flags (4 W/2), padding to 8 bytes, then 3 W/2 proposals of P doubles; with the state

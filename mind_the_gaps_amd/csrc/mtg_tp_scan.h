@@ -89,7 +89,7 @@ static inline int mtg_tp_big_chunks(int64_t N, int64_t B)
     // is then half as long (scripts/c5_chunk_target.sh, N = 2e5, ms per half-step at 32 768 / 16 384: 8 rows 0.311 / 0.265,
     // 16 rows 0.385 / 0.349, 32 rows 0.540 / 0.534, 64 rows 0.843 / 0.876, 256 rows 2.66 / 2.87)
     int64_t target = B <= 16 ? 16384 : 32768;
-    if (const char *env = getenv("MTG_TP_CHUNK_TARGET")) {  // measurements only
+    if (const char *env = mtg_measure_env("MTG_TP_CHUNK_TARGET")) {  // MTG_MEASURE builds only: the chunk count decides a result's bits
         const long v = atol(env);
         if (v >= 64) target = v;
     }

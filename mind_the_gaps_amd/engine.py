@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_pair_patience",
     "mtg_set_simulate_draws",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
@@ -250,6 +250,10 @@ def load_library():
     lib.mtg_simulate_plan.argtypes = [c_vp, c_i64]
     lib.mtg_set_simulate_pairs.restype = c_int
     lib.mtg_set_simulate_pairs.argtypes = [c_vp, c_int]
+    lib.mtg_set_simulate_transform.restype = c_int
+    lib.mtg_set_simulate_transform.argtypes = [c_vp, c_int]
+    lib.mtg_set_pair_patience.restype = c_int
+    lib.mtg_set_pair_patience.argtypes = [c_vp, c_int]
     lib.mtg_set_simulate_draws.restype = c_int
     lib.mtg_set_simulate_draws.argtypes = [c_vp, c_i64, c_i64, _dp, ctypes.POINTER(c_i64)]
     lib.mtg_pair_contexts.restype = c_int
@@ -763,6 +767,12 @@ class Engine:
         other series of the call (include/mtg.h: mtg_set_simulate_pairs)."""
         self._check(self._lib.mtg_set_simulate_pairs(self._ctx, 1 if on else 0))
 
+    def set_simulate_transform(self, mode):
+        """"auto" / 0: hipFFT's plan for grid lengths it takes natively, chirp-z otherwise; "library" / 1; "chirp-z" / 2
+        (include/mtg.h: mtg_set_simulate_transform)."""
+        mode = {"auto": 0, "library": 1, "chirp-z": 2}.get(mode, mode)
+        self._check(self._lib.mtg_set_simulate_transform(self._ctx, int(mode)))
+
     def set_simulate_draws(self, normals, starts):
         """Hand the next simulate_tk95 its random numbers (include/mtg.h: mtg_set_simulate_draws): ``normals`` [S][2][nk]
         standard normals, ``starts`` [S] first fine-grid index of every cut.  ``None``: clear."""
@@ -788,6 +798,10 @@ class Engine:
 
     def unpair(self):
         self._check(self._lib.mtg_unpair_contexts(self._ctx))
+
+    def set_pair_patience(self, milliseconds):
+        """Longest host-side wait of this (paired) context for its partner's half-step (include/mtg.h: mtg_set_pair_patience)."""
+        self._check(self._lib.mtg_set_pair_patience(self._ctx, int(milliseconds)))
 
     def pair_stats(self):
         """{"paired": launches shared with the partner, "solo": pipelined launches made alone, "broken": bool} since pairing."""

@@ -103,9 +103,14 @@ class Simulator:
 
     def __init__(self, psd_model, times, exposures, mean, pdf="gaussian", bkg_rate=None, bkg_rate_err=None,
                  sigma_noise=None, aliasing_factor=2, extension_factor=10, epsilon=1.001, max_iter=400,
-                 random_state=None, device=0, kraft_counts=15, stream="philox"):
+                 random_state=None, device=0, kraft_counts=15, stream="philox", transform="auto"):
         if stream not in ("philox", "numpy"):
             raise ValueError("stream must be 'philox' or 'numpy'")
+        if transform not in ("auto", "library", "chirp-z"):
+            raise ValueError("transform must be 'auto', 'library' or 'chirp-z'")
+        # which inverse transform the device takes (mtg_set_simulate_transform): "auto" picks by grid length; the other
+        # two exist so that tests can hold one against the other
+        self.transform = transform
         if stream == "numpy" and pdf.lower() != "gaussian":
             raise NotImplementedError("stream='numpy' reproduces the reference's Gaussian (TK95) light curves only")
         self.stream = stream
@@ -212,11 +217,15 @@ class Simulator:
             n = len(self._times)
             self._evaluator = LogProbEvaluator(self._times, np.zeros(n), np.ones(n), device=self.device)
         if self._kernel is None:
-            return self._evaluator._bind_lightcurves(), None
+            eng = self._evaluator._bind_lightcurves()
+            eng.set_simulate_transform(self.transform)
+            return eng, None
         model = DeviceModel(self._kernel, ConstantModel(0.0), np.zeros(1, dtype=bool))
         if not model.device_terms:
             raise ValueError("the device simulator needs device-expandable terms")
-        return self._evaluator._bind(model), model
+        eng = self._evaluator._bind(model)
+        eng.set_simulate_transform(self.transform)     # (engines are shared per device: every simulator says which)
+        return eng, model
 
     def warm_up(self):
         """Start building the inverse-transform plan of this simulator's grid on a helper thread (the engine keeps one

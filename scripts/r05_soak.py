@@ -2,7 +2,7 @@
   (1) mtg_pair_contexts -- random null / alternative pair (tests/test_pipe_gpu.py: PAIRS), N in [64, 3000], light curves,
       walkers, both SHO regimes, prior rejections: paired rows == each model's own pipelined kernel, bit for bit;
   (2) the simulator's chirp-z transform -- random sampling patterns (grid lengths of either parity, 10^4 .. 10^5 points),
-      1 .. 7 series: against hipFFT's own transform of the same spectrum (MTG_SIM_CZT = 1 / 0), 1e-11 of the series' scale.
+      1 .. 7 series: against hipFFT's own transform of the same spectrum (Simulator(transform="chirp-z" / "library")), 1e-11 of the series' scale.
     python scripts/r05_soak.py [cases_pairs] [cases_czt] [seed]"""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,9 +78,8 @@ for case in range(n_czt):
     ext = float(rng.choice([1.5, 2, 3]))
     S = int(rng.integers(1, 8))
     got = {}
-    for mode in ("1", "0"):
-        os.environ["MTG_SIM_CZT"] = mode
-        sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=ext, random_state=4)
+    for mode, transform in (("1", "chirp-z"), ("0", "library")):
+        sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=ext, random_state=4, transform=transform)
         thetas = np.tile(sim._engine()[1].full[sim._engine()[1].free_index][None, :], (S, 1))
         got[mode] = sim.simulate(thetas, seed=1000 + case, want_clean=True)["clean"]
     parities.add(sim.fftndatapoints % 2)

@@ -315,24 +315,30 @@ def test_paired_contexts_share_a_launch_and_keep_every_bit(N):
             eng.close()
 
 
-def test_a_partner_that_does_not_come_breaks_the_pair_not_the_run(monkeypatch):
-    """A paired context whose partner never reaches a pipelined half-step waits MTG_PAIR_PATIENCE_MS once, launches alone
-    and never waits again; a pair of shapes without a compiled kernel goes alone as well.  Same results."""
+def test_a_partner_that_does_not_come_breaks_the_pair_not_the_run():
+    """A paired context whose partner does not reach a pipelined half-step in time (mtg_set_pair_patience) launches alone
+    THIS time -- a partner may be stalled between two C calls for a moment --, waits half as long the next time, and after
+    four misses in a row never waits again; a pair of shapes without a compiled kernel goes alone at once.  Same results."""
     import time
-    monkeypatch.setenv("MTG_PAIR_PATIENCE_MS", "40")
     engines, thetas, lc = _two_models(N=300)
     try:
         alone = engines[1].loglike(thetas[1], lc, add_prior=True)
         engines[0].pair_with(engines[1])
+        engines[1].set_pair_patience(40)
         t0 = time.perf_counter()
         got = engines[1].loglike(thetas[1], lc, add_prior=True)        # the partner never calls
         waited = time.perf_counter() - t0
-        again = engines[1].loglike(thetas[1], lc, add_prior=True)
+        assert engines[1].pair_stats() == {"paired": 0, "solo": 1, "broken": False} and 0.03 < waited < 2.0
+        for _ in range(3):
+            again = engines[1].loglike(thetas[1], lc, add_prior=True)
         stats = engines[1].pair_stats()
+        t0 = time.perf_counter()
+        fifth = engines[1].loglike(thetas[1], lc, add_prior=True)      # broken: no wait at all
+        assert time.perf_counter() - t0 < 1.0
         engines[1].unpair()
         assert "mtg_pipe_kernel" in engines[1].last_solver
-        assert np.array_equal(got[0], alone[0]) and np.array_equal(again[0], alone[0])
-        assert stats == {"paired": 0, "solo": 2, "broken": True} and 0.03 < waited < 2.0
+        assert np.array_equal(got[0], alone[0]) and np.array_equal(again[0], alone[0]) and np.array_equal(fifth[0], alone[0])
+        assert stats == {"paired": 0, "solo": 4, "broken": True}
         # the same model twice is not a pair the library has a kernel for: known at pairing time, both go alone at once
         full_kinds = MODELS["alt_drw_sho_lorentzian"]
         t, y, dy = synth.make_lightcurves(300, 9, seed=3)
@@ -347,6 +353,41 @@ def test_a_partner_that_does_not_come_breaks_the_pair_not_the_run(monkeypatch):
         engines[0].unpair()
         assert stats["paired"] == 0 and stats["broken"] and stats["solo"] == 2
         assert np.array_equal(both[0][0], alone[0]) and np.array_equal(both[1][0], alone[0])
+    finally:
+        for eng in engines:
+            eng.close()
+
+
+def test_a_context_may_be_closed_while_its_partner_waits_for_it():
+    """mtg_destroy on one member of a pair while the partner's thread sits in the rendezvous (waiting for a half-step that
+    will never come): the partner wakes, launches alone with the right numbers, and nothing is freed under it -- the
+    rendezvous is reference-counted (csrc/mtg_capi.hip, MtgPair)."""
+    import threading
+    import time
+    engines, thetas, lc = _two_models(N=300)
+    try:
+        alone = engines[1].loglike(thetas[1], lc, add_prior=True)
+        for _ in range(5):
+            engines[0].pair_with(engines[1])
+            engines[1].set_pair_patience(2000)
+            got = {}
+            worker = threading.Thread(target=lambda: got.update(out=engines[1].loglike(thetas[1], lc, add_prior=True)))
+            t0 = time.perf_counter()
+            worker.start()
+            time.sleep(0.05)                       # the worker is inside pair_launch, waiting for engine 0
+            engines[0].unpair()                    # (what mtg_destroy does first)
+            worker.join(10)
+            assert not worker.is_alive() and time.perf_counter() - t0 < 1.5      # woken by the unpairing, not by the patience
+            assert np.array_equal(got["out"][0], alone[0])
+            assert engines[1].pair_stats() == {"paired": 0, "solo": 0, "broken": False}     # unpaired: nothing to report
+        engines[0].pair_with(engines[1])
+        engines[1].set_pair_patience(2000)
+        worker = threading.Thread(target=lambda: got.update(out=engines[1].loglike(thetas[1], lc, add_prior=True)))
+        worker.start()
+        time.sleep(0.05)
+        engines[0].close()                         # destroyed outright under the waiting partner
+        worker.join(10)
+        assert not worker.is_alive() and np.array_equal(got["out"][0], alone[0])
     finally:
         for eng in engines:
             eng.close()

@@ -196,18 +196,17 @@ def test_closed_form_spectra_drive_the_simulator_like_their_terms():
 
 
 @pytest.mark.parametrize("nsims", [1, 2, 5])
-def test_chirp_z_transform_is_the_library_transform(monkeypatch, nsims):
+def test_chirp_z_transform_is_the_library_transform(nsims):
     """A grid length with large prime factors is transformed by hand on power-of-two transforms (csrc/mtg_simulate.hip,
-    chirp-z: hipFFT's own plan for such a length takes 0.9 s to BUILD); forced on and off (MTG_SIM_CZT) for the same seed the
+    chirp-z: hipFFT's own plan for such a length takes 0.9 s to BUILD); forced on and off (Simulator(transform=...), mtg_set_simulate_transform) for the same seed the
     two paths give the same series -- odd and even numbers of series (two share a complex transform), one alone."""
     rng = np.random.default_rng(11)
     times = synth.make_times(157, rng)                    # (the grid length is whatever the reference's arithmetic makes it)
     kernel = DampedRandomWalk(np.log(100.0), np.log(2 * np.pi / 10), bounds=[(-10, 50), (-10, 10)]) + \
         Lorentzian(np.log(50.0), np.log(20.0), np.log(2 * np.pi / 3.0), bounds=[(-10, 50), (-10, 10), (-10, 10)])
     got = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MTG_SIM_CZT", mode)
-        sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=3, random_state=4)
+    for mode, transform in (("1", "chirp-z"), ("0", "library")):
+        sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=3, random_state=4, transform=transform)
         thetas = np.tile(sim._engine()[1].full[sim._engine()[1].free_index][None, :], (nsims, 1))
         got[mode] = (sim.fftndatapoints, sim.simulate(thetas, seed=2468, want_clean=True))
     n = got["1"][0]
@@ -227,9 +226,8 @@ def test_chirp_z_transform_even_and_odd_lengths(monkeypatch):
     for seed in (100, 101, 104, 105):         # sampling patterns whose grids come out at 56 989, 57 051, 56 414, 55 246 points
         times = synth.make_times(150, np.random.default_rng(seed))
         got = {}
-        for mode in ("1", "0"):
-            monkeypatch.setenv("MTG_SIM_CZT", mode)
-            sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=2, random_state=4)
+        for mode, transform in (("1", "chirp-z"), ("0", "library")):
+            sim = Simulator(kernel, times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=2, random_state=4, transform=transform)
             thetas = np.tile(sim._engine()[1].full[sim._engine()[1].free_index][None, :], (3, 1))
             got[mode] = sim.simulate(thetas, seed=97531, want_clean=True)["clean"]
         seen.add(sim.fftndatapoints % 2)
