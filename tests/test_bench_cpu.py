@@ -45,4 +45,4 @@ def test_design_table_is_in_sync_with_the_bench_line_on_file():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     done = subprocess.run([sys.executable, os.path.join(root, "scripts", "design_table.py"), "--check"], capture_output=True, text=True)
     assert done.returncode == 0, done.stderr
-    assert os.path.getsize(os.path.join(root, "DESIGN.md")) <= 40 * 1024      # a current-state document, not a notebook
+    assert os.path.getsize(os.path.join(root, "DESIGN.md")) <= 64 * 1024      # a current-state document, not a notebook
