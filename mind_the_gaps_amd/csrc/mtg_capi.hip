@@ -77,6 +77,8 @@ struct mtg_ctx {
 
     // workspaces
     DevBuf coef, lists, counts, tp_ws, sig;
+    DevBuf tables;            // resident exp2 / (cos, sin) tables for the time-parallel kernels (mtg_launch_tables)
+    bool tables_ready = false;
     int64_t cstride = 0;
     int nsig_ws = 1;  // signature lists the workspace was laid out for
     int bank = 0;     // which of the two banks of structure lists / counters the next expansion and solve use (the device
@@ -508,12 +510,12 @@ int pair_launch(mtg_ctx *ctx, const MtgSolveArgs &sa, int64_t B, const MtgPipeSh
 // Launch the solver(s) for B prepared evaluations living in ctx->coef (lists / counts filled).
 // may_sort: the caller's order is arbitrary (mtg_loglike_batch[_device]); the device sampler's batches are grouped
 // by ensemble, hence by light curve, by construction.
-int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s, bool may_sort)
+// What every solver launch of B prepared evaluations takes: the resident light curves, the coefficient columns, the
+// context's tables (made at the first call).
+int solve_args_base(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s, MtgSolveArgs &sa)
 {
     const MtgModel &m = ctx->model;
-    const int nsig = m.nsho + 1;
     MtgCoefLayout lay{m.nr_max, m.nc_max};
-    MtgSolveArgs sa;
     sa.coef = ctx->coef.as<double>();
     sa.cstride = ctx->cstride;
     sa.lay = lay;
@@ -535,6 +537,27 @@ int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, 
     sa.has_mean = !(m.mean_kind == MTG_MEAN_CONSTANT && m.src[m.nk] < 0 && m.defaults[m.nk] == 0.0);
     for (int i = 0; i < m.nterms; ++i)
         if (m.kinds[i] == MTG_TERM_JITTER) sa.has_mean = 1;  // the plain sweep variant also skips the jitter add
+    if (!ctx->tables_ready) {   // once per context, on the stream of its first batch (every later one is ordered behind it)
+        HIP_TRY(ctx, ctx->tables.reserve(mtg_tables_bytes()));
+        mtg_launch_tables(ctx->tables.p, s);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->tables_ready = true;
+    }
+    sa.tables = ctx->tables.p;
+    if (const char *env = mtg_measure_env("MTG_GLOBAL_TABLES"))   // MTG_MEASURE builds only: 0 = every workgroup computes its own
+        if (atoi(env) == 0) sa.tables = nullptr;
+    return MTG_OK;
+}
+
+int solve_prepared(mtg_ctx *ctx, int64_t B, const int32_t *d_lc, double *d_out, int32_t *d_status, hipStream_t s, bool may_sort)
+{
+    const MtgModel &m = ctx->model;
+    const int nsig = m.nsho + 1;
+    MtgSolveArgs sa;
+    {
+        const int rc = solve_args_base(ctx, B, d_lc, d_out, d_status, s, sa);
+        if (rc) return rc;
+    }
     // A small batch of long light curves leaves a one-lane-per-evaluation launch idle for N serial
     // steps: give every evaluation a whole wave (or four) instead (mtg_timeparallel.hip); the rank-10
     // structures get as many chunks per evaluation as fill the GPU (mtg_tp_big.h).
@@ -826,7 +849,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->foreign_pending) (void)hipEventSynchronize(ctx->foreign_done);
     DevBuf *bufs[] = {&ctx->sort_keys, &ctx->sort_keys_out, &ctx->sort_order, &ctx->sort_tmp, &ctx->dxt, &ctx->yv, &ctx->t_tmp, &ctx->y_tmp, &ctx->dy_tmp, &ctx->off_tmp, &ctx->dxmax, &ctx->coef, &ctx->lists,
-                      &ctx->counts, &ctx->tp_ws, &ctx->sig, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
+                      &ctx->counts, &ctx->tp_ws, &ctx->sig, &ctx->tables, &ctx->theta, &ctx->lc, &ctx->out, &ctx->status,
                       &ctx->ens_coords, &ctx->ens_lnp, &ctx->ens_perm, &ctx->ens_q, &ctx->ens_factor,
                       &ctx->ens_new, &ctx->ens_st, &ctx->ens_lc_full, &ctx->ens_lc_half, &ctx->ens_lc_spec, &ctx->ens_perm_all, &ctx->ens_naccept,
                       &ctx->ens_best_lnp, &ctx->ens_best_coords, &ctx->ens_notpd, &ctx->ens_chain,

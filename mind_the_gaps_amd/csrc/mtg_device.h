@@ -114,7 +114,14 @@ struct MtgSolveArgs {
     // this launch takes the seg_k-th segment of it, which starts after seg_counts[0 .. seg_k); NULL: list starts at 0
     const int *seg_counts = nullptr;
     int seg_k = 0;
+    // the context's resident copy of the exp2 / (cos, sin) tables (struct MtgMathTablesT<true> of mtg_math.h, made once by
+    // mtg_launch_tables): the time-parallel kernels copy it into LDS instead of computing it per workgroup; NULL: computed
+    const void *tables = nullptr;
 };
+
+// fills `tables` (sizeof(MtgMathTablesT<true>) bytes of device memory) -- mtg_timeparallel.hip
+void mtg_launch_tables(void *tables, hipStream_t stream);
+size_t mtg_tables_bytes();
 
 // doubles per filtering element (A | b | eta | C | Jm | five likelihood scalars) of the time-parallel kernel,
 // rounded up to an odd number: lane l's element starts l * MTG_TP_ELEM doubles into LDS, and an even stride

@@ -56,6 +56,43 @@ __device__ __forceinline__ void mtg_fill_tables(MtgMathTablesT<TRIG> *tab, int t
         }
 }
 
+// The same tables copied from a resident global copy (made once per context by mtg_tables_kernel with mtg_fill_tables
+// itself, so the entries are the same bits): a workgroup of ONE wave spends ~5 us computing 2048 exp2 and 2048 sincospi
+// entries -- as long as the rest of a short light curve's time-parallel solve -- and ~1 us copying them.  `src` NULL:
+// computed as before.  TRIG_USED = false: the (cos, sin) table is left alone (a model without complex terms never reads it).
+template <bool TRIG_USED>
+__device__ __forceinline__ void mtg_load_tables(MtgMathTablesT<true> *tab, const MtgMathTablesT<true> *src, int tid, int nthreads)
+{
+    if (!src) {
+        for (int j = tid; j < MTG_EXP_N; j += nthreads) tab->exp2_frac[j] = exp2((double)j * (1.0 / MTG_EXP_N));
+        if (TRIG_USED)
+            for (int j = tid; j < MTG_TRIG_N; j += nthreads) {
+                double s, c;
+                sincospi((double)j * (2.0 / MTG_TRIG_N), &s, &c);
+                tab->cis[j] = make_double2(c, s);
+            }
+        return;
+    }
+    // batches of loads issued together (a loop of load -> LDS store waits for memory once per trip)
+    constexpr int BATCH = 16;
+    const double2 *s = reinterpret_cast<const double2 *>(src);
+    double2 *d = reinterpret_cast<double2 *>(tab);
+    const int n = TRIG_USED ? (int)(sizeof(MtgMathTablesT<true>) / sizeof(double2)) : MTG_EXP_N / 2;
+    for (int base = tid; base < n; base += BATCH * nthreads) {
+        double2 r[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int j = base + u * nthreads;
+            r[u] = j < n ? s[j] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int j = base + u * nthreads;
+            if (j < n) d[j] = r[u];
+        }
+    }
+}
+
 // exp(r) - 1 on |r| <= ln2 / 2^(BITS+1), truncation error below 4e-17 absolute.
 __device__ __forceinline__ double mtg_expm1_small(double r)
 {

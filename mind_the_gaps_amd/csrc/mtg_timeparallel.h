@@ -1403,7 +1403,7 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_kernel(MtgSolveArgs a)
     if ((int64_t)blockIdx.x >= count) return;
     const int64_t ev = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
     if (!a.list && a.status[ev] != MTG_ST_OK) return;
-    mtg_fill_tables(&tab, threadIdx.x, LANES);
+    mtg_load_tables<(NC > 0)>(&tab, static_cast<const MtgMathTables *>(a.tables), threadIdx.x, LANES);
     __syncthreads();
     mtg_tp_eval<NR, NC, LANES>(a, ev, &tab, sh, red);
 }
@@ -1446,7 +1446,7 @@ __global__ void __launch_bounds__(LANES, 1) mtg_tp_fused_kernel(MtgSolveArgs a)
     }
     if (k == NSIG) return;  // beyond the evaluations that passed the prior
     const int64_t ev = a.list[(int64_t)k * a.cstride + r];
-    mtg_fill_tables(&tab, threadIdx.x, LANES);
+    mtg_load_tables<(NC0 > 0)>(&tab, static_cast<const MtgMathTables *>(a.tables), threadIdx.x, LANES);
     __syncthreads();
     mtg_tp_dispatch<NR0, NC0, 0, NSIG, LANES>(k, a, ev, &tab, sh, red);
 }
@@ -1457,3 +1457,4 @@ static void mtg_launch_tp_fused(const MtgSolveArgs &a, int64_t nevals, hipStream
     if (nevals <= 0) return;
     hipLaunchKernelGGL((mtg_tp_fused_kernel<NR0, NC0, NSIG, LANES>), dim3((unsigned)nevals), dim3(LANES), 0, stream, a);
 }
+

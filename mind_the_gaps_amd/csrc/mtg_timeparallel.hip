@@ -22,6 +22,16 @@ struct MtgTpWideSel<NR, NC, false> { static constexpr mtg_solve_launcher fn = nu
 static const mtg_solve_launcher mtg_tp_wide_table[6][3] = {MTG_TPW_ROW(0), MTG_TPW_ROW(1), MTG_TPW_ROW(2),
                                                            MTG_TPW_ROW(3), MTG_TPW_ROW(4), MTG_TPW_ROW(5)};
 
+// the context's resident copy of the tables: mtg_fill_tables itself, once (same entries as a workgroup's own fill)
+__global__ void __launch_bounds__(256) mtg_tables_kernel(MtgMathTables *tab) { mtg_fill_tables(tab, (int)threadIdx.x, 256); }
+
+void mtg_launch_tables(void *tables, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mtg_tables_kernel, dim3(1), dim3(256), 0, stream, static_cast<MtgMathTables *>(tables));
+}
+
+size_t mtg_tables_bytes() { return sizeof(MtgMathTables); }
+
 mtg_solve_launcher mtg_find_tp_wide_solver(int nr, int nc)
 {
     if (nr < 0 || nc < 0 || nr > 5 || nc > 2) return nullptr;

@@ -1,5 +1,8 @@
-"""Iterations per second of small chains with the sampler's state in LDS (default) and without (MTG_SAMPLER_LDS=0), in
-two processes, and that the two chains are the same to the last bit.   python scripts/small_chain_ab.py"""
+"""Iterations per second of small chains with a measurement knob of the library on (default) and off, in two processes, and
+that the two chains are the same to the last bit.  The knobs exist in MTG_MEASURE builds only (scripts/build_variant.sh
+measure): MTG_SAMPLER_LDS (the sampler's state in LDS), MTG_GLOBAL_TABLES (exp2 / cis tables copied from the context's
+resident copy instead of computed per workgroup).
+    scripts/build_variant.sh measure && python scripts/small_chain_ab.py [KNOB]      (default MTG_SAMPLER_LDS)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -30,14 +33,19 @@ for name, N, W, kernel in cases:
     digest = hashlib.sha256(np.ascontiguousarray(m.sampler.get_chain()).tobytes()).hexdigest()[:16]
     print("%%-32s %%8.0f iterations/s  chain %%s" %% (name, 4000 / dt, digest), flush=True)
 ''' % ROOT
+KNOB = sys.argv[1] if len(sys.argv) > 1 else "MTG_SAMPLER_LDS"
+VARIANT = os.path.join(ROOT, "mind_the_gaps_amd", "libmtg_var_measure.so")
+if not os.path.exists(VARIANT):
+    raise SystemExit("build the measurement variant first: scripts/build_variant.sh measure")
 out = {}
 for mode in ("1", "0"):
-    env = dict(os.environ, MTG_SAMPLER_LDS=mode)
+    env = dict(os.environ, MTG_HIP_LIB=VARIANT)
+    env[KNOB] = mode
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     out[mode] = [l for l in r.stdout.splitlines() if "iterations/s" in l]
     if r.returncode:
         print(r.stderr[-2000:])
-print("%-32s %14s %14s   same chain" % ("", "state in LDS", "MTG_SAMPLER_LDS=0"))
+print("%-32s %14s %14s   same chain" % ("", KNOB + "=1", KNOB + "=0"))
 for a, b in zip(out["1"], out["0"]):
     name = a[:32]
     ra, rb = float(a[32:].split()[0]), float(b[32:].split()[0])

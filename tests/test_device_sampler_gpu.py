@@ -371,3 +371,4 @@ def test_resume_across_a_speculative_run_at_256_walkers(engine, tmp_path):
     assert np.array_equal(second.get_chain(), whole.get_chain()) and np.array_equal(second.get_log_prob(), whole.get_log_prob())
     for key in ("coords", "log_prob", "naccept", "best_log_prob", "best_coords"):
         assert np.array_equal(state[key], whole.state[key]), key
+
