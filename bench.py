@@ -29,7 +29,9 @@ The JSON line also carries
   roofline        : algorithmic bytes (24 N + 8 P + 12 per evaluation) / mean
                     duration of the dominant kernel (named by the library: mtg_last_solver), HIP events
                     on the launch stream; "bound": "hbm" (the contract's nominal roofline), "binds": "fp64_valu" (FP64
-                    vector issue, what really limits it; the sub-object of that name prices it against the FP64 peak);
+                    vector issue, what really limits it; the sub-object of that name prices it against the FP64 peak;
+                    fp64_issue_frac_at_clock = the sweep's issue floor at the sclk the card holds under this load /
+                    its measured time: the fraction that says how much headroom the kernel has);
   walker_sharded  : (N > 1) configs[2] and configs[4] -- ONE light curve, 256 / 512 walkers -- through
                     GPModelling.derive_posteriors(device_sampler=True, shard_walkers=True): every
                     half-step's proposals split over the ranks, ncclAllGather pair on the launch stream
@@ -80,7 +82,26 @@ FLOP_PER_SAMPLE = {"mtg_solve_kernel<1,2,1>": 2 * 91 + 53, "mtg_solve_kernel<1,1
                    # every structure of the model in one launch (csrc/mtg_kernels_multi.hip): the bench's rows are all
                    # under-damped, i.e. the same sweep loop as the one-structure kernel's
                    "mtg_solve_kernel_multi<1,2,2,1>": 2 * 91 + 53, "mtg_solve_kernel_multi<1,1,2,0>": 2 * 47 + 28}
+# vector instructions per sample and lane in the serial sweep's loop (scripts/loop_stats.py NR NC NB0: VALU of the two-step
+# trip / 2): what the kernel's time really scales with -- every FP64 opcode takes a SIMD's issue slot for 4 cycles per wave64
+VALU_PER_SAMPLE = {"mtg_solve_kernel<1,2,1>": 166, "mtg_solve_kernel_multi<1,2,2,1>": 166, "mtg_solve_kernel<1,1,0>": 91,
+                   "mtg_solve_kernel_multi<1,1,2,0>": 91, "mtg_solve_kernel<0,3,0>": 215, "mtg_solve_kernel<2,1,0>": 125}
+SIMDS = 1024            # 256 CUs x 4
 MAX_RANKS_PER_GPU = 6   # the GPU box's process guard
+
+
+def fp64_issue(kernel, waves, n_samples, kernel_s, clock):
+    """The sweep against its own issue floor AT THE CLOCK THE CARD HOLDS: waves x samples x VALU instructions x 4 cycles,
+    spread over every SIMD, at the sclk rocm-smi reports under this load -- the bound that matters (the nominal HBM
+    roofline of the contract counts bytes that 256 walkers share through L2; the FP64 peak is quoted at 2.4 GHz, which
+    the card does not hold at its power limit).  None when the kernel's loop has not been counted or no clock was read."""
+    valu = VALU_PER_SAMPLE.get(kernel)
+    if not valu or not clock or not clock.get("sclk_mhz"):
+        return None
+    floor_s = waves * n_samples * valu * 4.0 / (SIMDS * clock["sclk_mhz"] * 1e6)
+    return {"frac": floor_s / kernel_s, "floor_ms": floor_s * 1e3, "valu_per_sample_and_lane": valu, "cycles_per_instruction": 4,
+            "simds": SIMDS, "sclk_mhz": clock["sclk_mhz"],
+            "what": "waves x N x VALU instructions of the sweep loop x 4 cycles / (1024 SIMDs x sclk under load) / kernel time"}
 
 
 def parse():
@@ -679,6 +700,10 @@ def main():
             },
         }
         line.update(extras)
+        issue = fp64_issue(kernel_name, n_ok_roof / 64.0, N, solve_s, extras.get("clock_under_load"))
+        if issue:     # first-class: THE fraction that says how much headroom the kernel has (nominal frac above: 0.57 != 43 % left)
+            line["roofline"]["fp64_issue_frac_at_clock"] = issue["frac"]
+            line["roofline"]["fp64_issue"] = issue
         if "hbm_copy_measured" in extras:    # the algorithmic rate against the copy bandwidth measured on this box
             copy = extras["hbm_copy_measured"]["GB_per_s"]
             line["roofline"]["hbm_copy_measured"] = copy
@@ -693,6 +718,12 @@ def main():
         # of its timed batch, which it checks on the way), after the timed region; the other ranks wait at the barrier
         if rank == 0:
             extras["cpu_baseline"] = cpu_baseline(t, y, dy, kinds, theta, y_mean, args.cpu_seconds, bounds, out, status)
+        dist.barrier()
+    if world > 1 and not args.no_extras:
+        # the clock rank 0's card holds under this load (rocm-smi's first card = rank 0's), for roofline.fp64_issue_frac_at_clock
+        clock = clock_under_load(lambda: [sweep() for _ in range(40)], lambda: torch.cuda.synchronize(dev)) if rank == 0 else None
+        if clock:
+            extras["clock_under_load"] = dict(clock, what=clock["what"] + " (rank 0's card)")
         dist.barrier()
     if grouped:
         extras["rccl_ranks"] = {"torch_distributed_world": dist.get_world_size(), "backend": dist.get_backend()}
@@ -859,6 +890,7 @@ def main():
             "kernel": k0, "kernel_ms": s0 * 1e3,
             "algorithmic_hbm_frac": n_ok0 * (24 * N + 8 * 5 + 12) / s0 / 1e9 / HBM_PEAK_GBS,
             "fp64_valu_frac": None if flop0 is None else n_ok0 * N * flop0 / s0 / 1e12 / FP64_PEAK_TFLOPS,
+            "fp64_issue_frac_at_clock": (fp64_issue(k0, n_ok0 / 64.0, N, s0, clock) or {}).get("frac"),
             "both_models_evals_per_s": 2 * B / (dt0 + elapsed / args.steps)}
         eng.set_model(kinds, full, free, bounds)
         # (d) a model whose six ranks are all arithmetic -- three SHO terms, NR = 0, NC = 3 -- beside the headline, whose
@@ -889,7 +921,8 @@ def main():
             "model": "3 x SHO, all under-damped (NR = 0, NC = 3: J = 6 of arithmetic, P = 9)", "evals_per_step": B,
             "ms_per_step": dt6 * 1e3, "evals_per_s": B / dt6, "kernel": k6, "kernel_ms": s6 * 1e3, "evals_ok": n_ok6,
             "algorithmic_hbm_frac": n_ok6 * (24 * N + 8 * 9 + 12) / s6 / 1e9 / HBM_PEAK_GBS,
-            "fp64_valu_frac": None if flop6 is None else n_ok6 * N * flop6 / s6 / 1e12 / FP64_PEAK_TFLOPS}
+            "fp64_valu_frac": None if flop6 is None else n_ok6 * N * flop6 / s6 / 1e12 / FP64_PEAK_TFLOPS,
+            "fp64_issue_frac_at_clock": (fp64_issue(k6, n_ok6 / 64.0, N, s6, clock) or {}).get("frac")}
         eng.set_model(kinds, full, free, bounds)
         # (e) the mid-batch regime: one GPU's half-step at 8 GPUs -- 250 light curves x 128 proposals = 32 000 rows -- on
         # the one-lane sweep and on its two-wave pipeline (csrc/mtg_kernels_pipe.hip), both models, device time

@@ -67,12 +67,14 @@ def rows():
                             m["workflow_config3_sharded"]["p_value"],
                             "identical" if inv.get("identical_to_one_rank_alone") else "NOT RUN"))
     head = ("`%s`: **%s evals/s** at N = 10⁴, J = 6 (%.2f ms per 512 000 rows; kernel `%s` %.2f ms); roofline %.3f of "
-            "algorithmic HBM bytes, %.3f of the FP64 vector peak; HBM traffic %s; worst difference to the CPU port %.1e over %d "
+            "algorithmic HBM bytes, %.3f of the FP64 vector peak%s; HBM traffic %s; worst difference to the CPU port %.1e over %d "
             "rows of the timed batch; CPU port %s evals/s on %d cores, %s on one; null model (J = 3) %s; three SHO terms (six "
             "ranks of arithmetic) %s, FP64 fraction %.2f; 32 000 rows: %.2f / %.2f ms on the pipeline against %.2f / %.2f "
             "one-lane; PCIe-inclusive %s"
             % (src, sci(d["value"]), d["ms_per_step"], roof["kernel"], roof["kernel_ms"], roof["frac"],
                roof["fp64_valu"]["frac"],
+               (", **%.2f of its FP64 issue floor at the clock held** (%d MHz)" % (roof["fp64_issue_frac_at_clock"], roof["fp64_issue"]["sclk_mhz"]))
+               if roof.get("fp64_issue_frac_at_clock") else "",
                "%.2f GB per launch = %.1f %% of algorithmic" % (roof["traffic"] / 1e9, 100 * roof["traffic"] / (roof["evals_per_launch"] * roof["bytes_per_eval"]))
                if roof.get("traffic") else "see `profiles/r04_pmc_traffic.json`",
                cpu["max_rel_diff_vs_gpu"], cpu["compared"], sci(cpu["value"]), cpu["cores"], sci(cpu["single_thread"]),
