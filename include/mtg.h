@@ -351,6 +351,9 @@ MTG_API int mtg_ensemble_get(mtg_ctx *ctx, double *coords, double *lnp, double *
  * its dimension, as emcee does.
  */
 MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int P, const double *chain, double *rho);
+/* Pairs of hipFFT plans mtg_chain_autocorr has built on this context so far (it keeps the four most recently used
+ * shapes): a call on a cached shape leaves the count alone. */
+MTG_API int64_t mtg_chain_autocorr_plans_built(const mtg_ctx *ctx);
 /* hipFFT's one-time start-up (~1.4 s: the first plan of a process) paid now, on the context's device; safe to call
  * from a helper thread (HIP's current device is per thread: the call selects ctx's; NULL = the thread's current). */
 MTG_API int mtg_fft_warmup(mtg_ctx *ctx);

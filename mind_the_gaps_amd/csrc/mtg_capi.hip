@@ -125,6 +125,7 @@ struct mtg_ctx {
     struct AcfPlans { hipfftHandle fwd = 0, inv = 0; bool have = false; int64_t n2 = 0, S = 0, P = 0; uint64_t used = 0; } acf_slots[4];
     uint64_t acf_clock = 0;
     DevBuf acf_chain, acf_x, acf_f, acf_g, acf_r, acf_ss, acf_tmp;
+    int64_t acf_plans_built = 0;   // plan pairs made so far (mtg_chain_autocorr_plans_built: a cached shape must not add to it)
 
     // mtg_simulate_tk95: the inverse transform's plan (made once per length: a Bluestein plan for the 1 087 853 points
     // of BASELINE configs[3] takes 0.9 s to build, as long as the 2000 simulations it then runs) and its buffers.
@@ -1768,6 +1769,7 @@ MTG_API int mtg_chain_autocorr(mtg_ctx *ctx, int64_t n_t, int64_t E, int W, int 
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftPlanMany (inverse) failed");
         }
         slot->have = true; slot->n2 = n2; slot->S = S; slot->P = EP;
+        ctx->acf_plans_built += 1;
         if (hipfftSetStream(slot->fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(slot->inv, s) != HIPFFT_SUCCESS)
             return fail(ctx, MTG_E_HIP, "mtg_chain_autocorr: hipfftSetStream failed");
     }
@@ -2298,6 +2300,8 @@ MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on)
     ctx->czt.pairs_on = on != 0;
     return MTG_OK;
 }
+
+MTG_API int64_t mtg_chain_autocorr_plans_built(const mtg_ctx *ctx) { return ctx ? ctx->acf_plans_built : -1; }
 
 MTG_API int mtg_set_simulate_transform(mtg_ctx *ctx, int mode)
 {

@@ -32,7 +32,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_pair_patience",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_pair_patience", "mtg_chain_autocorr_plans_built",
     "mtg_set_simulate_draws",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
@@ -254,6 +254,8 @@ def load_library():
     lib.mtg_set_simulate_transform.argtypes = [c_vp, c_int]
     lib.mtg_set_pair_patience.restype = c_int
     lib.mtg_set_pair_patience.argtypes = [c_vp, c_int]
+    lib.mtg_chain_autocorr_plans_built.restype = c_i64
+    lib.mtg_chain_autocorr_plans_built.argtypes = [c_vp]
     lib.mtg_set_simulate_draws.restype = c_int
     lib.mtg_set_simulate_draws.argtypes = [c_vp, c_i64, c_i64, _dp, ctypes.POINTER(c_i64)]
     lib.mtg_pair_contexts.restype = c_int
@@ -785,6 +787,11 @@ class Engine:
             raise ValueError("normals must be [S][2][nk] and starts [S]")
         self._check(self._lib.mtg_set_simulate_draws(self._ctx, normals.shape[0], normals.shape[2], _ptr(normals),
                                                      starts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+
+    @property
+    def acf_plans_built(self):
+        """hipFFT plan pairs chain_autocorr has built on this context (a cached shape does not add to it)"""
+        return int(self._lib.mtg_chain_autocorr_plans_built(self._ctx))
 
     def set_pipeline(self, mode):
         """0: never the two-wave pipeline of the serial sweep, 1: whenever compiled, 2 (default): for batches of ~8e3 to
