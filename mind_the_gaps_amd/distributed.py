@@ -263,6 +263,8 @@ def _try_rccl(engine, group, rank, world):
     import os
     import threading
     import torch.distributed as dist
+    if os.environ.get("MTG_SHARD_FAIL_RCCL") in ("all", str(rank)):      # rehearsal of the fall-back (bench.py, tests)
+        return "injected failure (MTG_SHARD_FAIL_RCCL)"
     try:
         objs = [engine.rccl_unique_id() if rank == 0 else None]
     except Exception as exc:        # (rank 0 could not even load librccl: the others must not wait for an id)
