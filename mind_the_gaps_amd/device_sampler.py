@@ -24,7 +24,6 @@ __all__ = ["DeviceEnsembleSampler"]
 # chain point -- not a measured time) has reached what the plan would cost, or a single check would -- at most
 # twice the cost of always choosing right.  The choice is a pure function of the sequence of chain shapes checked
 # so far: the same run takes the same path (and gets the same tau, to the last bit) every time, on every rank.
-ACF_PLAN_SLOTS = 4                   # plan pairs mtg_chain_autocorr keeps (csrc/mtg_capi.hip: acf_slots)
 HOST_SECONDS_PER_POINT = 1.1e-8      # measured: 7 ms for 6.4e5 points, 30 ms for 2e6, 220 ms for 2e7
 
 
@@ -57,8 +56,7 @@ def _autocorr_time_where_it_is_cheapest(engine, chain, kwargs):
             rho = engine.chain_autocorr(chain)   # (waits for the hipFFT warm-up thread if it is still at it)
         except Exception:        # (too large for the device's workspace, hipFFT refusing a plan ...): the host can always
             rho = None
-        else:
-            state["planned"] = [k for k in state["planned"] if k != key][-(ACF_PLAN_SLOTS - 1):] + [key]
+        else:                    # (engine.chain_autocorr keeps state["planned"] itself)
             return taus(rho)
     state["rented"][key] = rented + estimate
     return taus(None)

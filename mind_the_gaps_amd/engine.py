@@ -13,6 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ACF_PLAN_SLOTS = 4     # plan pairs mtg_chain_autocorr keeps (csrc/mtg_capi.hip: acf_slots)
 # MTG_HIP_LIB selects an alternative build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("MTG_HIP_LIB") or os.path.join(_HERE, "libmtg_hip.so")
 
@@ -640,6 +641,11 @@ class Engine:
         self._join_fft_warmup()   # (two threads inside hipFFT's first plan is not something to find out about)
         self._check(self._lib.mtg_chain_autocorr(self._ctx, n_t, E, W, P, _ptr(chain), _ptr(rho)))
         self.fft_ready = True
+        # the shapes the library now holds plans for, least recently used first: kept HERE, beside the call that changes
+        # them, so that callers of this method and of device_sampler's placement rule see the same list
+        key = (1 << max(n_t - 1, 1).bit_length(),) + tuple(chain.shape[1:])
+        state = self.__dict__.setdefault("_acf_state", {"planned": [], "rented": {}})
+        state["planned"] = [k for k in state["planned"] if k != key][-(ACF_PLAN_SLOTS - 1):] + [key]
         return rho if chain.ndim == 4 else rho[:, 0]
 
     def ensemble_restore(self, iteration, log_prob=None, naccept=None, best_log_prob=None, best_coords=None):
