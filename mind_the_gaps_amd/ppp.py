@@ -16,7 +16,6 @@ the burn-in / thinning arithmetic are those of `sampler.EnsembleSampler` and
 `GPModelling.derive_posteriors` (gpmodelling.py:197-286), applied per light curve;
 random numbers come from one vectorised generator instead of L private streams.
 """
-import os
 import warnings
 
 import numpy as np
@@ -444,7 +443,9 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     half-step leaves the GPU room -- at most ~40 000 rows, e.g. one GPU's 250 light curves x 128 proposals at 8 GPUs,
     where the two models' launches interleave and their tails and sampler kernels overlap (7.1 ms per iteration of both
     against 8.1 ms one after the other); with the GPU full (2000 x 128 rows) there is nothing to gain (26.30 s against
-    26.36 s) and the refits run one after the other.
+    26.36 s) and the refits run one after the other.  For measurements: "unpaired" = side by side without
+    ``mtg_pair_contexts`` (each context launches its own pipelined half-steps), "slices" = each context on its own half of
+    the compute units (``mtg_create_on_slice``); same results all ways.
 
     ``observed_side_by_side`` (default on; even walker counts): the observed light curve's two chains of step 1 from two
     host threads, each model on a device context and a random generator of its own -- two single-light-curve chains
@@ -596,11 +597,13 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
             sim_seed = (sim_seed + 7919 * block) % (2 ** 31 - 1)   # independent noise on every block (the two ranks
             fit_seeds = [f + 7919 * block for f in fit_seeds]       # of a block under the model split draw the same)
     out, fits, best, failure, pair_stats = None, [None, None], [np.empty(0), np.empty(0)], None, None
-    # each model on a context of its own (MTG_PPP_CU_SLICES=1: and on its own half of the compute units,
-    # mtg_create_on_slice -- measured no faster: 7.24 against 7.14 ms per iteration)
-    side_by_side = len(models) == 2 and (concurrent_refits is True or
+    # each model on a context of its own ("slices": and on its own half of the compute units, mtg_create_on_slice --
+    # measured no faster: 7.24 against 7.14 ms per iteration)
+    if concurrent_refits not in (True, False, "auto", "unpaired", "slices"):
+        raise ValueError("concurrent_refits must be True, False, 'auto', 'unpaired' or 'slices'")
+    side_by_side = len(models) == 2 and (concurrent_refits in (True, "unpaired", "slices") or
                                          (concurrent_refits == "auto" and (hi - lo) * (sw // 2) <= 40000 and hi - lo > 1))
-    if side_by_side and os.environ.get("MTG_PPP_CU_SLICES") == "1":
+    if side_by_side and concurrent_refits == "slices":
         side_by_side = "slices"
     if hi > lo:
         try:
@@ -621,7 +624,7 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
             # (mtg_pair_contexts: eight waves per compute unit on one table set, two per SIMD -- a pipelined sweep alone
             # takes the whole compute unit, so unpaired launches alternate rather than share SIMDs).  Paired between the
             # starting fits and the chains: the fits' batches come at each model's own pace and must not wait for each other.
-            paired = side_by_side is True and os.environ.get("MTG_PPP_PAIR", "1") != "0"
+            paired = side_by_side is True and concurrent_refits != "unpaired"
 
             def meet_then_pair():
                 first = meet.wait() == 0

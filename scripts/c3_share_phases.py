@@ -14,8 +14,8 @@ def traced(*a, **k):
           {x: round(v, 3) for x, v in r.seconds.items()}, t0 - T0, time.perf_counter() - T0), flush=True)
     return r
 ppp.derive_posteriors_batch = traced
-for mode, pair in ((False, "1"), ("auto", "0"), ("auto", "1"), ("auto", "0"), ("auto", "1")):
-    os.environ["MTG_PPP_PAIR"] = pair       # side by side: the two contexts' pipelined half-steps in one launch (1) or not (0)
+for mode, pair in ((False, "1"), ("unpaired", "0"), ("auto", "1"), ("unpaired", "0"), ("auto", "1")):
+    # side by side: the two contexts' pipelined half-steps in one launch ("auto": paired) or not ("unpaired")
     T0 = time.perf_counter()
     d = probe.run(250, concurrent_refits=mode)
     print("mode %r pair %s: whole %.3f s, refits %.3f s, p = %.10f, T_sim checksum %.12f" % (
