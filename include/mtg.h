@@ -226,6 +226,22 @@ MTG_API int mtg_set_stream_base(mtg_ctx *ctx, int64_t first_index);
  * blocks over several GPUs needs to be the set of one call, bit for bit (with mtg_set_stream_base); default 1.
  */
 MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on);
+/*
+ * The flux PDF of the light curves mtg_simulate_tk95 makes (Simulator(..., pdf=...), simulator.py:149-150): kind 0 (default)
+ * Gaussian = the TK95 series as it is; 1 lognormal, 2 uniform = every cut segment goes through the amplitude / rank
+ * adjustment of Emmanoulopoulos et al. 2013 as the reference runs it (simulator.py:65-140 E13Simulator; the distributions
+ * of stats.py:116-146 with the simulator's mean and the segment's standard deviation), at most max_iter + 1 iterations
+ * (the reference's `max_iter`), ON THE DEVICE (csrc/mtg_e13.hip: batched hipFFT transforms, one segmented radix sort per
+ * iteration) before the segment is averaged into the epochs; everything after it -- noise, make_resident -- as for the
+ * Gaussian case, so a posterior-predictive run with a non-Gaussian PDF never leaves the GPU.  The white series is drawn
+ * from the context's Philox stream (keyed by seed and global series index), or taken from the caller for the NEXT call:
+ * mtg_set_simulate_pdf_draws(ctx, S, n, draws[S][n]) with n = seg_len (tests hold the device against the host with it).
+ * mtg_simulate_pdf_report: segments of the last call that used all their iterations without converging (the reference
+ * warns), and the largest iteration count.
+ */
+MTG_API int mtg_set_simulate_pdf(mtg_ctx *ctx, int kind, int max_iter);
+MTG_API int mtg_set_simulate_pdf_draws(mtg_ctx *ctx, int64_t S, int64_t n, const double *draws);
+MTG_API int mtg_simulate_pdf_report(const mtg_ctx *ctx, int64_t *not_converged, int *iterations);
 /* Which transform mtg_simulate_tk95 takes: 0 (default) = by grid length (hipFFT's plan for lengths of radices 2-13, the
  * hand-written chirp-z otherwise), 1 = always hipFFT's plan, 2 = always chirp-z (tests compare the two). */
 MTG_API int mtg_set_simulate_transform(mtg_ctx *ctx, int mode);

@@ -148,6 +148,19 @@ struct mtg_ctx {
     // draws handed in by the caller for the NEXT mtg_simulate_tk95 (mtg_set_simulate_draws): standard normals
     // [S][2][nfft / 2 + 1] and segment starts [S]
     struct { DevBuf normals, starts; std::vector<int64_t> starts_host; int64_t S = 0, nk = 0; } given;
+    // the flux PDF of the simulated light curves (mtg_set_simulate_pdf): 0 Gaussian = TK95 as it is, 1 lognormal, 2 uniform
+    // = the E13 adjustment of every cut segment on the device (mtg_e13.hip); its buffers, plans and last run's report
+    struct E13 {
+        int kind = 0, max_iter = 400;
+        DevBuf seg, x, fresh, values, adj, keys, amp, spec, idx, order, off, flags, stdv, temp;
+        hipfftHandle fwd = 0, inv = 0;
+        bool have = false;
+        int64_t n = 0, batch = 0;
+        int64_t not_converged = 0;
+        int iterations = 0;
+        DevBuf given;            // caller's draws for the next simulation (mtg_set_simulate_pdf_draws): [S][n]
+        int64_t given_S = 0, given_n = 0;
+    } e13;
 
     // side streams: the structures (signatures) of a small batch run next to each other
     hipStream_t side[MTG_MAX_J / 2] = {};
@@ -865,7 +878,12 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
             if (sp.have) (void)hipfftDestroy(sp.h);
         for (auto &sp : ctx->czt.plans)
             if (sp.have) (void)hipfftDestroy(sp.h);
+        if (ctx->e13.have) { (void)hipfftDestroy(ctx->e13.fwd); (void)hipfftDestroy(ctx->e13.inv); ctx->e13.have = false; }
     }
+    for (DevBuf *b : {&ctx->e13.seg, &ctx->e13.x, &ctx->e13.fresh, &ctx->e13.values, &ctx->e13.adj, &ctx->e13.keys, &ctx->e13.amp,
+                      &ctx->e13.spec, &ctx->e13.idx, &ctx->e13.order, &ctx->e13.off, &ctx->e13.flags, &ctx->e13.stdv, &ctx->e13.temp,
+                      &ctx->e13.given})
+        b->release();
     ctx->sim_spec.release();
     ctx->sim_series.release();
     for (DevBuf *b : {&ctx->acf_chain, &ctx->acf_x, &ctx->acf_f, &ctx->acf_g, &ctx->acf_r, &ctx->acf_ss, &ctx->acf_tmp}) b->release();
@@ -1905,6 +1923,85 @@ MTG_API int mtg_simulate_plan(mtg_ctx *ctx, int64_t nfft)
     return sim_plan_get(ctx, nfft, INT64_MAX, nullptr);   // the bulk plan
 }
 
+// The E13 flux-PDF adjustment (mtg_e13.hip) of the `sc` segments e13.seg[sc][n] of one simulation chunk (global indices
+// s0 .. s0 + sc): on return e13.x[sc][n] holds the adjusted series.  `chunk` = the batch of the plans (sc <= chunk).
+static int e13_adjust_chunk(mtg_ctx *ctx, int64_t sc, int64_t chunk, int64_t s0, int64_t n, double mean_rate, uint64_t seed, hipStream_t s)
+{
+    mtg_ctx::E13 &E = ctx->e13;
+    const int64_t nk = n / 2 + 1;
+    if (chunk * n >= ((int64_t)1 << 31)) return fail(ctx, MTG_E_ARG, "E13 adjustment: %lld segments of %lld samples per chunk exceed 2^31 elements", (long long)chunk, (long long)n);
+    const size_t temp_bytes = mtg_e13_sort_temp_bytes(chunk, n);
+    HIP_TRY(ctx, E.x.reserve((size_t)chunk * n * 8));
+    HIP_TRY(ctx, E.fresh.reserve((size_t)chunk * n * 8));
+    HIP_TRY(ctx, E.values.reserve((size_t)chunk * n * 8));
+    HIP_TRY(ctx, E.adj.reserve((size_t)chunk * n * 8));
+    HIP_TRY(ctx, E.keys.reserve((size_t)chunk * n * 8));
+    HIP_TRY(ctx, E.amp.reserve((size_t)chunk * nk * 8));
+    HIP_TRY(ctx, E.spec.reserve((size_t)chunk * nk * 16));
+    HIP_TRY(ctx, E.idx.reserve((size_t)chunk * n * 4));
+    HIP_TRY(ctx, E.order.reserve((size_t)chunk * n * 4));
+    HIP_TRY(ctx, E.off.reserve((size_t)(chunk + 1) * 4));
+    HIP_TRY(ctx, E.flags.reserve((size_t)(2 * chunk + 1) * 4));
+    HIP_TRY(ctx, E.stdv.reserve((size_t)chunk * 8));
+    HIP_TRY(ctx, E.temp.reserve(temp_bytes > 0 ? temp_bytes : 16));
+    if (!E.have || E.n != n || E.batch != chunk) {
+        std::lock_guard<std::mutex> plans(g_fft_plan_mu);
+        if (E.have) { (void)hipfftDestroy(E.fwd); (void)hipfftDestroy(E.inv); E.have = false; }
+        int len = (int)n;
+        if (hipfftPlanMany(&E.fwd, 1, &len, nullptr, 1, (int)n, nullptr, 1, (int)nk, HIPFFT_D2Z, (int)chunk) != HIPFFT_SUCCESS)
+            return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftPlanMany (forward, n = %lld, batch = %lld) failed", (long long)n, (long long)chunk);
+        if (hipfftPlanMany(&E.inv, 1, &len, nullptr, 1, (int)nk, nullptr, 1, (int)n, HIPFFT_Z2D, (int)chunk) != HIPFFT_SUCCESS) {
+            (void)hipfftDestroy(E.fwd);
+            return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftPlanMany (inverse, n = %lld, batch = %lld) failed", (long long)n, (long long)chunk);
+        }
+        E.have = true; E.n = n; E.batch = chunk;
+    }
+    if (hipfftSetStream(E.fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(E.inv, s) != HIPFFT_SUCCESS)
+        return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftSetStream failed");
+    double *seg = E.seg.as<double>(), *x = E.x.as<double>(), *fresh = E.fresh.as<double>(), *values = E.values.as<double>();
+    double *adj = E.adj.as<double>(), *keys = E.keys.as<double>(), *amp = E.amp.as<double>();
+    double2 *spec = E.spec.as<double2>();
+    int32_t *idx = E.idx.as<int32_t>(), *order = E.order.as<int32_t>();
+    uint32_t *off = E.off.as<uint32_t>();
+    int32_t *done = E.flags.as<int32_t>(), *notconv = done + chunk, *running = done + 2 * chunk;
+    HIP_TRY(ctx, hipMemsetAsync(E.flags.p, 0, (size_t)(2 * chunk + 1) * 4, s));
+    if (sc < chunk) {   // the plans transform `chunk` slots: the unused ones hold zeros
+        HIP_TRY(ctx, hipMemsetAsync(seg + sc * n, 0, (size_t)(chunk - sc) * n * 8, s));
+        HIP_TRY(ctx, hipMemsetAsync(x + sc * n, 0, (size_t)(chunk - sc) * n * 8, s));
+    }
+    mtg_launch_e13_iota(sc, n, idx, off, done, s);
+    // the target: amplitudes of the TK95 segment; the white series and its sorted values
+    if (hipfftExecD2Z(E.fwd, seg, (hipfftDoubleComplex *)spec) != HIPFFT_SUCCESS) return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftExecD2Z failed");
+    mtg_launch_e13_abs(sc * nk, spec, amp, s);
+    if (E.given_S) {
+        const int64_t gS = E.given_S, gn = E.given_n;
+        if (gn != n || s0 + sc > gS) return fail(ctx, MTG_E_ARG, "E13 adjustment: the draws of mtg_set_simulate_pdf_draws are [%lld][%lld], this call needs series %lld..%lld of %lld samples",
+                                                  (long long)gS, (long long)gn, (long long)s0, (long long)(s0 + sc), (long long)n);
+        HIP_TRY(ctx, hipMemcpyAsync(x, E.given.as<double>() + s0 * n, (size_t)sc * n * 8, hipMemcpyDeviceToDevice, s));
+    } else {
+        mtg_launch_e13_std(sc, n, seg, E.stdv.as<double>(), s);
+        mtg_launch_e13_draw(sc, s0, ctx->stream_base, n, E.kind, mean_rate, E.stdv.as<double>(), seed, x, s);
+    }
+    HIP_TRY(ctx, mtg_launch_e13_sort_values(sc, n, x, values, off, E.temp.p, temp_bytes, s));
+    HIP_TRY(ctx, hipGetLastError());
+    int it = 0;
+    int32_t still = (int32_t)sc;
+    for (; it <= E.max_iter && still > 0; ++it) {
+        if (hipfftExecD2Z(E.fwd, x, (hipfftDoubleComplex *)spec) != HIPFFT_SUCCESS) return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftExecD2Z failed");
+        mtg_launch_e13_phase(sc * nk, amp, spec, s);
+        if (hipfftExecZ2D(E.inv, (hipfftDoubleComplex *)spec, adj) != HIPFFT_SUCCESS) return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftExecZ2D failed");
+        HIP_TRY(ctx, mtg_launch_e13_rank(sc, n, adj, keys, idx, order, off, E.temp.p, temp_bytes, s));
+        HIP_TRY(ctx, hipMemsetAsync(running, 0, 4, s));
+        mtg_launch_e13_step(sc, n, order, values, x, fresh, done, notconv, running, s);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(&still, running, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    if (it > E.iterations) E.iterations = it;
+    E.not_converged += still;
+    return MTG_OK;
+}
+
 MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, const double *psd_table, int64_t psd_rows,
                               uint64_t seed, int64_t nfft, double sim_dt, double mean_rate, int64_t seg_len,
                               const int32_t *win_lo, const int32_t *win_hi, int noise_kind, double sigma_noise,
@@ -1942,6 +2039,14 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     const int64_t *given_starts = given_S ? ctx->given.starts.as<int64_t>() : nullptr;
     rc = use_device(ctx);
     if (rc) return rc;
+    struct E13Given {   // the E13 draws handed in for this call are consumed whatever happens next; the report starts afresh
+        mtg_ctx *c;
+        ~E13Given() { c->e13.given_S = 0; }
+    } e13_given{ctx};
+    ctx->e13.iterations = 0;
+    ctx->e13.not_converged = 0;
+    if (ctx->e13.kind != 0 && !(mean_rate > 0.0) && ctx->e13.kind == 1)
+        return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: a lognormal flux PDF needs a positive mean rate");
     mtg_trace::Range range("mtg:simulate_tk95");
     MtgModel m0;
     memset(&m0, 0, sizeof m0);
@@ -2041,6 +2146,30 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
                 cleanup();
                 return fail(ctx, MTG_E_HIP, "mtg_simulate_tk95: hipfftExecZ2D failed");  // (the resident set is untouched so far)
             }
+        }
+        if (ctx->e13.kind != 0) {
+            // A non-Gaussian flux PDF (simulator.py:65-140): the cut segments as rates on the fine grid, adjusted on the
+            // device (mtg_e13.hip), then averaged into the epochs from the ADJUSTED series (start 0, no rescaling).
+            // (the segment kernel indexes its output by the GLOBAL series number: the chunk's buffer is handed over shifted)
+            what = "E13 adjustment";
+            e = ctx->e13.seg.reserve((size_t)chunk * seg_len * 8);
+            if (e != hipSuccess) break;
+            mtg_launch_tk95_segment(sc, s0, ctx->stream_base, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
+                                    given_starts, ctx->e13.seg.as<double>() - s0 * seg_len, s);
+            if (segments)   // (what the caller asked for: the segments as the reference hands them to its adjustment)
+                e = hipMemcpyAsync(d_seg.as<double>() + s0 * seg_len, ctx->e13.seg.p, (size_t)sc * seg_len * 8, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) break;
+            const int arc = e13_adjust_chunk(ctx, sc, chunk, s0, seg_len, mean_rate, seed, s);
+            if (arc) {
+                cleanup();
+                if (make_resident) { ctx->N = 0; ctx->L = 0; }
+                return arc;
+            }
+            mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, seg_len, seg_len, sim_dt, sim_dt, 0.0, ctx->e13.x.as<double>(),
+                                    d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
+                                    0, seed, nullptr, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+            e = hipGetLastError();
+            continue;
         }
         mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
                                 d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
@@ -2302,6 +2431,37 @@ MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on)
 }
 
 MTG_API int64_t mtg_chain_autocorr_plans_built(const mtg_ctx *ctx) { return ctx ? ctx->acf_plans_built : -1; }
+
+MTG_API int mtg_set_simulate_pdf(mtg_ctx *ctx, int kind, int max_iter)
+{
+    if (!ctx || kind < 0 || kind > 2 || max_iter < 0) return MTG_E_ARG;
+    ctx->e13.kind = kind;
+    ctx->e13.max_iter = max_iter;
+    return MTG_OK;
+}
+
+MTG_API int mtg_set_simulate_pdf_draws(mtg_ctx *ctx, int64_t S, int64_t n, const double *draws)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (S == 0 || !draws) { ctx->e13.given_S = 0; return MTG_OK; }
+    if (S < 0 || n < 2) return fail(ctx, MTG_E_ARG, "mtg_set_simulate_pdf_draws: bad shape");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    CTX_STREAM(ctx, s);
+    HIP_TRY(ctx, ctx->e13.given.reserve((size_t)S * n * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->e13.given.p, draws, (size_t)S * n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->e13.given_S = S; ctx->e13.given_n = n;
+    return MTG_OK;
+}
+
+MTG_API int mtg_simulate_pdf_report(const mtg_ctx *ctx, int64_t *not_converged, int *iterations)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (not_converged) *not_converged = ctx->e13.not_converged;
+    if (iterations) *iterations = ctx->e13.iterations;
+    return MTG_OK;
+}
 
 MTG_API int mtg_set_simulate_transform(mtg_ctx *ctx, int mode)
 {

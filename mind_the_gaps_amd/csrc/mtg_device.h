@@ -218,6 +218,20 @@ void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft
 void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, uint64_t seed, const int64_t *given_start, double *out,
                              hipStream_t);
+// the E13 flux-PDF adjustment of the cut segments (mtg_e13.hip)
+size_t mtg_e13_sort_temp_bytes(int64_t S, int64_t n);
+void mtg_launch_e13_std(int64_t S, int64_t n, const double *seg, double *stdv, hipStream_t);
+void mtg_launch_e13_draw(int64_t S, int64_t s0, int64_t sbase, int64_t n, int kind, double mean, const double *stdv, uint64_t seed,
+                         double *x, hipStream_t);
+void mtg_launch_e13_iota(int64_t S, int64_t n, int32_t *idx, uint32_t *offsets, int32_t *done, hipStream_t);
+void mtg_launch_e13_abs(int64_t total, const double2 *spec, double *amp, hipStream_t);
+void mtg_launch_e13_phase(int64_t total, const double *amp, double2 *spec, hipStream_t);
+hipError_t mtg_launch_e13_sort_values(int64_t S, int64_t n, const double *x, double *values, const uint32_t *offsets, void *temp,
+                                      size_t temp_bytes, hipStream_t);
+hipError_t mtg_launch_e13_rank(int64_t S, int64_t n, const double *adjusted, double *keys_out, const int32_t *idx, int32_t *order,
+                               const uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t);
+void mtg_launch_e13_step(int64_t S, int64_t n, const int32_t *order, const double *values, double *x, double *fresh, int32_t *done,
+                         int32_t *notconv, int32_t *running, hipStream_t);
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,

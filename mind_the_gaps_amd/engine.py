@@ -33,7 +33,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_pair_patience", "mtg_chain_autocorr_plans_built",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_simulate_pdf", "mtg_set_simulate_pdf_draws", "mtg_simulate_pdf_report", "mtg_set_pair_patience", "mtg_chain_autocorr_plans_built",
     "mtg_set_simulate_draws",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
@@ -255,6 +255,12 @@ def load_library():
     lib.mtg_set_simulate_transform.argtypes = [c_vp, c_int]
     lib.mtg_set_pair_patience.restype = c_int
     lib.mtg_set_pair_patience.argtypes = [c_vp, c_int]
+    lib.mtg_set_simulate_pdf.restype = c_int
+    lib.mtg_set_simulate_pdf.argtypes = [c_vp, c_int, c_int]
+    lib.mtg_set_simulate_pdf_draws.restype = c_int
+    lib.mtg_set_simulate_pdf_draws.argtypes = [c_vp, c_i64, c_i64, _dp]
+    lib.mtg_simulate_pdf_report.restype = c_int
+    lib.mtg_simulate_pdf_report.argtypes = [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]
     lib.mtg_chain_autocorr_plans_built.restype = c_i64
     lib.mtg_chain_autocorr_plans_built.argtypes = [c_vp]
     lib.mtg_set_simulate_draws.restype = c_int
@@ -780,6 +786,28 @@ class Engine:
         (include/mtg.h: mtg_set_simulate_transform)."""
         mode = {"auto": 0, "library": 1, "chirp-z": 2}.get(mode, mode)
         self._check(self._lib.mtg_set_simulate_transform(self._ctx, int(mode)))
+
+    def set_simulate_pdf(self, kind, max_iter=400):
+        """The flux PDF of simulate_tk95's light curves: "gaussian" / 0 (TK95 as it is), "lognormal" / 1, "uniform" / 2 (the
+        E13 adjustment of every cut segment, on the device; include/mtg.h: mtg_set_simulate_pdf)."""
+        kind = {"gaussian": 0, "lognormal": 1, "uniform": 2}.get(str(kind).lower(), kind)
+        self._check(self._lib.mtg_set_simulate_pdf(self._ctx, int(kind), int(max_iter)))
+
+    def set_simulate_pdf_draws(self, draws):
+        """The white series the NEXT simulate_tk95's E13 adjustment starts from, [S][seg_len] (None: clear)."""
+        if draws is None:
+            self._check(self._lib.mtg_set_simulate_pdf_draws(self._ctx, 0, 0, None))
+            return
+        draws = _f64(draws)
+        if draws.ndim != 2:
+            raise ValueError("draws must be [S][seg_len]")
+        self._check(self._lib.mtg_set_simulate_pdf_draws(self._ctx, draws.shape[0], draws.shape[1], _ptr(draws)))
+
+    def simulate_pdf_report(self):
+        """{"not_converged": segments of the last simulate_tk95 that used up their iterations, "iterations": the most any took}"""
+        a, b = ctypes.c_int64(0), ctypes.c_int(0)
+        self._check(self._lib.mtg_simulate_pdf_report(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return {"not_converged": int(a.value), "iterations": int(b.value)}
 
     def set_simulate_draws(self, normals, starts):
         """Hand the next simulate_tk95 its random numbers (include/mtg.h: mtg_set_simulate_draws): ``normals`` [S][2][nk]

@@ -422,7 +422,7 @@ def derive_posteriors_batch(times, Y, DY, kernel, walkers=12, max_steps=500, fit
 def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, max_steps=500, sim_walkers=None,
                    sim_steps=500, sigma_noise=None, extension_factor=2, seed=None, device=0, progress=False,
                    sharded=False, group=None, concurrent_refits="auto", split="auto", reproducible=None,
-                   observed_side_by_side=True, observed_split=True):
+                   observed_side_by_side=True, observed_split=True, pdf="Gaussian", max_iter=400):
     """The whole posterior-predictive likelihood-ratio test of the reference's workflow
     (README.md:38-41, docs/notebooks/tutorial_ppp.ipynb) on the GPU:
 
@@ -511,9 +511,11 @@ def protassov_test(lightcurve, null_kernel, alt_kernel, nsims=100, walkers=12, m
     import time
     clock = [time.perf_counter()]
     # the simulator's transform plan is built beside the observed chains (its grid depends on the sampling alone)
-    sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, "Gaussian",
+    # (``pdf``: the flux PDF of the simulated light curves, simulator.py:149-150 -- "Lognormal" / "Uniform" go through the
+    # E13 adjustment on the device, csrc/mtg_e13.hip, ``max_iter`` iterations at most: the loop still never leaves the GPU)
+    sim = Simulator(null_kernel, lightcurve.times, lightcurve.exposures, lightcurve.mean, pdf,
                     lightcurve.bkg_rate, lightcurve.bkg_rate_err, sigma_noise=sigma_noise,
-                    extension_factor=extension_factor, random_state=0, device=device)
+                    extension_factor=extension_factor, max_iter=max_iter, random_state=0, device=device)
     sim.warm_up()
     shard = None
     if sharded:

@@ -18,10 +18,12 @@ What drives the spectrum:
   ``PowerLaw1D``): evaluated once on the host at the grid's angular frequencies and uploaded as a
   table.
 
-Host-side parts (the reference's behaviour, at the reference's kind of speed -- they are not on the
-Protassov hot path): the Emmanoulopoulos et al. (2013) amplitude adjustment for
-``pdf="lognormal" | "uniform"`` (simulator.py:65-131), applied to the fine-grid segments the device
-returns, and the Kraft et al. (1991) treatment of low-count epochs with background
+The Emmanoulopoulos et al. (2013) amplitude / rank adjustment for ``pdf="lognormal" | "uniform"``
+(simulator.py:65-131) runs on the device too (round 6: ``mtg_set_simulate_pdf``, csrc/mtg_e13.hip -- batched
+transforms and one segmented sort per iteration over all the segments of a chunk), between the cut and the
+down-sampling, so a posterior-predictive run with a non-Gaussian flux PDF stays on the GPU; ``adjust_on="host"``
+keeps the numpy implementation (``_adjust_pdf``: the reference's loop, at the reference's kind of speed), which the
+tests hold the device against.  Host-side: the Kraft et al. (1991) treatment of low-count epochs with background
 (noise_models.py:81-150).
 
 Random numbers.  Default (``stream="philox"``): counter-based streams on the device, keyed by (seed, series index) -- what
@@ -103,11 +105,14 @@ class Simulator:
 
     def __init__(self, psd_model, times, exposures, mean, pdf="gaussian", bkg_rate=None, bkg_rate_err=None,
                  sigma_noise=None, aliasing_factor=2, extension_factor=10, epsilon=1.001, max_iter=400,
-                 random_state=None, device=0, kraft_counts=15, stream="philox", transform="auto"):
+                 random_state=None, device=0, kraft_counts=15, stream="philox", transform="auto", adjust_on="device"):
         if stream not in ("philox", "numpy"):
             raise ValueError("stream must be 'philox' or 'numpy'")
         if transform not in ("auto", "library", "chirp-z"):
             raise ValueError("transform must be 'auto', 'library' or 'chirp-z'")
+        if adjust_on not in ("device", "host"):
+            raise ValueError("adjust_on must be 'device' or 'host'")
+        self.adjust_on = adjust_on        # where a non-Gaussian flux PDF is imposed on the segments (module docstring)
         # which inverse transform the device takes (mtg_set_simulate_transform): "auto" picks by grid length; the other
         # two exist so that tests can hold one against the other
         self.transform = transform
@@ -246,7 +251,7 @@ class Simulator:
 
     # -- simulation --------------------------------------------------------------------
     def simulate(self, thetas=None, noise=True, want_clean=False, make_resident=False, seed=None, nsims=None,
-                 index_base=None, pair_series=None):
+                 index_base=None, pair_series=None, pdf_draws=None):
         """Light curves for S kernel parameter vectors ``thetas`` [S][P] (default: the kernel's
         current one; with a callable PSD: ``nsims`` realisations of it) in one device call ->
         dict(rates[S][N], dy[S][N], means[S], clean[S][N] | None).  ``index_base``: global index of the first of
@@ -258,17 +263,25 @@ class Simulator:
         2p + 1 of a call into one complex transform, which ties a series' last bits to its neighbour's.  Default: on
         without an ``index_base``, off with one (a block's series must not depend on where the block was cut).  A caller
         that cuts at EVEN global indices -- so that every series keeps the partner it has in the whole set -- may turn it
-        on and keep both the speed and the invariance (``ppp.protassov_test`` does)."""
+        on and keep both the speed and the invariance (``ppp.protassov_test`` does).
+        ``pdf_draws`` [S][seg_len] (tests): the white series a non-Gaussian flux PDF's adjustment starts from, instead of
+        the device's own draws (``adjust_on="device"``) or this simulator's generator (``"host"``)."""
         if self.stream == "numpy":
             raise NotImplementedError("stream='numpy' serves generate_lightcurve / simulate_regularly_sampled / add_noise (one light "
                                       "curve per call, as the reference); the batched simulate() draws on the device")
         eng, model = self._engine()
         if seed is None:
             seed = int(self.random_state.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self.random_state.randint(0, 2 ** 31 - 1))
-        host_side = self.pdf.lower() != "gaussian" or (noise and self._noise_kind == 3)
+        shaped = self.pdf.lower() != "gaussian"
+        on_device = shaped and self.adjust_on == "device"
+        host_adjust = shaped and not on_device
+        host_side = host_adjust or (noise and self._noise_kind == 3)          # (Kraft noise is made on the host)
         kw = dict(noise_kind=0 if (host_side or not noise) else self._noise_kind, sigma_noise=self.sigma_noise,
                   exposures=self._exposures, want_clean=want_clean and not host_side,
-                  make_resident=make_resident and not host_side, want_segments=self.pdf.lower() != "gaussian")
+                  make_resident=make_resident and not host_side, want_segments=host_adjust)
+        eng.set_simulate_pdf(self.pdf if on_device else 0, self.max_iter)
+        if pdf_draws is not None and on_device:
+            eng.set_simulate_pdf_draws(pdf_draws)
         eng.set_stream_base(index_base or 0)
         if pair_series and index_base is not None and int(index_base) % 2:
             raise ValueError("pair_series with an index_base needs an even index_base (series 2p and 2p + 1 share a transform)")
@@ -286,16 +299,24 @@ class Simulator:
         finally:
             eng.set_stream_base(0)
             eng.set_simulate_pairs(True)
+            eng.set_simulate_pdf(0)
+            eng.set_simulate_pdf_draws(None)
             if make_resident:
                 eng.bound_to = None    # whatever happened, the engine no longer holds this evaluator's dummy data
+        if on_device:
+            self.last_adjustment = eng.simulate_pdf_report()
+            if self.last_adjustment["not_converged"]:      # the reference's warning (simulator.py:125-126), once per call
+                warnings.warn("Lightcurve did not converge after %d iterations, PDF might be inaccurate. Try increase the "
+                              "maximum number of iterations (%d of %d)" % (self.max_iter, self.last_adjustment["not_converged"], len(out["rates"])))
         if host_side:
-            out = self._finish_on_host(out, noise, want_clean, None if index_base is None else (int(seed), int(index_base)))
+            out = self._finish_on_host(out, noise, want_clean, None if index_base is None else (int(seed), int(index_base)),
+                                       adjust=host_adjust, draws=pdf_draws)
             if make_resident:          # the refits want the set resident: upload what the host produced
                 eng.set_lightcurves(self._times, out["rates"], out["dy"] + 1e-12, y_offset=out["means"])
         out.pop("segments", None)
         return out
 
-    def _finish_on_host(self, out, noise, want_clean, keyed=None):
+    def _finish_on_host(self, out, noise, want_clean, keyed=None, adjust=True, draws=None):
         """Flux-PDF adjustment of the fine-grid segments, down-sampling and noise for the cases the device
         kernels do not cover (module docstring).  ``keyed`` = (seed, index_base): series l draws from
         RandomState([seed, index_base + l]) -- its values then do not depend on which block it was simulated in."""
@@ -311,10 +332,10 @@ class Simulator:
         rates, dy = [out["rates"][l] for l in range(S)], []
         try:
             # (the adjustment of every series comes before the noise of any, as it always did on the shared generator)
-            if self.pdf.lower() != "gaussian":
+            if adjust:
                 for l in range(S):
                     own_stream(l, 0)
-                    rates[l] = self.downsample(self.segment_times, self._adjust_pdf(out["segments"][l]))
+                    rates[l] = self.downsample(self.segment_times, self._adjust_pdf(out["segments"][l], None if draws is None else draws[l]))
             clean = np.array(rates) if want_clean else None
             if noise:
                 for l in range(S):
@@ -327,7 +348,7 @@ class Simulator:
         dy = np.array(dy) if noise else np.zeros_like(rates)
         return dict(rates=rates, dy=dy, means=rates.mean(axis=1), clean=clean)
 
-    def _adjust_pdf(self, segment):
+    def _adjust_pdf(self, segment, draws=None):
         """Emmanoulopoulos et al. (2013), as simulator.py:65-140 runs it: a white series drawn from the
         wanted flux PDF (mean = the simulator's, standard deviation = the segment's) repeatedly takes the
         Fourier amplitudes of the TK95 segment and gives its values back by rank, until it stops changing."""
@@ -341,8 +362,12 @@ class Simulator:
             pdf = stats.uniform(loc=mean - half, scale=2.0 * half)
         n = len(segment)
         amplitudes = np.abs(np.fft.rfft(segment))
-        values = np.sort(pdf.rvs(size=n, random_state=self.random_state))[::-1]     # the flux values, descending
-        current = self.random_state.permutation(values)
+        if draws is None:
+            values = np.sort(pdf.rvs(size=n, random_state=self.random_state))[::-1]     # the flux values, descending
+            current = self.random_state.permutation(values)
+        else:                                   # the caller's white series (tests: the same one on the device)
+            current = np.asarray(draws, dtype=np.float64).copy()
+            values = np.sort(current)[::-1]
         for iteration in range(self.max_iter + 1):
             spectrum = amplitudes * np.exp(1j * np.angle(np.fft.rfft(current)))
             adjusted = np.fft.irfft(spectrum, n=n)

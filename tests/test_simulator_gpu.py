@@ -331,3 +331,59 @@ def test_numpy_stream_against_the_restated_reference_pipeline():
         simulator.simulate(nsims=2)
     with pytest.raises(NotImplementedError):
         Simulator(kernel.get_psd, times, exposures, 50.0, pdf="Lognormal", stream="numpy")
+
+
+# ---- a non-Gaussian flux PDF: the E13 adjustment on the device (csrc/mtg_e13.hip) against the host loop -----------------
+def _shaped_simulators(pdf, n_epochs=90, seed=5, **kw):
+    rng = np.random.default_rng(seed)
+    times = synth.make_times(n_epochs, rng)
+    kernel = DampedRandomWalk(np.log(16.0), np.log(2 * np.pi / 12), bounds=[(-10, 50), (-10, 10)])
+    make = lambda where: Simulator(kernel, times, 0.04, 25.0, pdf, sigma_noise=0.5, extension_factor=2, random_state=4,
+                                   adjust_on=where, **kw)
+    return make("device"), make("host")
+
+
+@pytest.mark.parametrize("pdf", ["Lognormal", "Uniform"])
+def test_flux_pdf_adjustment_on_the_device_is_the_host_loop(pdf):
+    """simulator.py:65-140 on the device: started from the SAME white series (pdf_draws), the batched device loop -- hipFFT
+    transforms, a segmented rank sort per iteration, np.allclose's test per segment -- ends on the light curves the numpy
+    loop ends on, series by series (each stops at its own iteration: a converged segment is frozen)."""
+    dev, host = _shaped_simulators(pdf)
+    S = 5
+    model = dev._engine()[1]
+    thetas = np.tile(model.full[model.free_index][None, :], (S, 1)) + 0.05 * np.arange(S)[:, None]
+    rng = np.random.default_rng(8)
+    draws = 25.0 * np.exp(0.15 * rng.standard_normal((S, dev.seg_len))) if pdf == "Lognormal" \
+        else rng.uniform(18.0, 32.0, size=(S, dev.seg_len))
+    a = dev.simulate(thetas, seed=4242, noise=False, pdf_draws=draws)
+    b = host.simulate(thetas, seed=4242, noise=False, pdf_draws=draws)
+    assert dev.last_adjustment["not_converged"] == 0 and 2 <= dev.last_adjustment["iterations"] <= dev.max_iter
+    assert a["rates"].shape == b["rates"].shape == (S, len(dev._times))
+    assert np.max(np.abs(a["rates"] - b["rates"])) <= 1e-12 * np.max(np.abs(b["rates"]))
+    # ... and it did something: the Gaussian (TK95) light curves of the same seed are others
+    plain = Simulator(dev._kernel, dev._times, 0.04, 25.0, "Gaussian", sigma_noise=0.5, extension_factor=2, random_state=4)
+    assert np.max(np.abs(plain.simulate(thetas, seed=4242, noise=False)["rates"] - a["rates"])) > 0.1
+
+
+def test_flux_pdf_on_the_device_draws_blocks_and_noise():
+    """The device's own draws: lognormal light curves are positive with the simulator's mean; a set simulated in blocks
+    (index_base) is the set of one call; noise and make_resident follow the adjusted series without a host round trip; a
+    run that is not given enough iterations says so as the reference does."""
+    dev, _ = _shaped_simulators("Lognormal", n_epochs=70)
+    S = 6
+    model = dev._engine()[1]
+    thetas = np.tile(model.full[model.free_index][None, :], (S, 1))
+    whole = dev.simulate(thetas, seed=77, noise=False, index_base=0)
+    assert np.all(whole["rates"] > 0) and abs(whole["rates"].mean() / 25.0 - 1.0) < 0.1
+    assert dev.last_adjustment["not_converged"] == 0
+    parts = [dev.simulate(thetas[lo:hi], seed=77, noise=False, index_base=lo)["rates"] for lo, hi in ((0, 2), (2, 3), (3, 6))]
+    assert np.array_equal(np.vstack(parts), whole["rates"])
+    noisy = dev.simulate(thetas, seed=77, noise=True, want_clean=True, make_resident=True, index_base=0)
+    assert np.array_equal(noisy["clean"], whole["rates"]) and np.all(noisy["dy"] == 0.5)
+    assert 0.3 < np.std(noisy["rates"] - noisy["clean"]) < 0.7
+    eng = dev._engine()[0]
+    assert eng.L == S                    # the adjusted, noisy set is the resident set
+    short, _ = _shaped_simulators("Lognormal", n_epochs=70, max_iter=1)
+    with pytest.warns(UserWarning, match="did not converge after 1 iterations"):
+        short.simulate(thetas[:2], seed=77, noise=False)
+    assert short.last_adjustment == {"not_converged": 2, "iterations": 2}
