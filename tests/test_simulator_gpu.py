@@ -378,11 +378,11 @@ def test_flux_pdf_on_the_device_draws_blocks_and_noise():
     assert dev.last_adjustment["not_converged"] == 0
     parts = [dev.simulate(thetas[lo:hi], seed=77, noise=False, index_base=lo)["rates"] for lo, hi in ((0, 2), (2, 3), (3, 6))]
     assert np.array_equal(np.vstack(parts), whole["rates"])
+    eng = dev._engine()[0]
     noisy = dev.simulate(thetas, seed=77, noise=True, want_clean=True, make_resident=True, index_base=0)
+    assert eng.L == S                    # the adjusted, noisy set is the resident set (no host round trip)
     assert np.array_equal(noisy["clean"], whole["rates"]) and np.all(noisy["dy"] == 0.5)
     assert 0.3 < np.std(noisy["rates"] - noisy["clean"]) < 0.7
-    eng = dev._engine()[0]
-    assert eng.L == S                    # the adjusted, noisy set is the resident set
     short, _ = _shaped_simulators("Lognormal", n_epochs=70, max_iter=1)
     with pytest.warns(UserWarning, match="did not converge after 1 iterations"):
         short.simulate(thetas[:2], seed=77, noise=False)
