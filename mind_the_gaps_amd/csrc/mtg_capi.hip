@@ -152,7 +152,7 @@ struct mtg_ctx {
     // = the E13 adjustment of every cut segment on the device (mtg_e13.hip); its buffers, plans and last run's report
     struct E13 {
         int kind = 0, max_iter = 400;
-        DevBuf seg, x, fresh, values, adj, keys, amp, spec, idx, order, off, flags, stdv, temp;
+        DevBuf seg, x, fresh, values, adj, keys, amp, spec, idx, order, order_tmp, segment, segment_out, flags, stdv, temp;
         hipfftHandle fwd = 0, inv = 0;
         bool have = false;
         int64_t n = 0, batch = 0;
@@ -881,7 +881,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
         if (ctx->e13.have) { (void)hipfftDestroy(ctx->e13.fwd); (void)hipfftDestroy(ctx->e13.inv); ctx->e13.have = false; }
     }
     for (DevBuf *b : {&ctx->e13.seg, &ctx->e13.x, &ctx->e13.fresh, &ctx->e13.values, &ctx->e13.adj, &ctx->e13.keys, &ctx->e13.amp,
-                      &ctx->e13.spec, &ctx->e13.idx, &ctx->e13.order, &ctx->e13.off, &ctx->e13.flags, &ctx->e13.stdv, &ctx->e13.temp,
+                      &ctx->e13.spec, &ctx->e13.idx, &ctx->e13.order, &ctx->e13.order_tmp, &ctx->e13.segment, &ctx->e13.segment_out, &ctx->e13.flags, &ctx->e13.stdv, &ctx->e13.temp,
                       &ctx->e13.given})
         b->release();
     ctx->sim_spec.release();
@@ -1940,7 +1940,9 @@ static int e13_adjust_chunk(mtg_ctx *ctx, int64_t sc, int64_t chunk, int64_t s0,
     HIP_TRY(ctx, E.spec.reserve((size_t)chunk * nk * 16));
     HIP_TRY(ctx, E.idx.reserve((size_t)chunk * n * 4));
     HIP_TRY(ctx, E.order.reserve((size_t)chunk * n * 4));
-    HIP_TRY(ctx, E.off.reserve((size_t)(chunk + 1) * 4));
+    HIP_TRY(ctx, E.order_tmp.reserve((size_t)chunk * n * 4));
+    HIP_TRY(ctx, E.segment.reserve((size_t)chunk * n * 4));
+    HIP_TRY(ctx, E.segment_out.reserve((size_t)chunk * n * 4));
     HIP_TRY(ctx, E.flags.reserve((size_t)(2 * chunk + 1) * 4));
     HIP_TRY(ctx, E.stdv.reserve((size_t)chunk * 8));
     HIP_TRY(ctx, E.temp.reserve(temp_bytes > 0 ? temp_bytes : 16));
@@ -1961,15 +1963,15 @@ static int e13_adjust_chunk(mtg_ctx *ctx, int64_t sc, int64_t chunk, int64_t s0,
     double *seg = E.seg.as<double>(), *x = E.x.as<double>(), *fresh = E.fresh.as<double>(), *values = E.values.as<double>();
     double *adj = E.adj.as<double>(), *keys = E.keys.as<double>(), *amp = E.amp.as<double>();
     double2 *spec = E.spec.as<double2>();
-    int32_t *idx = E.idx.as<int32_t>(), *order = E.order.as<int32_t>();
-    uint32_t *off = E.off.as<uint32_t>();
+    int32_t *idx = E.idx.as<int32_t>(), *order = E.order.as<int32_t>(), *order_tmp = E.order_tmp.as<int32_t>();
+    uint32_t *segment = E.segment.as<uint32_t>(), *segment_out = E.segment_out.as<uint32_t>();
     int32_t *done = E.flags.as<int32_t>(), *notconv = done + chunk, *running = done + 2 * chunk;
     HIP_TRY(ctx, hipMemsetAsync(E.flags.p, 0, (size_t)(2 * chunk + 1) * 4, s));
     if (sc < chunk) {   // the plans transform `chunk` slots: the unused ones hold zeros
         HIP_TRY(ctx, hipMemsetAsync(seg + sc * n, 0, (size_t)(chunk - sc) * n * 8, s));
         HIP_TRY(ctx, hipMemsetAsync(x + sc * n, 0, (size_t)(chunk - sc) * n * 8, s));
     }
-    mtg_launch_e13_iota(sc, n, idx, off, done, s);
+    mtg_launch_e13_iota(sc, n, idx, done, s);
     // the target: amplitudes of the TK95 segment; the white series and its sorted values
     if (hipfftExecD2Z(E.fwd, seg, (hipfftDoubleComplex *)spec) != HIPFFT_SUCCESS) return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftExecD2Z failed");
     mtg_launch_e13_abs(sc * nk, spec, amp, s);
@@ -1982,7 +1984,7 @@ static int e13_adjust_chunk(mtg_ctx *ctx, int64_t sc, int64_t chunk, int64_t s0,
         mtg_launch_e13_std(sc, n, seg, E.stdv.as<double>(), s);
         mtg_launch_e13_draw(sc, s0, ctx->stream_base, n, E.kind, mean_rate, E.stdv.as<double>(), seed, x, s);
     }
-    HIP_TRY(ctx, mtg_launch_e13_sort_values(sc, n, x, values, off, E.temp.p, temp_bytes, s));
+    HIP_TRY(ctx, mtg_launch_e13_sort_values(sc, n, x, keys, idx, order_tmp, segment, segment_out, order, values, E.temp.p, temp_bytes, s));
     HIP_TRY(ctx, hipGetLastError());
     int it = 0;
     int32_t still = (int32_t)sc;
@@ -1990,7 +1992,7 @@ static int e13_adjust_chunk(mtg_ctx *ctx, int64_t sc, int64_t chunk, int64_t s0,
         if (hipfftExecD2Z(E.fwd, x, (hipfftDoubleComplex *)spec) != HIPFFT_SUCCESS) return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftExecD2Z failed");
         mtg_launch_e13_phase(sc * nk, amp, spec, s);
         if (hipfftExecZ2D(E.inv, (hipfftDoubleComplex *)spec, adj) != HIPFFT_SUCCESS) return fail(ctx, MTG_E_HIP, "E13 adjustment: hipfftExecZ2D failed");
-        HIP_TRY(ctx, mtg_launch_e13_rank(sc, n, adj, keys, idx, order, off, E.temp.p, temp_bytes, s));
+        HIP_TRY(ctx, mtg_launch_e13_rank(sc, n, adj, keys, idx, order_tmp, segment, segment_out, order, E.temp.p, temp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(running, 0, 4, s));
         mtg_launch_e13_step(sc, n, order, values, x, fresh, done, notconv, running, s);
         HIP_TRY(ctx, hipGetLastError());

@@ -223,13 +223,14 @@ size_t mtg_e13_sort_temp_bytes(int64_t S, int64_t n);
 void mtg_launch_e13_std(int64_t S, int64_t n, const double *seg, double *stdv, hipStream_t);
 void mtg_launch_e13_draw(int64_t S, int64_t s0, int64_t sbase, int64_t n, int kind, double mean, const double *stdv, uint64_t seed,
                          double *x, hipStream_t);
-void mtg_launch_e13_iota(int64_t S, int64_t n, int32_t *idx, uint32_t *offsets, int32_t *done, hipStream_t);
+void mtg_launch_e13_iota(int64_t S, int64_t n, int32_t *idx, int32_t *done, hipStream_t);
 void mtg_launch_e13_abs(int64_t total, const double2 *spec, double *amp, hipStream_t);
 void mtg_launch_e13_phase(int64_t total, const double *amp, double2 *spec, hipStream_t);
-hipError_t mtg_launch_e13_sort_values(int64_t S, int64_t n, const double *x, double *values, const uint32_t *offsets, void *temp,
+hipError_t mtg_launch_e13_sort_values(int64_t S, int64_t n, const double *x, double *keys_out, const int32_t *idx, int32_t *order_tmp,
+                                      uint32_t *segment, uint32_t *segment_out, int32_t *order, double *values, void *temp,
                                       size_t temp_bytes, hipStream_t);
-hipError_t mtg_launch_e13_rank(int64_t S, int64_t n, const double *adjusted, double *keys_out, const int32_t *idx, int32_t *order,
-                               const uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t);
+hipError_t mtg_launch_e13_rank(int64_t S, int64_t n, const double *keys, double *keys_out, const int32_t *idx, int32_t *order_tmp,
+                               uint32_t *segment, uint32_t *segment_out, int32_t *order, void *temp, size_t temp_bytes, hipStream_t);
 void mtg_launch_e13_step(int64_t S, int64_t n, const int32_t *order, const double *values, double *x, double *fresh, int32_t *done,
                          int32_t *notconv, int32_t *running, hipStream_t);
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,

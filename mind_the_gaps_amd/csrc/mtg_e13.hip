@@ -10,15 +10,18 @@
 //            new[argsort(-adjusted)] = values;  allclose(new, x) -> done;  x = new
 // (only the ranks of `adjusted` are used, so the reference's amplitude normalisation 1 / (n // 2 + 1) and hipFFT's
 // unnormalised inverse drop out).  Everything is batched over the `S` segments of one simulation chunk: the transforms
-// are two batched hipFFT plans (plumbing, made by the caller), the rank matching one segmented radix sort of
-// (adjusted, index) pairs per iteration (rocPRIM, as in mtg_sort.hip), the rest the kernels below.  A segment that has
+// are two batched hipFFT plans (plumbing, made by the caller), the rank matching two device-wide radix sorts per iteration
+// (rocPRIM, as in mtg_sort.hip): all S n (adjusted, global index) pairs by value, descending, then -- stably -- by segment
+// number, which leaves every segment's indices in the order of its ranks.  (rocPRIM's SEGMENTED sort gives a long segment
+// to ONE workgroup: 16 segments of 870 000 samples -- the chunk of BASELINE configs[3] -- kept 16 compute units busy, 2.3 ms
+// per segment and iteration; the two device-wide sorts use the whole GPU.)  The rest are the kernels below.  A segment that has
 // converged is frozen (its slots of the batched transforms keep running and are not looked at), so every segment's result
 // is the one a loop of its own would give.  Random numbers: Philox4x32-10 keyed by (seed, global series index, element).
 #include "mtg_device.h"
 
 #include <math.h>
 
-#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -74,7 +77,7 @@ __global__ void __launch_bounds__(1024) mtg_e13_std_kernel(int64_t n, const doub
 // x[s][j] ~ the wanted PDF with the simulator's mean and segment s's standard deviation:
 //   kind 1 lognormal (stats.py:116-129): s_ln = sqrt(ln(var / mean^2 + 1)), scale = mean^2 / sqrt(var + mean^2), x = scale exp(s_ln z)
 //   kind 2 uniform   (stats.py:132-146): mean -+ sqrt(3) std
-// also: idx[s][j] = j (the payload of the rank sort), done[s] = 0
+
 __global__ void __launch_bounds__(256) mtg_e13_draw_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t n, int kind, double mean,
                                                           const double *stdv, uint32_t seed_lo, uint32_t seed_hi, double *x)
 {
@@ -102,12 +105,25 @@ __global__ void __launch_bounds__(256) mtg_e13_draw_kernel(int64_t S, int64_t s0
     if (2 * p + 1 < n) x[s * n + 2 * p + 1] = v1;
 }
 
-__global__ void __launch_bounds__(256) mtg_e13_iota_kernel(int64_t S, int64_t n, int32_t *idx, uint32_t *offsets, int32_t *done)
+__global__ void __launch_bounds__(256) mtg_e13_iota_kernel(int64_t S, int64_t n, int32_t *idx, int32_t *done)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < S * n) idx[i] = (int32_t)(i % n);
-    if (i <= S) offsets[i] = (uint32_t)(i * n);
+    if (i < S * n) idx[i] = (int32_t)i;          // GLOBAL index s n + j: the payload of the rank sort
     if (done && i < S) done[i] = 0;
+}
+
+// segment number of every entry of a list of global indices
+__global__ void __launch_bounds__(256) mtg_e13_segment_kernel(int64_t total, int64_t n, const int32_t *idx, uint32_t *segment)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) segment[i] = (uint32_t)(idx[i] / n);
+}
+
+// values[r] = x[order[r]]
+__global__ void __launch_bounds__(256) mtg_e13_gather_kernel(int64_t total, const int32_t *order, const double *x, double *values)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) values[i] = x[order[i]];
 }
 
 // amp[s][k] = |spec[s][k]|
@@ -135,9 +151,9 @@ __global__ void __launch_bounds__(256) mtg_e13_scatter_kernel(int64_t S, int64_t
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * n) return;
-    const int64_t s = i / n;
+    const int64_t s = i / n;      // (the list is grouped by segment, n entries each: position r of segment s is i = s n + r)
     if (done[s]) return;
-    const int64_t at = s * n + order[i];
+    const int64_t at = order[i];
     const double v = values[i], c = x[at];
     fresh[at] = v;
     if (!(fabs(v - c) <= 1.0e-8 + 1.0e-4 * fabs(c))) notconv[s] = 1;
@@ -174,9 +190,9 @@ size_t mtg_e13_sort_temp_bytes(int64_t S, int64_t n)
     size_t a = 0, b = 0;
     double *k = nullptr;
     int32_t *v = nullptr;
-    uint32_t *o = nullptr;
-    (void)rocprim::segmented_radix_sort_keys_desc(nullptr, a, k, k, (unsigned)(S * n), (unsigned)S, o, o + 1, 0u, 64u, (hipStream_t) nullptr);
-    (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, b, k, k, v, v, (unsigned)(S * n), (unsigned)S, o, o + 1, 0u, 64u, (hipStream_t) nullptr);
+    uint32_t *g = nullptr;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, a, k, k, v, v, (size_t)(S * n), 0u, 64u, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, b, g, g, v, v, (size_t)(S * n), 0u, 32u, (hipStream_t) nullptr);
     return a > b ? a : b;
 }
 
@@ -192,9 +208,9 @@ void mtg_launch_e13_draw(int64_t S, int64_t s0, int64_t sbase, int64_t n, int ki
                        (uint32_t)seed, (uint32_t)(seed >> 32), x);
 }
 
-void mtg_launch_e13_iota(int64_t S, int64_t n, int32_t *idx, uint32_t *offsets, int32_t *done, hipStream_t st)
+void mtg_launch_e13_iota(int64_t S, int64_t n, int32_t *idx, int32_t *done, hipStream_t st)
 {
-    hipLaunchKernelGGL(mtg_e13_iota_kernel, dim3(blocks(S * n + 1)), dim3(256), 0, st, S, n, idx, offsets, done);
+    hipLaunchKernelGGL(mtg_e13_iota_kernel, dim3(blocks(S * n)), dim3(256), 0, st, S, n, idx, done);
 }
 
 void mtg_launch_e13_abs(int64_t total, const double2 *spec, double *amp, hipStream_t st)
@@ -207,19 +223,29 @@ void mtg_launch_e13_phase(int64_t total, const double *amp, double2 *spec, hipSt
     hipLaunchKernelGGL(mtg_e13_phase_kernel, dim3(blocks(total)), dim3(256), 0, st, total, amp, spec);
 }
 
-// values[s][:] = x[s][:] sorted, descending
-hipError_t mtg_launch_e13_sort_values(int64_t S, int64_t n, const double *x, double *values, const uint32_t *offsets, void *temp,
-                                      size_t temp_bytes, hipStream_t st)
+// order[s n + r] = GLOBAL index of the r-th largest entry of keys[s][:]: all pairs by value, descending, then stably by
+// segment (bits of S).  keys_out, order_tmp, segment, segment_out: S n entries of scratch each.
+hipError_t mtg_launch_e13_rank(int64_t S, int64_t n, const double *keys, double *keys_out, const int32_t *idx, int32_t *order_tmp,
+                               uint32_t *segment, uint32_t *segment_out, int32_t *order, void *temp, size_t temp_bytes, hipStream_t st)
 {
-    return rocprim::segmented_radix_sort_keys_desc(temp, temp_bytes, x, values, (unsigned)(S * n), (unsigned)S, offsets, offsets + 1, 0u, 64u, st);
+    const int64_t total = S * n;
+    hipError_t e = rocprim::radix_sort_pairs_desc(temp, temp_bytes, keys, keys_out, idx, order_tmp, (size_t)total, 0u, 64u, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mtg_e13_segment_kernel, dim3(blocks(total)), dim3(256), 0, st, total, n, order_tmp, segment);
+    unsigned bits = 1;
+    while (bits < 32 && ((uint64_t)(S - 1) >> bits) != 0) ++bits;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, segment, segment_out, order_tmp, order, (size_t)total, 0u, bits, st);
 }
 
-// order[s][r] = position of the r-th largest entry of adjusted[s][:]
-hipError_t mtg_launch_e13_rank(int64_t S, int64_t n, const double *adjusted, double *keys_out, const int32_t *idx, int32_t *order,
-                               const uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st)
+// values[s][:] = x[s][:] sorted, descending (the same two sorts, then a gather)
+hipError_t mtg_launch_e13_sort_values(int64_t S, int64_t n, const double *x, double *keys_out, const int32_t *idx, int32_t *order_tmp,
+                                      uint32_t *segment, uint32_t *segment_out, int32_t *order, double *values, void *temp,
+                                      size_t temp_bytes, hipStream_t st)
 {
-    return rocprim::segmented_radix_sort_pairs_desc(temp, temp_bytes, adjusted, keys_out, idx, order, (unsigned)(S * n), (unsigned)S, offsets,
-                                                    offsets + 1, 0u, 64u, st);
+    hipError_t e = mtg_launch_e13_rank(S, n, x, keys_out, idx, order_tmp, segment, segment_out, order, temp, temp_bytes, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mtg_e13_gather_kernel, dim3(blocks(S * n)), dim3(256), 0, st, S * n, order, x, values);
+    return hipGetLastError();
 }
 
 // one step's bookkeeping after the rank sort: scatter + convergence test, copy, verdicts; *running (device) = segments not done
