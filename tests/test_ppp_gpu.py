@@ -264,16 +264,17 @@ def test_simulated_series_in_blocks_are_the_series_of_one_call():
         sim.simulate(thetas[3:6], seed=12345, index_base=3, pair_series=True)
 
 
-@pytest.mark.parametrize("pdf", ["Gaussian", "Lognormal"])
-def test_host_drawn_noise_in_blocks_is_the_noise_of_one_call(pdf):
-    """A light curve with a background takes the Kraft noise model, a non-Gaussian flux PDF the iterative adjustment: both
-    are drawn on the HOST.  Given an index_base every series draws from a generator of its own (seed, global index), so
-    blocks -- ranks of a sharded Protassov test -- reproduce the whole set; without it they share one stream and do not."""
+@pytest.mark.parametrize("pdf,adjust_on", [("Gaussian", "device"), ("Lognormal", "host"), ("Lognormal", "device")])
+def test_host_drawn_noise_in_blocks_is_the_noise_of_one_call(pdf, adjust_on):
+    """A light curve with a background takes the Kraft noise model, drawn on the HOST; a non-Gaussian flux PDF the iterative
+    adjustment -- on the device (its white series keyed by seed and global index, csrc/mtg_e13.hip) or, adjust_on="host",
+    in numpy.  Given an index_base every series draws from a generator of its own (seed, global index), so blocks -- ranks
+    of a sharded Protassov test -- reproduce the whole set; without it the host's draws share one stream and do not."""
     from mind_the_gaps_amd.simulator import Simulator
     rng = np.random.default_rng(4)
     times = synth.make_times(120, rng)
     sim = Simulator(null_kernel(), times, 0.04, 400.0, pdf, bkg_rate=30.0, bkg_rate_err=2.0, extension_factor=2,
-                    random_state=1, max_iter=30)
+                    random_state=1, max_iter=30, adjust_on=adjust_on)
     assert sim.noise_name == "Kraft"
     thetas = synth.draw_thetas(synth.NULL_MODEL, 6, seed=8, percent=0.05)
     import warnings
@@ -288,3 +289,33 @@ def test_host_drawn_noise_in_blocks_is_the_noise_of_one_call(pdf):
         shared_a = sim.simulate(thetas[2:6], seed=777)
     assert np.all(np.isfinite(whole["rates"])) and np.all(whole["dy"] > 0)
     assert not np.array_equal(shared_a["rates"], whole["rates"][2:6])
+
+
+def test_protassov_test_with_a_lognormal_flux_pdf_never_leaves_the_device(monkeypatch):
+    """protassov_test(pdf="Lognormal"): every simulated light curve goes through the E13 adjustment ON THE DEVICE between the
+    cut and the down-sampling (simulator.py:65-140; csrc/mtg_e13.hip), stays resident for the refits, and the numpy loop
+    is never entered; same seed, same test."""
+    from mind_the_gaps_amd.ppp import protassov_test
+    from mind_the_gaps_amd.simulator import Simulator
+
+    def never(self, *a, **k):
+        raise AssertionError("the host adjustment ran")
+    monkeypatch.setattr(Simulator, "_adjust_pdf", never)
+    monkeypatch.setattr(Simulator, "_finish_on_host", never)
+    times = np.arange(0.5, 200.0, 1.0)
+    th = synth.truth([synth.K_DRW])
+    drw = lambda: DampedRandomWalk(th[0], th[1], bounds=[AMP, OTHER])
+    lor = synth.truth([synth.K_LORENTZIAN])
+    obs = Simulator(drw(), times, 0.2, 100.0, "Lognormal", sigma_noise=2.0, extension_factor=3, random_state=9).simulate()
+    assert np.all(obs["rates"] > 0)
+    lc = GappyLightcurve(times, obs["rates"][0], obs["dy"][0], exposures=0.2)
+    alt = drw() + Lorentzian(lor[0], lor[1], lor[2], bounds=[AMP, OTHER, OTHER])
+    runs = [protassov_test(lc, drw(), alt, nsims=12, walkers=16, max_steps=100, sim_steps=40, sigma_noise=2.0, seed=5,
+                           pdf="Lognormal") for _ in range(2)]
+    res = runs[0]
+    assert res["T_sim"].shape == (12,) and np.all(np.isfinite(res["T_sim"])) and np.isfinite(res["T_obs"])
+    assert np.all(res["lightcurves"]["rates"] > 50.0) and 1 / 13 <= res["p_value"] <= 1.0
+    assert np.array_equal(runs[1]["T_sim"], res["T_sim"]) and runs[1]["p_value"] == res["p_value"]
+    # ... and it is another test than the Gaussian one of the same seed
+    plain = protassov_test(lc, drw(), alt, nsims=12, walkers=16, max_steps=100, sim_steps=40, sigma_noise=2.0, seed=5)
+    assert not np.array_equal(plain["T_sim"], res["T_sim"])
