@@ -240,6 +240,16 @@ MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on);
  * warns), and the largest iteration count.
  */
 MTG_API int mtg_set_simulate_pdf(mtg_ctx *ctx, int kind, int max_iter);
+/*
+ * KraftNoise (noise_models.py:81-150) for mtg_simulate_tk95(noise_kind = 3), on the device: total counts ~ Poisson(rate x
+ * exposure + bkg_counts[n]); net rate = (total - bkg) / exposure, dy = sqrt((sqrt(total) / exposure)^2 + bkg_rate_err[n]^2);
+ * epochs with total < threshold (the reference's kraft_counts, 15) take the median of the Kraft, Burrows & Nousek (1991)
+ * posterior of the source counts and half the width of its 68 % interval instead -- functions of (total, background)
+ * alone, tabulated by the caller for total = 0 .. K - 1 and every epoch: median[N][K], half[N][K] (counts; K >= threshold).
+ * N must be the number of epochs of the resident sampling; N = 0 forgets the tables.
+ */
+MTG_API int mtg_set_simulate_kraft(mtg_ctx *ctx, int64_t N, int K, double threshold, const double *bkg_counts, const double *bkg_rate_err,
+                                   const double *median, const double *half);
 MTG_API int mtg_set_simulate_pdf_draws(mtg_ctx *ctx, int64_t S, int64_t n, const double *draws);
 MTG_API int mtg_simulate_pdf_report(const mtg_ctx *ctx, int64_t *not_converged, int *iterations);
 /* Which transform mtg_simulate_tk95 takes: 0 (default) = by grid length (hipFFT's plan for lengths of radices 2-13, the
@@ -434,7 +444,8 @@ MTG_API int mtg_ensemble_shard_profile_read(mtg_ctx *ctx, int capacity, double *
  *   seg_len        fine samples in the randomly cut segment (sim_duration / sim_dt)
  *   win_lo/win_hi  [N] fine-sample ranges [lo, hi) of the segment averaged into every
  *                  epoch (the `strategy` windows of simulator.py:266-267, 340-367)
- *   noise_kind     0 none, 1 Gaussian(sigma_noise), 2 Poisson over exposures[N]
+ *   noise_kind     0 none, 1 Gaussian(sigma_noise), 2 Poisson over exposures[N], 3 Kraft (Poisson with background and the
+ *                  Bayesian estimates of the faint epochs: mtg_set_simulate_kraft first)
  *   clean          [S][N] noise-free rates or NULL; rates, dy [S][N]: noisy rates and
  *                  their 1-sigma errors (host buffers); lc_means [S] or NULL
  *   make_resident  != 0: the simulated set becomes the context's light curves (frozen mean

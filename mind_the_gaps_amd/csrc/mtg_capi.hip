@@ -148,6 +148,8 @@ struct mtg_ctx {
     // draws handed in by the caller for the NEXT mtg_simulate_tk95 (mtg_set_simulate_draws): standard normals
     // [S][2][nfft / 2 + 1] and segment starts [S]
     struct { DevBuf normals, starts; std::vector<int64_t> starts_host; int64_t S = 0, nk = 0; } given;
+    // KraftNoise for noise_kind 3 (mtg_set_simulate_kraft): per-epoch background and the faint epochs' tables
+    struct { DevBuf bkg, err, med, half; int K = 0; double threshold = 0.0; int64_t N = 0; } kraft;
     // the flux PDF of the simulated light curves (mtg_set_simulate_pdf): 0 Gaussian = TK95 as it is, 1 lognormal, 2 uniform
     // = the E13 adjustment of every cut segment on the device (mtg_e13.hip); its buffers, plans and last run's report
     struct E13 {
@@ -880,6 +882,7 @@ MTG_API void mtg_destroy(mtg_ctx *ctx)
             if (sp.have) (void)hipfftDestroy(sp.h);
         if (ctx->e13.have) { (void)hipfftDestroy(ctx->e13.fwd); (void)hipfftDestroy(ctx->e13.inv); ctx->e13.have = false; }
     }
+    for (DevBuf *b : {&ctx->kraft.bkg, &ctx->kraft.err, &ctx->kraft.med, &ctx->kraft.half}) b->release();
     for (DevBuf *b : {&ctx->e13.seg, &ctx->e13.x, &ctx->e13.fresh, &ctx->e13.values, &ctx->e13.adj, &ctx->e13.keys, &ctx->e13.amp,
                       &ctx->e13.spec, &ctx->e13.idx, &ctx->e13.order, &ctx->e13.order_tmp, &ctx->e13.segment, &ctx->e13.segment_out, &ctx->e13.flags, &ctx->e13.stdv, &ctx->e13.temp,
                       &ctx->e13.given})
@@ -2019,8 +2022,16 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     if (S <= 0 || nfft < 4 || !(sim_dt > 0.0) || seg_len <= 0 || seg_len > nfft || !win_lo || !win_hi || !rates || !dy ||
         (!psd_table && !theta && ctx->model.P > 0))
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad arguments");
-    if (noise_kind < 0 || noise_kind > 2 || (noise_kind == 2 && !exposures) || (noise_kind == 1 && !(sigma_noise >= 0.0)))
+    if (noise_kind < 0 || noise_kind > 3 || (noise_kind >= 2 && !exposures) || (noise_kind == 1 && !(sigma_noise >= 0.0)))
         return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: bad noise specification");
+    if (noise_kind == 3 && ctx->kraft.N != N)
+        return fail(ctx, MTG_E_STATE, "mtg_simulate_tk95: noise_kind 3 (Kraft) needs mtg_set_simulate_kraft for the %lld epochs of the resident sampling", (long long)N);
+    MtgKraftTables kraft;
+    if (noise_kind == 3) {
+        kraft.bkg_counts = ctx->kraft.bkg.as<double>(); kraft.bkg_rate_err = ctx->kraft.err.as<double>();
+        kraft.median = ctx->kraft.med.as<double>(); kraft.half = ctx->kraft.half.as<double>();
+        kraft.K = ctx->kraft.K; kraft.threshold = ctx->kraft.threshold;
+    }
     for (int64_t n = 0; n < N; ++n)
         if (win_lo[n] < 0 || win_hi[n] < win_lo[n] || win_hi[n] > seg_len)
             return fail(ctx, MTG_E_ARG, "mtg_simulate_tk95: window %lld = [%d, %d) outside the segment of %lld samples",
@@ -2169,13 +2180,13 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
             }
             mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, seg_len, seg_len, sim_dt, sim_dt, 0.0, ctx->e13.x.as<double>(),
                                     d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
-                                    0, seed, nullptr, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+                                    0, seed, nullptr, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s, kraft);
             e = hipGetLastError();
             continue;
         }
         mtg_launch_tk95_observe(sc, s0, ctx->stream_base, N, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(),
                                 d_lo.as<int32_t>(), d_hi.as<int32_t>(), noise_kind, sigma_noise, d_expo.as<double>(),
-                                -1, seed, given_starts, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s);
+                                -1, seed, given_starts, clean ? d_clean.as<double>() : nullptr, d_rates.as<double>(), d_dy.as<double>(), s, kraft);
         if (segments)
             mtg_launch_tk95_segment(sc, s0, ctx->stream_base, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
                                     given_starts, d_seg.as<double>(), s);
@@ -2433,6 +2444,29 @@ MTG_API int mtg_set_simulate_pairs(mtg_ctx *ctx, int on)
 }
 
 MTG_API int64_t mtg_chain_autocorr_plans_built(const mtg_ctx *ctx) { return ctx ? ctx->acf_plans_built : -1; }
+
+MTG_API int mtg_set_simulate_kraft(mtg_ctx *ctx, int64_t N, int K, double threshold, const double *bkg_counts, const double *bkg_rate_err,
+                                   const double *median, const double *half)
+{
+    if (!ctx) return MTG_E_ARG;
+    if (N == 0) { ctx->kraft.N = 0; return MTG_OK; }
+    if (N < 0 || K < 1 || K > 4096 || !(threshold >= 0.0) || threshold > (double)K || !bkg_counts || !bkg_rate_err || !median || !half)
+        return fail(ctx, MTG_E_ARG, "mtg_set_simulate_kraft: bad arguments (the tables must cover total counts 0 .. K - 1 >= threshold - 1)");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    CTX_STREAM(ctx, s);
+    HIP_TRY(ctx, ctx->kraft.bkg.reserve((size_t)N * 8));
+    HIP_TRY(ctx, ctx->kraft.err.reserve((size_t)N * 8));
+    HIP_TRY(ctx, ctx->kraft.med.reserve((size_t)N * K * 8));
+    HIP_TRY(ctx, ctx->kraft.half.reserve((size_t)N * K * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->kraft.bkg.p, bkg_counts, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->kraft.err.p, bkg_rate_err, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->kraft.med.p, median, (size_t)N * K * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->kraft.half.p, half, (size_t)N * K * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->kraft.N = N; ctx->kraft.K = K; ctx->kraft.threshold = threshold;
+    return MTG_OK;
+}
 
 MTG_API int mtg_set_simulate_pdf(mtg_ctx *ctx, int kind, int max_iter)
 {

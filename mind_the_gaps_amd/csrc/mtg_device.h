@@ -218,6 +218,13 @@ void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft
 void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, uint64_t seed, const int64_t *given_start, double *out,
                              hipStream_t);
+// KraftNoise (noise_models.py:81-150) for noise_kind 3: background counts and rate errors per epoch, and the posterior
+// median / half-width of the 68 % interval of the source counts for total counts 0 .. K - 1 (< threshold), [N][K]
+struct MtgKraftTables {
+    const double *bkg_counts = nullptr, *bkg_rate_err = nullptr, *median = nullptr, *half = nullptr;
+    int K = 0;
+    double threshold = 0.0;
+};
 // the E13 flux-PDF adjustment of the cut segments (mtg_e13.hip)
 size_t mtg_e13_sort_temp_bytes(int64_t S, int64_t n);
 void mtg_launch_e13_std(int64_t S, int64_t n, const double *seg, double *stdv, hipStream_t);
@@ -236,7 +243,8 @@ void mtg_launch_e13_step(int64_t S, int64_t n, const int32_t *order, const doubl
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
-                             uint64_t seed, const int64_t *given_start, double *clean, double *rates, double *dy, hipStream_t);
+                             uint64_t seed, const int64_t *given_start, double *clean, double *rates, double *dy, hipStream_t,
+                             const MtgKraftTables &kraft = MtgKraftTables());
 void mtg_launch_tk95_resident(int64_t L, int64_t N, const double *rates, const double *dy, double2 *yv, double *means,
                               hipStream_t);
 // inverse real transform of a length with large prime factors on power-of-two transforms (chirp-z; mtg_simulate.hip)

@@ -138,12 +138,55 @@ mtg_tk95_segment_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int6
     out[sg * seg_len + j] = series[s * nfft + j0 + j] * scale / dt + mean_rate;
 }
 
+// numpy.random.poisson's two regimes on a Philox stream keyed by (epoch, series): Knuth's multiplication below 10, the
+// transformed rejection of Hoermann (1993, PTRS) above; NaN for a negative mean (numpy raises: the epoch is flagged instead)
+__device__ inline double tk95_poisson(double lam, uint32_t n, uint32_t sg, uint32_t seed_lo, uint32_t seed_hi)
+{
+    double counts;
+    if (!(lam >= 0.0)) {
+        counts = NAN;
+    } else if (lam < 10.0) {
+        const double limit = exp(-lam);
+        double prod = 1.0;
+        int kcount = 0;
+        for (uint32_t ctr = 1; ctr < 64; ++ctr) {
+            const Philox r = philox4x32_10(n, PURPOSE_NOISE, sg, ctr, seed_lo, seed_hi);
+            prod *= u01(r.c[0], r.c[1]);
+            if (prod <= limit) break;
+            ++kcount;
+            prod *= u01(r.c[2], r.c[3]);
+            if (prod <= limit) break;
+            ++kcount;
+        }
+        counts = (double)kcount;
+    } else {
+        const double slam = sqrt(lam), loglam = log(lam);
+        const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+        const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+        counts = floor(lam + 0.5);
+        for (uint32_t ctr = 1; ctr < 256; ++ctr) {
+            const Philox r = philox4x32_10(n, PURPOSE_NOISE, sg, ctr, seed_lo, seed_hi);
+            const double U = u01(r.c[0], r.c[1]) - 0.5, V = u01(r.c[2], r.c[3]);
+            const double us = 0.5 - fabs(U);
+            const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+            if (us >= 0.07 && V <= vr) { counts = kf; break; }
+            if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+            if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) {
+                counts = kf;
+                break;
+            }
+        }
+    }
+    return counts;
+}
+
 // Segment cut + bin average onto the observing pattern + noise.  One thread per (simulation, epoch).
 __global__ void __launch_bounds__(256)
 mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                         double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                         int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
-                        uint32_t seed_lo, uint32_t seed_hi, const int64_t *given_start, double *clean, double *rates, double *dy)
+                        uint32_t seed_lo, uint32_t seed_hi, const int64_t *given_start, double *clean, double *rates, double *dy,
+                        MtgKraftTables kraft)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * N) return;
@@ -166,44 +209,19 @@ mtg_tk95_observe_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t
         ev = sigma_noise;
     } else if (noise_kind == 2) {  // PoissonNoise without background (noise_models.py:29-78)
         const double expo = exposures[n];
-        const double lam = rate * expo;
-        double counts;
-        if (!(lam >= 0.0)) {
-            counts = NAN;  // numpy.random.poisson raises for lam < 0: flag the epoch instead
-        } else if (lam < 10.0) {  // Knuth's multiplication method
-            const double limit = exp(-lam);
-            double prod = 1.0;
-            int kcount = 0;
-            for (uint32_t ctr = 1; ctr < 64; ++ctr) {
-                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)(sg + sbase), ctr, seed_lo, seed_hi);
-                prod *= u01(r.c[0], r.c[1]);
-                if (prod <= limit) break;
-                ++kcount;
-                prod *= u01(r.c[2], r.c[3]);
-                if (prod <= limit) break;
-                ++kcount;
-            }
-            counts = (double)kcount;
-        } else {  // transformed rejection (Hoermann 1993, PTRS)
-            const double slam = sqrt(lam), loglam = log(lam);
-            const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
-            const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
-            counts = floor(lam + 0.5);
-            for (uint32_t ctr = 1; ctr < 256; ++ctr) {
-                const Philox r = philox4x32_10((uint32_t)n, PURPOSE_NOISE, (uint32_t)(sg + sbase), ctr, seed_lo, seed_hi);
-                const double U = u01(r.c[0], r.c[1]) - 0.5, V = u01(r.c[2], r.c[3]);
-                const double us = 0.5 - fabs(U);
-                const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
-                if (us >= 0.07 && V <= vr) { counts = kf; break; }
-                if (kf < 0.0 || (us < 0.013 && V > us)) continue;
-                if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) {
-                    counts = kf;
-                    break;
-                }
-            }
-        }
+        const double counts = tk95_poisson(rate * expo, (uint32_t)n, (uint32_t)(sg + sbase), seed_lo, seed_hi);
         yv = counts / expo;
         ev = sqrt(counts) / expo;
+    } else if (noise_kind == 3) {  // KraftNoise (noise_models.py:81-150): Poisson with background; the faint epochs' Bayesian estimates
+        const double expo = exposures[n], bkg = kraft.bkg_counts[n], err = kraft.bkg_rate_err[n];
+        const double total = tk95_poisson(rate * expo + bkg, (uint32_t)n, (uint32_t)(sg + sbase), seed_lo, seed_hi);
+        yv = (total - bkg) / expo;
+        ev = sqrt((sqrt(total) / expo) * (sqrt(total) / expo) + err * err);
+        if (total < kraft.threshold) {   // posterior median and half-width of the 68 % interval, tabulated per (epoch, counts)
+            const int64_t at = n * kraft.K + (int64_t)total;
+            yv = kraft.median[at] / expo;
+            ev = kraft.half[at] / expo;
+        }
     }
     rates[o] = yv;
     dy[o] = ev;
@@ -357,12 +375,13 @@ void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft,
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, const int32_t *win_lo, const int32_t *win_hi,
                              int noise_kind, double sigma_noise, const double *exposures, int64_t fixed_start,
-                             uint64_t seed, const int64_t *given_start, double *clean, double *rates, double *dy, hipStream_t st)
+                             uint64_t seed, const int64_t *given_start, double *clean, double *rates, double *dy, hipStream_t st,
+                             const MtgKraftTables &kraft)
 {
     const int64_t n = S * N;
     hipLaunchKernelGGL(mtg_tk95_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, N, nfft,
                        seg_len, dt, scale, mean_rate, series, win_lo, win_hi, noise_kind, sigma_noise, exposures,
-                       fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), given_start, clean, rates, dy);
+                       fixed_start, (uint32_t)seed, (uint32_t)(seed >> 32), given_start, clean, rates, dy, kraft);
 }
 
 

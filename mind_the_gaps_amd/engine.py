@@ -33,7 +33,7 @@ EXPORTS = (
     "mtg_predict", "mtg_simulate_tk95", "mtg_set_time_parallel", "mtg_set_window_bytes",
     "mtg_apply_inverse", "mtg_set_tp_direct", "mtg_tk95_observe_series", "mtg_rccl_load",
     "mtg_rccl_unique_id", "mtg_ensemble_shard_rccl", "mtg_ensemble_shard_host", "mtg_ensemble_unshard",
-    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_simulate_pdf", "mtg_set_simulate_pdf_draws", "mtg_simulate_pdf_report", "mtg_set_pair_patience", "mtg_chain_autocorr_plans_built",
+    "mtg_chain_autocorr", "mtg_fft_warmup", "mtg_simulate_plan", "mtg_ensemble_restore", "mtg_set_sort", "mtg_set_pipeline", "mtg_set_stream_base", "mtg_set_speculation", "mtg_last_solver", "mtg_pair_contexts", "mtg_unpair_contexts", "mtg_pair_stats", "mtg_set_simulate_pairs", "mtg_set_simulate_transform", "mtg_set_simulate_pdf", "mtg_set_simulate_kraft", "mtg_set_simulate_pdf_draws", "mtg_simulate_pdf_report", "mtg_set_pair_patience", "mtg_chain_autocorr_plans_built",
     "mtg_set_simulate_draws",
     "mtg_ensemble_shard_info", "mtg_ensemble_shard_profile", "mtg_ensemble_shard_profile_read",
 )
@@ -257,6 +257,8 @@ def load_library():
     lib.mtg_set_pair_patience.argtypes = [c_vp, c_int]
     lib.mtg_set_simulate_pdf.restype = c_int
     lib.mtg_set_simulate_pdf.argtypes = [c_vp, c_int, c_int]
+    lib.mtg_set_simulate_kraft.restype = c_int
+    lib.mtg_set_simulate_kraft.argtypes = [c_vp, c_i64, c_int, ctypes.c_double, _dp, _dp, _dp, _dp]
     lib.mtg_set_simulate_pdf_draws.restype = c_int
     lib.mtg_set_simulate_pdf_draws.argtypes = [c_vp, c_i64, c_i64, _dp]
     lib.mtg_simulate_pdf_report.restype = c_int
@@ -792,6 +794,15 @@ class Engine:
         E13 adjustment of every cut segment, on the device; include/mtg.h: mtg_set_simulate_pdf)."""
         kind = {"gaussian": 0, "lognormal": 1, "uniform": 2}.get(str(kind).lower(), kind)
         self._check(self._lib.mtg_set_simulate_pdf(self._ctx, int(kind), int(max_iter)))
+
+    def set_simulate_kraft(self, bkg_counts, bkg_rate_err, median, half, threshold):
+        """KraftNoise for simulate_tk95(noise_kind=3): background counts and rate errors per epoch [N], posterior median and
+        half-width of the 68 % interval per epoch and total counts [N][K] (include/mtg.h: mtg_set_simulate_kraft)."""
+        bkg, err, med, hw = _f64(bkg_counts), _f64(bkg_rate_err), _f64(median), _f64(half)
+        if med.ndim != 2 or med.shape != hw.shape or bkg.shape != (med.shape[0],) or err.shape != bkg.shape:
+            raise ValueError("median / half must be [N][K], bkg_counts / bkg_rate_err [N]")
+        self._check(self._lib.mtg_set_simulate_kraft(self._ctx, med.shape[0], med.shape[1], float(threshold), _ptr(bkg), _ptr(err),
+                                                     _ptr(med), _ptr(hw)))
 
     def set_simulate_pdf_draws(self, draws):
         """The white series the NEXT simulate_tk95's E13 adjustment starts from, [S][seg_len] (None: clear)."""

@@ -23,8 +23,10 @@ The Emmanoulopoulos et al. (2013) amplitude / rank adjustment for ``pdf="lognorm
 transforms and one segmented sort per iteration over all the segments of a chunk), between the cut and the
 down-sampling, so a posterior-predictive run with a non-Gaussian flux PDF stays on the GPU; ``adjust_on="host"``
 keeps the numpy implementation (``_adjust_pdf``: the reference's loop, at the reference's kind of speed), which the
-tests hold the device against.  Host-side: the Kraft et al. (1991) treatment of low-count epochs with background
-(noise_models.py:81-150).
+tests hold the device against.  The Kraft et al. (1991) treatment of low-count epochs with background
+(noise_models.py:81-150) as well: the posterior median and 68 % interval of the source counts depend on (total counts,
+background) alone, so the simulator tabulates them once per epoch for totals below ``kraft_counts`` and the device looks
+them up after its Poisson draw (``mtg_set_simulate_kraft``; ``adjust_on="host"``: numpy, per light curve).
 
 Random numbers.  Default (``stream="philox"``): counter-based streams on the device, keyed by (seed, series index) -- what
 the batched Protassov loop needs.  ``stream="numpy"``: the reference draws everything from numpy's GLOBAL generator
@@ -275,7 +277,9 @@ class Simulator:
         shaped = self.pdf.lower() != "gaussian"
         on_device = shaped and self.adjust_on == "device"
         host_adjust = shaped and not on_device
-        host_side = host_adjust or (noise and self._noise_kind == 3)          # (Kraft noise is made on the host)
+        host_side = host_adjust or (noise and self._noise_kind == 3 and self.adjust_on == "host")
+        if noise and self._noise_kind == 3 and not host_side:
+            eng.set_simulate_kraft(self._bkg_counts, self._bkg_rate_err, *self._kraft_tables(), self.kraft_counts)
         kw = dict(noise_kind=0 if (host_side or not noise) else self._noise_kind, sigma_noise=self.sigma_noise,
                   exposures=self._exposures, want_clean=want_clean and not host_side,
                   make_resident=make_resident and not host_side, want_segments=host_adjust)
@@ -347,6 +351,21 @@ class Simulator:
         rates = np.array(rates)
         dy = np.array(dy) if noise else np.zeros_like(rates)
         return dict(rates=rates, dy=dy, means=rates.mean(axis=1), clean=clean)
+
+    def _kraft_tables(self):
+        """(median[N][K], half[N][K]): Kraft, Burrows & Nousek's posterior median of the source counts and half the width of
+        its 68 % interval for total counts 0 .. K - 1 (K = the first integer >= kraft_counts) at every epoch's background --
+        what ``add_noise`` computes per faint epoch, once per distinct background."""
+        if getattr(self, "_kraft_cache", None) is None:
+            K = max(int(np.ceil(self.kraft_counts)), 1)
+            med, half = np.empty((len(self._bkg_counts), K)), np.empty((len(self._bkg_counts), K))
+            for b in np.unique(self._bkg_counts):
+                rows = self._bkg_counts == b
+                m = [kraft_median(c, b) for c in range(K)]
+                h = [(lambda lo_hi: (lo_hi[1] - lo_hi[0]) / 2.0)(kraft_interval(c, b, 0.68)) for c in range(K)]
+                med[rows], half[rows] = m, h
+            self._kraft_cache = (med, half)
+        return self._kraft_cache
 
     def _adjust_pdf(self, segment, draws=None):
         """Emmanoulopoulos et al. (2013), as simulator.py:65-140 runs it: a white series drawn from the

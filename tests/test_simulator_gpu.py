@@ -387,3 +387,51 @@ def test_flux_pdf_on_the_device_draws_blocks_and_noise():
     with pytest.warns(UserWarning, match="did not converge after 1 iterations"):
         short.simulate(thetas[:2], seed=77, noise=False)
     assert short.last_adjustment == {"not_converged": 2, "iterations": 2}
+
+
+def test_kraft_noise_on_the_device_is_add_noise_epoch_by_epoch():
+    """noise_models.py:81-150 on the device (mtg_set_simulate_kraft): every (rate, dy) pair the device returns is what the
+    host's add_noise formulas give for an integer number of total counts -- the Poisson branch for 15 counts or more, the
+    tabulated Kraft-Burrows-Nousek median and half-interval below --, the counts scatter around rate x exposure + background
+    as Poisson counts do, and a set simulated in blocks is the set of one call."""
+    rng = np.random.default_rng(4)
+    times = synth.make_times(150, rng)
+    kernel = DampedRandomWalk(np.log(900.0), np.log(2 * np.pi / 12), bounds=[(-10, 50), (-10, 10)])
+    sim = Simulator(kernel, times, 0.04, 400.0, "Gaussian", bkg_rate=30.0, bkg_rate_err=2.0, extension_factor=2, random_state=1)
+    assert sim.noise_name == "Kraft" and sim.adjust_on == "device"
+    S = 40
+    model = sim._engine()[1]
+    thetas = np.tile(model.full[model.free_index][None, :], (S, 1))
+    out = sim.simulate(thetas, seed=31, want_clean=True, index_base=0)
+    expo, bkg, err = sim._exposures, sim._bkg_counts, sim._bkg_rate_err
+    med, half = sim._kraft_tables()
+    K = med.shape[1]
+    assert K == 15 and np.all(np.diff(med, axis=1) > 0) and np.all(half > 0)
+    rates, dy, clean = out["rates"], out["dy"], out["clean"]
+    assert np.all(np.isfinite(rates)) and np.all(dy > 0)
+    totals = np.full(rates.shape, -1.0)
+    # faint epochs: (rate, dy) = (median, half)[epoch][c] / exposure for exactly one c < 15
+    for c in range(K):
+        hit = (rates == med[:, c][None, :] / expo[None, :]) & (dy == half[:, c][None, :] / expo[None, :])
+        assert not np.any(hit & (totals >= 0))
+        totals[hit] = c
+    faint = totals >= 0
+    # the others: an integer total >= 15 through the Poisson formulas
+    t_guess = np.round(rates * expo + bkg)
+    poisson = (~faint) & (t_guess >= 15) & (np.abs(rates - (t_guess - bkg) / expo) <= 1e-9 * np.abs(rates) + 1e-9) \
+        & (np.abs(dy - np.sqrt((np.sqrt(t_guess) / expo) ** 2 + err ** 2)) <= 1e-9 * dy)
+    totals[poisson] = t_guess[poisson]
+    assert np.all(totals >= 0), "an epoch whose (rate, dy) is neither branch of add_noise"
+    assert faint.mean() > 0.05 and poisson.mean() > 0.05          # both branches exercised
+    lam = clean * expo + bkg
+    z = (totals - lam) / np.sqrt(lam)
+    assert abs(z.mean()) < 0.1 and 0.9 < z.std() < 1.1              # Poisson counts around the clean rates
+    parts = [sim.simulate(thetas[lo:hi], seed=31, index_base=lo) for lo, hi in ((0, 6), (6, 7), (7, 40))]
+    assert np.array_equal(np.vstack([p["rates"] for p in parts]), rates) and np.array_equal(np.vstack([p["dy"] for p in parts]), dy)
+    # the host's own add_noise on the same tables agrees with them (the table IS add_noise's per-epoch computation)
+    host = Simulator(kernel, times, 0.04, 400.0, "Gaussian", bkg_rate=30.0, bkg_rate_err=2.0, extension_factor=2, random_state=1,
+                     adjust_on="host")
+    r_h, dy_h = host.add_noise(np.full(len(times), 250.0))           # 10 + 1.2 counts expected: mostly faint
+    for n in np.flatnonzero(r_h * expo + bkg < 14.5)[:20]:
+        c = int(np.argmin(np.abs(med[n] / expo[n] - r_h[n])))
+        assert r_h[n] == med[n, c] / expo[n] and dy_h[n] == half[n, c] / expo[n]
