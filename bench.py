@@ -1002,6 +1002,13 @@ def main():
                                                              + max(alone.values()))
                 share["projected_speedup_at_8_gpus"] = (line["workflow_config3"]["whole_test_s"]
                                                         / share["whole_test_s_with_observed_split"])
+                # the same share with a LOGNORMAL flux PDF (simulator.py:65-140): every simulated segment through the E13
+                # amplitude / rank adjustment on the device (csrc/mtg_e13.hip) before it is observed -- the loop stays on the GPU
+                logn = workflow_probe().run(nsims=max(1, args.lightcurves // 8), pdf="Lognormal")
+                line["workflow_config3_share_of_8_lognormal"] = {
+                    k: logn[k] for k in ("nsims", "flux_pdf", "segment_points_per_simulation", "whole_test_s", "seconds", "p_value",
+                                         "refit_evaluations_per_s_end_to_end")}
+                line["workflow_config3_share_of_8_lognormal"]["simulate_s_gaussian"] = share["seconds"]["simulate"]
                 share["projected_speedup_at_8_gpus_what"] = (
                     "whole test on one GPU / (this GPU's share of 250 light curves, its observed-chains phase replaced by the "
                     "longer of the two chains run alone); leaves out the two broadcasts (rank 0's samples, rank 1's maximum) "

@@ -66,7 +66,7 @@ def observed_chains_alone(N=10000, W=256, device=0):
 
 
 def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurrent_refits="auto", reproducible=True,
-        keep_T_sim=False):
+        keep_T_sim=False, pdf="Gaussian"):
     """-> dict (the JSON line of this script).  bench.py calls it for its `workflow_config3` entry; ``sharded``: inside
     a torch.distributed job, the simulated light curves split over the ranks (ppp.protassov_test(sharded=True)).
     ``reproducible`` (default): T_sim and the p-value do not depend on the number of ranks or the split -- the sharded
@@ -79,7 +79,7 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurre
         t0 = time.perf_counter()
         res = protassov_test(lc, null_kernel(), alt_kernel(), nsims=nsims, walkers=W, max_steps=1000, sim_walkers=W,
                              sim_steps=steps, sigma_noise=1.0, extension_factor=2, seed=1, device=device, sharded=sharded,
-                             concurrent_refits=concurrent_refits, reproducible=reproducible)
+                             concurrent_refits=concurrent_refits, reproducible=reproducible, pdf=pdf)
         el = time.perf_counter() - t0
     evals = 2 * nsims * W * (steps + 1)
     extra = {"T_sim": [float(v) for v in res["T_sim"]]} if keep_T_sim else {}
@@ -87,6 +87,7 @@ def run(nsims=2000, N=10000, W=256, steps=500, sharded=False, device=0, concurre
         **extra,
         "workflow": "protassov_test, BASELINE configs[3]" + (", simulated light curves sharded over the ranks" if sharded else " on one GPU"),
         "nsims": nsims, "N": N, "walkers": W, "refit_steps": steps, "fft_points_per_simulation": sim.fftndatapoints,
+        "flux_pdf": pdf, "segment_points_per_simulation": sim.seg_len,
         "observed_lightcurve_s": t_obs_sim, "whole_test_s": el,
         "seconds": {k: float(v) for k, v in res["seconds"].items()}, "split": res["split"],
         "refit_evaluations": evals, "refit_evaluations_per_s_end_to_end": evals / el,
