@@ -320,12 +320,14 @@ class Simulator:
         out.pop("segments", None)
         return out
 
-    def _finish_on_host(self, out, noise, want_clean, keyed=None, adjust=True, draws=None):
+    def _finish_on_host(self, out, noise, want_clean, keyed=None, adjust=None, draws=None):
         """Flux-PDF adjustment of the fine-grid segments, down-sampling and noise for the cases the device
         kernels do not cover (module docstring).  ``keyed`` = (seed, index_base): series l draws from
         RandomState([seed, index_base + l]) -- its values then do not depend on which block it was simulated in."""
         S = len(out["rates"])
         shared = self.random_state
+        if adjust is None:
+            adjust = self.pdf.lower() != "gaussian"
 
         def own_stream(l, phase):
             if keyed is not None:
