@@ -2214,6 +2214,14 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
     // the plan's buffers stay with the context for the next call of the workflow -- unless they are large enough to be
     // in somebody's way (a fine simulation grid: hundreds of MB per transform)
     if (spec.cap + series.cap + ctx->czt.work.cap > ((size_t)1 << 30)) { spec.release(); series.release(); ctx->czt.work.release(); }
+    {   // ... and so do the E13 adjustment's (92 bytes per fine sample and segment of a chunk)
+        mtg_ctx::E13 &E = ctx->e13;
+        DevBuf *eb[] = {&E.seg, &E.x, &E.fresh, &E.values, &E.adj, &E.keys, &E.amp, &E.spec, &E.idx, &E.order, &E.order_tmp, &E.segment, &E.segment_out, &E.temp};
+        size_t held = 0;
+        for (DevBuf *b : eb) held += b->cap;
+        if (held > ((size_t)1 << 30))
+            for (DevBuf *b : eb) b->release();
+    }
     if (e != hipSuccess) {
         // the resident set may have been freed or partly overwritten on the way: nothing is resident any more
         if (make_resident) { ctx->N = 0; ctx->L = 0; }
