@@ -24,6 +24,10 @@ for where in ("device", "host"):
         t0 = time.perf_counter()
         out = sim.simulate(thetas, seed=6)
         dt = time.perf_counter() - t0
+        if where == "device":       # once more with the plans of this batch made (rocFFT builds a Bluestein plan per length and batch)
+            t0 = time.perf_counter()
+            out = sim.simulate(thetas, seed=7)
+            print("device, plans made: %.3f s = %.4f s per light curve (first call of this shape: %.3f s)" % (time.perf_counter() - t0, (time.perf_counter() - t0) / S, dt), flush=True)
     rep = getattr(sim, "last_adjustment", None)
     print("%-6s: %d light curves of %d epochs, segments of %d fine samples (grid %d): %.3f s = %.4f s per light curve%s"
           % (where, S, len(t), sim.seg_len, sim.fftndatapoints, dt, dt / S,
