@@ -224,3 +224,41 @@ def test_noise_model_classes_are_the_simulators_noise():
         assert np.array_equal(got, want) and np.array_equal(got_dy, want_dy) and got.shape == got_dy.shape == (n,)
     with pytest.raises(NotImplementedError):
         nm.BaseNoise("x").add_noise(rates)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pdf", ["Lognormal", "Uniform"])
+def test_flux_pdf_of_a_million_point_light_curve(engine, pdf):
+    """simulator_test.py:376-432 (test_pdf_lognormal / test_pdf_uniform) at the reference's own size -- 10^6 regular epochs,
+    one fine sample each, a bending power law, max_iter 1000 -- through the DEVICE adjustment: the light curve has the wanted
+    PDF with the simulator's mean and the TK95 segment's variance, to the reference's tolerances (mean 0.1 / 0.01, variance
+    0.2 / 0.1), and still the segment's power spectrum."""
+    from scipy import stats
+    from mind_the_gaps_amd.models.psd_models import BendingPowerlaw
+    dt, n, mean = 1.0, 1000000, 10.0
+    timestamps = np.arange(0, n, dt)
+    psd = BendingPowerlaw(S0=10, omega0=2 * np.pi / 1000)
+    make = lambda kind: Simulator(psd, timestamps, dt, mean, kind, extension_factor=1.05, aliasing_factor=1, max_iter=1000, random_state=15)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = make("Gaussian").simulate(noise=False, nsims=1, seed=151)["rates"][0]      # the TK95 segment itself (same seed, same cut)
+        simu = make(pdf)
+        out = simu.simulate(noise=False, nsims=1, seed=151)["rates"][0]
+    assert simu.last_adjustment["not_converged"] == 0 and simu.last_adjustment["iterations"] > 1
+    input_var = np.var(plain)
+    assert out.shape == (n,) and abs(out.mean() - mean) < (0.1 if pdf == "Lognormal" else 0.01)
+    assert abs(np.var(out) - input_var) < (0.2 if pdf == "Lognormal" else 0.1)
+    sub = out[::97]
+    if pdf == "Lognormal":
+        s = np.sqrt(np.log(input_var / mean ** 2 + 1.0))
+        assert np.all(out > 0) and stats.kstest(sub, stats.lognorm(s, scale=mean ** 2 / np.sqrt(input_var + mean ** 2)).cdf).pvalue > 1e-3
+    else:
+        half = np.sqrt(3.0 * input_var)
+        assert out.min() >= mean - half and out.max() <= mean + half
+        assert stats.kstest(sub, stats.uniform(mean - half, 2 * half).cdf).pvalue > 1e-3
+    # the adjustment keeps the amplitudes it was given: binned periodograms of the two series agree
+    k = np.arange(1, 20001)
+    p_in, p_out = (np.abs(np.fft.rfft(x - x.mean())[k]) ** 2 for x in (plain, out))
+    bins = np.array_split(np.arange(len(k)), 40)
+    ratio = np.array([p_out[b].mean() / p_in[b].mean() for b in bins])
+    assert np.all(np.abs(np.log(ratio)) < 0.25), ratio
