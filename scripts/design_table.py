@@ -131,7 +131,7 @@ def rows():
         ("f2 simulator", "`csrc/mtg_simulate.hip`, `simulator.py`, `models/psd_models.py`",
          "`test_simulator_gpu` (exact host replay, chirp-z vs library transform, moments, noise; `stream=numpy`: the reference notebook's own light curves for its seeds; "
          "the E13 flux-PDF adjustment on the device = the numpy loop to 10⁻¹² from the same white series; Kraft noise on the device = `add_noise` epoch by epoch), "
-         "`test_simulator_reference_cases` (the reference's known answers), `test_psd_models`, `test_ppp_gpu` (block invariance; a lognormal Protassov test that never enters the host loop)",
+         "`test_simulator_reference_cases` (the reference's known answers, incl. its `test_pdf_lognormal / _uniform` at their own 10⁶ points through the device adjustment), `test_psd_models`, `test_ppp_gpu` (block invariance; a lognormal Protassov test that never enters the host loop)",
          "%d × %s-point simulations in %.2f s inside the workflow" % (wf["nsims"], sci(wf["fft_points_per_simulation"]), wf["seconds"]["simulate"])),
         ("f3 predict", "`mtg_predict_kernel`, `mtg_apply_inverse_kernel`, `GP.predict`, `standarized_residuals`",
          "`test_gpmodelling_gpu` (dense algebra)", "O(N·J²) instead of celerite's dense N × N"),
