@@ -2163,12 +2163,11 @@ MTG_API int mtg_simulate_tk95(mtg_ctx *ctx, int64_t S, const double *theta, cons
         if (ctx->e13.kind != 0) {
             // A non-Gaussian flux PDF (simulator.py:65-140): the cut segments as rates on the fine grid, adjusted on the
             // device (mtg_e13.hip), then averaged into the epochs from the ADJUSTED series (start 0, no rescaling).
-            // (the segment kernel indexes its output by the GLOBAL series number: the chunk's buffer is handed over shifted)
             what = "E13 adjustment";
             e = ctx->e13.seg.reserve((size_t)chunk * seg_len * 8);
             if (e != hipSuccess) break;
             mtg_launch_tk95_segment(sc, s0, ctx->stream_base, nfft, seg_len, sim_dt, scale, mean_rate, series.as<double>(), seed,
-                                    given_starts, ctx->e13.seg.as<double>() - s0 * seg_len, s);
+                                    given_starts, ctx->e13.seg.as<double>(), s, /* out_first = */ s0);
             if (segments)   // (what the caller asked for: the segments as the reference hands them to its adjustment)
                 e = hipMemcpyAsync(d_seg.as<double>() + s0 * seg_len, ctx->e13.seg.p, (size_t)sc * seg_len * 8, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) break;

@@ -217,7 +217,7 @@ void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft
                               int64_t psd_rows, uint64_t seed, const double *given, double2 *X, hipStream_t);
 void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, uint64_t seed, const int64_t *given_start, double *out,
-                             hipStream_t);
+                             hipStream_t, int64_t out_first = 0);
 // KraftNoise (noise_models.py:81-150) for noise_kind 3: background counts and rate errors per epoch, and the posterior
 // median / half-width of the 68 % interval of the source counts for total counts 0 .. K - 1 (< threshold), [N][K]
 struct MtgKraftTables {

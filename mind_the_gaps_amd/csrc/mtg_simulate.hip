@@ -126,16 +126,17 @@ __device__ inline int64_t tk95_segment_start(int64_t sg, int64_t nfft, int64_t s
 }
 
 // The cut segment itself, as rates on the fine grid (the light curve the reference hands to its E13
-// amplitude adjustment before down-sampling): out[sg][j] = series[s][j0 + j] scale / dt + mean.
+// amplitude adjustment before down-sampling): out[sg - out_first][j] = series[s][j0 + j] scale / dt + mean  (out_first = 0: a buffer
+// for the whole set; = s0: one for this chunk alone).
 __global__ void __launch_bounds__(256)
 mtg_tk95_segment_kernel(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale, double mean_rate,
-                        const double *series, uint32_t seed_lo, uint32_t seed_hi, const int64_t *given_start, double *out)
+                        const double *series, uint32_t seed_lo, uint32_t seed_hi, const int64_t *given_start, double *out, int64_t out_first)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * seg_len) return;
     const int64_t s = i / seg_len, j = i % seg_len, sg = s0 + s;
     const int64_t j0 = tk95_segment_start(sg + sbase, nfft, seg_len, given_start ? given_start[sg] : -1, seed_lo, seed_hi);
-    out[sg * seg_len + j] = series[s * nfft + j0 + j] * scale / dt + mean_rate;
+    out[(sg - out_first) * seg_len + j] = series[s * nfft + j0 + j] * scale / dt + mean_rate;
 }
 
 // numpy.random.poisson's two regimes on a Philox stream keyed by (epoch, series): Knuth's multiplication below 10, the
@@ -365,11 +366,11 @@ void mtg_launch_tk95_spectrum(int64_t S, int64_t s0, int64_t sbase, int64_t nfft
 
 void mtg_launch_tk95_segment(int64_t S, int64_t s0, int64_t sbase, int64_t nfft, int64_t seg_len, double dt, double scale,
                              double mean_rate, const double *series, uint64_t seed, const int64_t *given_start, double *out,
-                             hipStream_t st)
+                             hipStream_t st, int64_t out_first)
 {
     const int64_t n = S * seg_len;
     hipLaunchKernelGGL(mtg_tk95_segment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, s0, sbase, nfft, seg_len,
-                       dt, scale, mean_rate, series, (uint32_t)seed, (uint32_t)(seed >> 32), given_start, out);
+                       dt, scale, mean_rate, series, (uint32_t)seed, (uint32_t)(seed >> 32), given_start, out, out_first);
 }
 
 void mtg_launch_tk95_observe(int64_t S, int64_t s0, int64_t sbase, int64_t N, int64_t nfft, int64_t seg_len, double dt, double scale,
