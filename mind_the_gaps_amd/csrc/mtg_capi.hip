@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <chrono>
@@ -107,6 +108,7 @@ struct mtg_ctx {
     // walker sharding (mtg_ensemble_shard_*): this rank evaluates rows [shard_lo, shard_hi) of every
     // half-step's proposals; the exchange brings everybody's log-probabilities before the accept step
     int shard_kind = 0;  // 0 none, 1 RCCL all-gather on the stream, 2 host callback
+    std::atomic<int> shard_generation{0};   // bumped by every (un)sharding: a communicator that comes up late is dropped
     int shard_rank = 0, shard_world = 1;
     int64_t shard_chunk = 0, shard_lo = 0, shard_hi = 0;
     void *shard_comm = nullptr;         // ncclComm_t
@@ -1390,6 +1392,7 @@ void shard_release(mtg_ctx *ctx)
     if (ctx->shard_h_st) (void)hipHostFree(ctx->shard_h_st);
     ctx->shard_comm = nullptr; ctx->shard_h_lnp = nullptr; ctx->shard_h_st = nullptr; ctx->shard_h_rows = 0;
     ctx->shard_kind = 0; ctx->shard_rank = 0; ctx->shard_world = 1;
+    ctx->shard_generation.fetch_add(1);
     ctx->shard_chunk = ctx->shard_lo = ctx->shard_hi = 0;
     ctx->shard_fn = nullptr; ctx->shard_user = nullptr;
 }
@@ -1484,7 +1487,14 @@ MTG_API int mtg_ensemble_shard_rccl(mtg_ctx *ctx, const void *id128, int rank, i
     Id128 id;
     memcpy(id.b, id128, sizeof id.b);
     void *comm = nullptr;
+    const int generation = ctx->shard_generation.load();
     RCCL_TRY(ctx, g_rccl.CommInitRank(&comm, world, id, rank));
+    if (ctx->shard_generation.load() != generation) {
+        // ncclCommInitRank took so long that the caller gave up and (un)sharded the context another way meanwhile
+        // (distributed.shard_device_ensemble's fall-back to the host-staged exchange): this communicator is nobody's
+        (void)g_rccl.CommDestroy(comm);
+        return fail(ctx, MTG_E_STATE, "mtg_ensemble_shard_rccl: the context was re-sharded while ncclCommInitRank was running");
+    }
     ctx->shard_comm = comm;
     ctx->shard_kind = 1;
     return MTG_OK;
