@@ -208,3 +208,26 @@ def test_host_side_noise_is_keyed_by_series_when_an_index_base_is_given():
     b = finish(2, 4, False)
     assert np.array_equal(a["rates"], b["rates"])                          # one stream, same state: the SAME noise
     assert not np.array_equal(a["rates"], whole["rates"][0:2])
+
+
+def test_kraft_tables_are_add_noise_per_epoch_and_count():
+    """Simulator._kraft_tables (what the device looks the faint epochs up in, mtg_set_simulate_kraft): for every epoch and
+    every total below kraft_counts, the posterior median and half the 68 % interval add_noise computes -- per distinct
+    background, whatever the number of epochs sharing it."""
+    from mind_the_gaps_amd.simulator import Simulator, kraft_interval, kraft_median
+    from mind_the_gaps_amd.models import DampedRandomWalk
+    times = np.cumsum(np.full(30, 1.0))
+    bkg_rate = np.where(np.arange(30) % 3 == 0, 4.0, 1.5)
+    sim = Simulator(DampedRandomWalk(1.0, -1.0, bounds=[(-10, 50), (-10, 10)]), times, 0.5, 50.0, "Gaussian", bkg_rate=bkg_rate,
+                    bkg_rate_err=0.5, extension_factor=2, random_state=3, kraft_counts=9.5)
+    med, half = sim._kraft_tables()
+    assert med.shape == half.shape == (30, 10)           # totals 0 .. 9 < 9.5
+    for n in (0, 1, 2, 29):
+        for c in (0, 1, 5, 9):
+            lo, hi = kraft_interval(c, sim._bkg_counts[n], 0.68)
+            assert med[n, c] == kraft_median(c, sim._bkg_counts[n]) and half[n, c] == (hi - lo) / 2.0
+    assert np.array_equal(med[0], med[3]) and not np.array_equal(med[0], med[1])
+    assert sim._kraft_tables()[0] is med                 # made once
+    for bad in (dict(adjust_on="gpu"), dict(transform="fftw")):
+        with pytest.raises(ValueError):
+            Simulator(DampedRandomWalk(1.0, -1.0, bounds=[(-10, 50), (-10, 10)]), times, 0.5, 50.0, **bad)
