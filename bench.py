@@ -40,6 +40,9 @@ The JSON line also carries
   clock_under_load: (N = 1) sclk and socket power from rocm-smi while sweeps are queued (the FP64 peak is quoted at 2.4 GHz);
   strong_shard_8  : (N = 1) one GPU on the share it gets of the 2000 light curves at 8 GPUs (250);
   null_model_sweep, config2_raw_kernel, other_configs (configs[0], [1], [2] + T_LRT, [4]),
+  workflow_config3_share_of_8_lognormal: (N = 1) one GPU's share of the Protassov test with a LOGNORMAL flux PDF: every simulated
+                    segment through the E13 amplitude / rank adjustment on the device (csrc/mtg_e13.hip) -- the loop never
+                    leaves the GPU (its `seconds.simulate` against `simulate_s_gaussian`);
   workflow_config3: (N = 1) the other SURVEY 8(d) figures: the null model's sweep beside the alternative's,
                     the raw kernel at B = 65 536 for DRW+SHO (J = 3 and zero-padded J = 4), the
                     single-light-curve chains, configs[3] as a whole workflow (scripts/config3_probe.py);
