@@ -27,16 +27,17 @@ os.makedirs(dst, exist_ok=True)
 
 
 def head_commit():
-    """The commit the profiled tree was at: `git rev-parse HEAD` here, or the .git_head file written before the tree
-    travelled to the GPU box (which has no .git)."""
+    """The commit the profiled tree was at: the .git_head file written before the tree travelled to the GPU box (which has
+    no .git) -- the profiles are summarised HERE, afterwards, possibly a few commits later -- else `git rev-parse HEAD`."""
     import subprocess
+    try:
+        return open(os.path.join(root, ".git_head")).read().strip()
+    except OSError:
+        pass
     try:
         return subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
     except Exception:
-        try:
-            return open(os.path.join(root, ".git_head")).read().strip()
-        except OSError:
-            return "unknown"
+        return "unknown"
 
 
 HEAD = head_commit()
